@@ -1,0 +1,134 @@
+"""Seeded synthetic inputs and weights.
+
+There is no network for real surveys or checkpoints, so benchmarks and tests
+use tiles of the shape the reference processes and random-init weights of the
+reference architecture with the upstream parameter names
+(``models/gnn.py`` + torch_geometric ``GATConv``/``BatchNorm`` key names).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import numpy as np
+
+NODATA = 1.0e6
+
+
+def synthetic_tile(h: int, w: int, seed: int, variant: str = "V0",
+                   with_uncertainty: bool = False):
+    """One synthetic depth tile.
+
+    depth[r,c] = -20 - 0.01 c - 0.005 r + 0.5 sin(2 pi r/37) cos(2 pi c/53) + 0.05 N(0,1),
+    0.5 % of cells spiked by +-U(1,5).  ``V0``: all valid.  ``V1``: 5 % iid invalid
+    plus one 16x16 hole (clipped to the tile), nodata 1e6 written into invalid cells.
+    Returns (depth f32 [h,w], valid_mask bool [h,w], uncertainty f32 [h,w] | None).
+    """
+    rng = np.random.default_rng(seed)
+    r = np.arange(h, dtype=np.float64)[:, None]
+    c = np.arange(w, dtype=np.float64)[None, :]
+    depth = (-20.0 - 0.01 * c - 0.005 * r
+             + 0.5 * np.sin(2 * np.pi * r / 37.0) * np.cos(2 * np.pi * c / 53.0)
+             + 0.05 * rng.standard_normal((h, w)))
+    spikes = rng.random((h, w)) < 0.005
+    mag = rng.uniform(1.0, 5.0, size=(h, w)) * rng.choice([-1.0, 1.0], size=(h, w))
+    depth = np.where(spikes, depth + mag, depth).astype(np.float32)
+    mask = np.ones((h, w), dtype=bool)
+    if variant == "V1":
+        mask &= rng.random((h, w)) >= 0.05
+        hh, hw_ = min(16, h), min(16, w)
+        r0 = int(rng.integers(0, h - hh + 1)); c0 = int(rng.integers(0, w - hw_ + 1))
+        mask[r0:r0 + hh, c0:c0 + hw_] = False
+        depth = np.where(mask, depth, np.float32(NODATA)).astype(np.float32)
+    elif variant != "V0":
+        raise ValueError(variant)
+    unc = None
+    if with_uncertainty:
+        unc = rng.uniform(0.05, 0.3, size=(h, w)).astype(np.float32)
+    return depth, mask, unc
+
+
+def synthetic_tile_batch(n: int, h: int, w: int, seed0: int, variant: str = "V0",
+                         with_uncertainty: bool = False):
+    ds, ms, us = [], [], []
+    for i in range(n):
+        d, m, u = synthetic_tile(h, w, seed0 + i, variant, with_uncertainty)
+        ds.append(d); ms.append(m); us.append(u)
+    depth = np.stack(ds); mask = np.stack(ms)
+    unc = np.stack(us) if with_uncertainty else None
+    return depth, mask, unc
+
+
+def vr_grid_stream(n: int, seed0: int = 1000, lo: int = 3, hi: int = 50):
+    """BASELINE config 4: refinement grids with dims iid uniform on {lo..hi}^2,
+    uncertainty U(0.05,0.3), mask variant V1-like 3 % invalid."""
+    out = []
+    for i in range(n):
+        rng = np.random.default_rng(seed0 + i)
+        h = int(rng.integers(lo, hi + 1)); w = int(rng.integers(lo, hi + 1))
+        d, m, u = synthetic_tile(h, w, seed0 + i, "V0", True)
+        inval = rng.random((h, w)) < 0.03
+        d = np.where(inval, np.float32(NODATA), d).astype(np.float32)
+        res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
+        out.append((d, u, (res, res)))
+    return out
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    a = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-a, a, size=shape).astype(np.float32)
+
+
+def synthetic_state_dict(in_channels: int = 7, hidden: int = 64, num_layers: int = 4,
+                         heads: int = 4, num_classes: int = 3, edge_dim: int = 3,
+                         predict_correction: bool = True, seed: int = 1234,
+                         legacy_lin_src: bool = False) -> "OrderedDict[str, np.ndarray]":
+    """Random-init weights under the reference's state_dict key names
+    (``training/trainer.py:809-829`` saves ``model.state_dict()``).
+
+    glorot-uniform lin / lin_edge / att_*, small random biases, NON-trivial BatchNorm
+    running statistics so that BN folding is exercised (SURVEY 8(c) 'Weights for tests').
+    ``legacy_lin_src``: emit ``lin_src.weight`` + ``lin_dst.weight`` (older
+    torch_geometric releases) instead of ``lin.weight``.
+    """
+    rng = np.random.default_rng(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def linear(prefix, out_f, in_f):
+        b = 1.0 / np.sqrt(in_f)
+        sd[prefix + ".weight"] = rng.uniform(-b, b, size=(out_f, in_f)).astype(np.float32)
+        sd[prefix + ".bias"] = rng.uniform(-b, b, size=(out_f,)).astype(np.float32)
+
+    linear("feature_extractor.mlp.0", hidden, in_channels)
+    linear("feature_extractor.mlp.3", hidden, hidden)
+    for l in range(num_layers):
+        last = l == num_layers - 1
+        H = 1 if last else heads
+        d_in = hidden if l == 0 else hidden * heads
+        p = f"gnn.convs.{l}."
+        w = _glorot(rng, (H * hidden, d_in), d_in, H * hidden)
+        if legacy_lin_src:
+            sd[p + "lin_src.weight"] = w
+            sd[p + "lin_dst.weight"] = w.copy()
+        else:
+            sd[p + "lin.weight"] = w
+        for nm in ("att_src", "att_dst", "att_edge"):
+            sd[p + nm] = _glorot(rng, (1, H, hidden), H, hidden)
+        sd[p + "lin_edge.weight"] = _glorot(rng, (H * hidden, edge_dim), edge_dim, H * hidden)
+        width = hidden if last else H * hidden
+        sd[p + "bias"] = (0.05 * rng.standard_normal(width)).astype(np.float32)
+        q = f"gnn.norms.{l}.module."
+        sd[q + "weight"] = rng.uniform(0.8, 1.2, size=width).astype(np.float32)
+        sd[q + "bias"] = (0.05 * rng.standard_normal(width)).astype(np.float32)
+        sd[q + "running_mean"] = (0.1 * rng.standard_normal(width)).astype(np.float32)
+        sd[q + "running_var"] = rng.uniform(0.5, 1.5, size=width).astype(np.float32)
+        sd[q + "num_batches_tracked"] = np.array(100, dtype=np.int64)
+    half = hidden // 2
+    linear("classification_head.mlp.0", half, hidden)
+    linear("classification_head.mlp.3", num_classes, half)
+    linear("confidence_head.mlp.0", half, hidden)
+    linear("confidence_head.mlp.3", 1, half)
+    if predict_correction:
+        linear("correction_head.mlp.0", half, hidden)
+        linear("correction_head.mlp.3", 1, half)
+    return sd

@@ -1,0 +1,171 @@
+"""CPU oracle: BathymetricGNN forward (restates reference ``models/gnn.py`` + the
+torch_geometric ``GATConv`` / ``BatchNorm`` / ``Batch`` semantics it calls).
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  **Parity unpinned**: the GATConv /
+BatchNorm arithmetic lives in ``torch_geometric`` (third party; the reference leaves the
+version unpinned -- ``environment.yml:50-52``, ``install.sh:58`` -- and it is not
+installable here), and the reference's tests assert no value at this boundary.  This file
+restates the published upstream algorithm (torch_geometric 2.3-2.6 ``GATConv`` with
+``edge_dim``) and is anchored on the reference's call sites:
+
+* ``models/gnn.py:52-68``   LocalFeatureExtractor: Linear, ReLU, Dropout, Linear (keys mlp.0 / mlp.3)
+* ``models/gnn.py:125-132`` GATConv(layer_in, 64, heads=H or 1 (last), dropout, edge_dim, concat=not last);
+  every other argument at its upstream default: negative_slope=0.2, add_self_loops=True,
+  fill_value='mean', bias=True
+* ``models/gnn.py:151-154`` BatchNorm(H*64) / BatchNorm(64) (wraps torch.nn.BatchNorm1d, eps 1e-5)
+* ``models/gnn.py:173-188`` conv -> norm -> (ReLU, dropout) except last layer
+* ``models/gnn.py:191-260`` heads: Linear(64,32) ReLU Dropout Linear(32,k) [Sigmoid for confidence]
+* ``models/gnn.py:386-406`` forward: logits, softmax, argmax, confidence, correction
+* ``models/gnn.py:427-449`` predict: action / needs_review / auto_correct
+
+The torch op sequence below is the one torch_geometric issues on a CPU tensor
+(index_select / scatter-amax / exp / index_add), with edges kept in the given order and the
+N self-loops appended last, so the float32 mode reproduces the summation order of the real
+library; the float64 mode is the "truth" used to report absolute error.
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(v, dtype):
+    if isinstance(v, torch.Tensor):
+        return v.detach().to("cpu", dtype)
+    return torch.as_tensor(np.asarray(v)).to(dtype)
+
+
+def _lin_weight(sd: Mapping, prefix: str, dtype):
+    # newer releases: lin.weight; older: lin_src.weight (lin_dst is an alias of it)
+    for k in (prefix + "lin.weight", prefix + "lin_src.weight"):
+        if k in sd:
+            return _t(sd[k], dtype)
+    raise KeyError(prefix + "lin.weight")
+
+
+def num_layers_of(sd: Mapping) -> int:
+    n = 0
+    while (f"gnn.convs.{n}.att_src") in sd:
+        n += 1
+    return n
+
+
+def gat_conv(x, edge_index, edge_attr, sd: Mapping, prefix: str, concat: bool, dtype,
+             return_alpha: bool = False):
+    """One torch_geometric GATConv forward (eval mode)."""
+    N = x.shape[0]
+    W = _lin_weight(sd, prefix, dtype)                    # [H*C, D]
+    att_src = _t(sd[prefix + "att_src"], dtype)           # [1,H,C]
+    att_dst = _t(sd[prefix + "att_dst"], dtype)
+    att_edge = _t(sd[prefix + "att_edge"], dtype)
+    W_e = _t(sd[prefix + "lin_edge.weight"], dtype)       # [H*C, edge_dim]
+    bias = _t(sd[prefix + "bias"], dtype)
+    H, C = att_src.shape[1], att_src.shape[2]
+
+    xs = (x @ W.t()).view(N, H, C)
+    a_s = (xs * att_src).sum(-1)                          # [N,H]
+    a_d = (xs * att_dst).sum(-1)
+
+    src, dst = edge_index[0], edge_index[1]
+    # remove_self_loops, then add_self_loops(fill_value='mean')
+    keep = src != dst
+    src, dst, ea = src[keep], dst[keep], edge_attr[keep]
+    loop_sum = torch.zeros(N, ea.shape[1], dtype=dtype).index_add_(0, dst, ea)
+    cnt = torch.zeros(N, dtype=dtype).index_add_(0, dst, torch.ones(dst.shape[0], dtype=dtype))
+    loop_attr = loop_sum / cnt.clamp(min=1).unsqueeze(-1)
+    ar = torch.arange(N, dtype=src.dtype)
+    src2 = torch.cat([src, ar]); dst2 = torch.cat([dst, ar]); ea2 = torch.cat([ea, loop_attr], 0)
+
+    a_e = ((ea2 @ W_e.t()).view(-1, H, C) * att_edge).sum(-1)      # [E',H]
+    e = F.leaky_relu(a_s.index_select(0, src2) + a_d.index_select(0, dst2) + a_e, 0.2)
+    m = torch.full((N, H), float("-inf"), dtype=dtype)
+    m = m.scatter_reduce(0, dst2.unsqueeze(-1).expand(-1, H), e, reduce="amax", include_self=True)
+    p = torch.exp(e - m.index_select(0, dst2))
+    s = torch.zeros(N, H, dtype=dtype).index_add_(0, dst2, p)
+    alpha = p / (s.index_select(0, dst2) + 1e-16)
+    msg = alpha.unsqueeze(-1) * xs.index_select(0, src2)           # [E',H,C]
+    out = torch.zeros(N, H, C, dtype=dtype).index_add_(0, dst2, msg)
+    out = out.reshape(N, H * C) if concat else out.mean(dim=1)
+    out = out + bias
+    if return_alpha:
+        return out, alpha, src2, dst2
+    return out
+
+
+def batch_norm_eval(x, sd: Mapping, prefix: str, dtype, eps: float = 1e-5):
+    w = _t(sd[prefix + "weight"], dtype); b = _t(sd[prefix + "bias"], dtype)
+    rm = _t(sd[prefix + "running_mean"], dtype); rv = _t(sd[prefix + "running_var"], dtype)
+    return F.batch_norm(x, rm, rv, w, b, False, 0.1, eps)
+
+
+def _mlp2(x, sd, p0, p1, dtype):
+    h = F.relu(F.linear(x, _t(sd[p0 + ".weight"], dtype), _t(sd[p0 + ".bias"], dtype)))
+    return F.linear(h, _t(sd[p1 + ".weight"], dtype), _t(sd[p1 + ".bias"], dtype))
+
+
+def backbone(x, edge_index, edge_attr, sd: Mapping, dtype):
+    """feature extractor + GNN backbone -> [N, hidden]"""
+    L = num_layers_of(sd)
+    h = _mlp2(x, sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", dtype)
+    for l in range(L):
+        last = l == L - 1
+        h = gat_conv(h, edge_index, edge_attr, sd, f"gnn.convs.{l}.", concat=not last, dtype=dtype)
+        h = batch_norm_eval(h, sd, f"gnn.norms.{l}.module.", dtype)
+        if not last:
+            h = F.relu(h)
+    return h
+
+
+def forward(sd: Mapping, x, edge_index, edge_attr, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """BathymetricGNN.forward (models/gnn.py:360-408), eval mode."""
+    x = _t(x, dtype); edge_attr = _t(edge_attr, dtype)
+    edge_index = _t(edge_index, torch.int64)
+    with torch.no_grad():
+        h = backbone(x, edge_index, edge_attr, sd, dtype)
+        logits = _mlp2(h, sd, "classification_head.mlp.0", "classification_head.mlp.3", dtype)
+        probs = F.softmax(logits, dim=-1)
+        out = {
+            "class_logits": logits,
+            "class_probs": probs,
+            "predicted_class": torch.argmax(probs, dim=-1),
+            "confidence": torch.sigmoid(
+                _mlp2(h, sd, "confidence_head.mlp.0", "confidence_head.mlp.3", dtype)).squeeze(-1),
+            "hidden": h,
+        }
+        if "correction_head.mlp.0.weight" in sd:
+            out["correction"] = _mlp2(h, sd, "correction_head.mlp.0", "correction_head.mlp.3", dtype).squeeze(-1)
+    return out
+
+
+def predict(sd: Mapping, x, edge_index, edge_attr, auto_correct_threshold: float = 0.85,
+            review_threshold: float = 0.6, dtype=torch.float32):
+    """BathymetricGNN.predict (models/gnn.py:410-451)."""
+    out = forward(sd, x, edge_index, edge_attr, dtype)
+    conf, cls = out["confidence"], out["predicted_class"]
+    action = torch.zeros_like(cls)
+    action[(cls == 2) & (conf > auto_correct_threshold)] = 1
+    action[conf < review_threshold] = 2
+    out["action"] = action
+    out["needs_review"] = action == 2
+    out["auto_correct"] = action == 1
+    return out
+
+
+def process_tile(sd: Mapping, g, auto_correct_threshold=0.85, review_threshold=0.6,
+                 dtype=torch.float32):
+    """BathymetricPipeline._process_tile (models/pipeline.py:243-314) on an oracle graph:
+    returns classification / confidence / correction grids (fill 0.0)."""
+    from . import graph_cpu
+    shape = g.grid_shape
+    out = predict(sd, g.x, g.edge_index, g.edge_attr, auto_correct_threshold, review_threshold, dtype)
+    cls = graph_cpu.graph_to_grid(g, out["predicted_class"].float().numpy(), 0.0)
+    conf = graph_cpu.graph_to_grid(g, out["confidence"].float().numpy(), 0.0)
+    corr = np.zeros(shape, np.float32)
+    if "correction" in out:
+        nc = graph_cpu.graph_to_grid(g, out["correction"].float().numpy(), 0.0)
+        ls = graph_cpu.graph_to_grid(g, g.local_std, 0.0)
+        corr = nc * np.maximum(ls, np.float32(0.01))      # config/constants.py:12
+    return {"classification": cls, "confidence": conf, "correction": corr}

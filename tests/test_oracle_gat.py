@@ -1,0 +1,108 @@
+"""Self-consistency of oracle/gat_cpu.py (parity unpinned: torch_geometric is absent, see
+oracle/__init__.py).  An independent pure-Python per-node statement of the published GATConv
+algorithm, and the oracle-free properties of SURVEY 8(c)."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gat_cpu, graph_cpu
+
+synth = importlib.import_module("bathymetric_gnn_amd.synthetic")
+
+
+def _gat_layer_loops(x, ei, ea, W, a_s, a_d, a_e, W_e, bias, H, C, concat):
+    """Per-node Python-loop GATConv (float64), written from the paper/upstream docs, sharing no
+    code with gat_cpu.gat_conv."""
+    N = x.shape[0]
+    xs = x @ W.T
+    out = np.zeros((N, H, C))
+    for i in range(N):
+        inc = [(int(ei[0, e]), ea[e]) for e in range(ei.shape[1]) if ei[1, e] == i and ei[0, e] != i]
+        loop = np.mean([a for _, a in inc], axis=0) if inc else np.zeros(ea.shape[1])
+        inc = inc + [(i, loop)]
+        for h in range(H):
+            sl = slice(h * C, (h + 1) * C)
+            logits = []
+            for j, attr in inc:
+                v = (xs[j, sl] @ a_s[h]) + (xs[i, sl] @ a_d[h]) + ((W_e[sl] @ attr) @ a_e[h])
+                logits.append(v if v > 0 else 0.2 * v)
+            m = max(logits)
+            p = [math.exp(v - m) for v in logits]
+            z = sum(p) + 1e-16
+            for (j, _), pj in zip(inc, p):
+                out[i, h] += (pj / z) * xs[j, sl]
+    out = out.reshape(N, H * C) if concat else out.mean(1)
+    return out + bias
+
+
+def test_known_answer_small_graph():
+    d = (np.arange(9, dtype=np.float32).reshape(3, 3)) ** 1.5
+    m = np.ones((3, 3), bool); m[0, 2] = False
+    g = graph_cpu.build_graph(d.astype(np.float32), m, resolution=(0.5, 1.0))
+    sd = synth.synthetic_state_dict(in_channels=7, hidden=8, num_layers=2, heads=2, seed=3)
+    x64 = torch.as_tensor(g.x, dtype=torch.float64)
+    h = gat_cpu._mlp2(x64, sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", torch.float64)
+    for l, (H, concat) in enumerate([(2, True), (1, False)]):
+        p = f"gnn.convs.{l}."
+        ref = _gat_layer_loops(
+            h.numpy(), g.edge_index, g.edge_attr.astype(np.float64),
+            sd[p + "lin.weight"].astype(np.float64), sd[p + "att_src"][0].astype(np.float64),
+            sd[p + "att_dst"][0].astype(np.float64), sd[p + "att_edge"][0].astype(np.float64),
+            sd[p + "lin_edge.weight"].astype(np.float64), sd[p + "bias"].astype(np.float64), H, 8, concat)
+        got = gat_cpu.gat_conv(h, torch.as_tensor(g.edge_index), torch.as_tensor(g.edge_attr, dtype=torch.float64),
+                               sd, p, concat, torch.float64)
+        np.testing.assert_allclose(got.numpy(), ref, rtol=1e-11, atol=1e-12)
+        h = torch.relu(gat_cpu.batch_norm_eval(got, sd, f"gnn.norms.{l}.module.", torch.float64))
+
+
+def test_alpha_rows_sum_to_one_and_isolated_node():
+    z = np.load("tests/golden/A2_4x4_isolated.npz")
+    g = graph_cpu.build_graph(z["depth"], z["mask"].astype(bool), z["unc"], (1.0, 1.0))
+    sd = synth.synthetic_state_dict(in_channels=8, seed=5)
+    x = torch.randn(g.num_nodes, 64, dtype=torch.float64)
+    out, alpha, src, dst = gat_cpu.gat_conv(x, torch.as_tensor(g.edge_index),
+                                            torch.as_tensor(g.edge_attr, dtype=torch.float64), sd,
+                                            "gnn.convs.0.", True, torch.float64, return_alpha=True)
+    s = torch.zeros(g.num_nodes, 4, dtype=torch.float64).index_add_(0, dst, alpha)
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-12)
+    # node 0 is isolated (in-degree 0): only its mean-filled (zero) self loop -> out = xW + b
+    W = torch.as_tensor(sd["gnn.convs.0.lin.weight"], dtype=torch.float64)
+    exp0 = x[0] @ W.t() + torch.as_tensor(sd["gnn.convs.0.bias"], dtype=torch.float64)
+    assert torch.allclose(out[0], exp0, atol=1e-12)
+
+
+def test_edge_permutation_and_batching_invariance():
+    tiles = [synth.synthetic_tile(12, 9, 11, "V1"), synth.synthetic_tile(7, 13, 12, "V0")]
+    gs = [graph_cpu.build_graph(d, m, None, (0.5, 0.5)) for d, m, _ in tiles]
+    sd = synth.synthetic_state_dict(seed=9)
+    singles = [gat_cpu.forward(sd, g.x, g.edge_index, g.edge_attr)["class_logits"] for g in gs]
+    bx, bei, bea, _, bb = graph_cpu.batch_graphs(gs)
+    batched = gat_cpu.forward(sd, bx, bei, bea)["class_logits"]
+    assert torch.allclose(torch.cat(singles), batched, atol=2e-6)
+    perm = np.random.default_rng(0).permutation(bei.shape[1])
+    permuted = gat_cpu.forward(sd, bx, bei[:, perm], bea[perm])["class_logits"]
+    assert torch.allclose(batched, permuted, atol=1e-5)
+
+
+def test_fp32_close_to_fp64_and_predict_flags():
+    d, m, _ = synth.synthetic_tile(24, 24, 3, "V1")
+    g = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    sd = synth.synthetic_state_dict(seed=1234)
+    o32 = gat_cpu.predict(sd, g.x, g.edge_index, g.edge_attr)
+    o64 = gat_cpu.forward(sd, g.x, g.edge_index, g.edge_attr, dtype=torch.float64)
+    assert (o32["class_logits"].double() - o64["class_logits"]).abs().max() < 1e-4
+    assert o32["predicted_class"].dtype == torch.int64 and o32["action"].dtype == torch.int64
+    a = o32["action"]; c = o32["confidence"]; k = o32["predicted_class"]
+    assert torch.equal(a == 2, c < 0.6)
+    assert torch.equal(a == 1, (k == 2) & (c > 0.85) & ~(c < 0.6))
+
+
+def test_legacy_lin_src_keys():
+    d, m, _ = synth.synthetic_tile(8, 8, 1, "V0")
+    g = graph_cpu.build_graph(d, m, None, (1.0, 1.0))
+    a = gat_cpu.forward(synth.synthetic_state_dict(seed=2), g.x, g.edge_index, g.edge_attr)
+    b = gat_cpu.forward(synth.synthetic_state_dict(seed=2, legacy_lin_src=True), g.x, g.edge_index, g.edge_attr)
+    assert torch.equal(a["class_logits"], b["class_logits"])
