@@ -1,0 +1,564 @@
+// C ABI of libbgnn_hip.so (declared in include/bgnn.h): contexts, weights, graph handles and the
+// forward / fused-inference orchestration.  Host code only; kernels live in the other TUs.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "bgnn_internal.h"
+
+namespace bgnn {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- pool -----------------------------------------------------------------------------------
+int DevPool::alloc(size_t bytes, void **out) {
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  auto it = free_blocks.lower_bound(bytes);
+  if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+    *out = it->second;
+    live[*out] = it->first;
+    free_blocks.erase(it);
+    return BGNN_OK;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    trim();
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return BGNN_ERR_NOMEM;
+  }
+  total_bytes += bytes;
+  live[p] = bytes;
+  *out = p;
+  return BGNN_OK;
+}
+
+void DevPool::release(void *p) {
+  if (!p) return;
+  auto it = live.find(p);
+  if (it == live.end()) return;
+  free_blocks.emplace(it->second, p);
+  live.erase(it);
+}
+
+void DevPool::trim() {
+  for (auto &kv : free_blocks) {
+    (void)hipFree(kv.second);
+    total_bytes -= kv.first;
+  }
+  free_blocks.clear();
+}
+
+int ctx_workspace(bgnn_ctx *ctx, int slot, size_t bytes, void **out) {
+  if (ctx->ws_bytes[slot] < bytes) {
+    if (ctx->ws[slot]) {
+      BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      BGNN_HIP_CHECK(hipFree(ctx->ws[slot]));
+      ctx->ws[slot] = nullptr;
+      ctx->ws_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&ctx->ws[slot], want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->pool.trim();
+      want = bytes;
+      e = hipMalloc(&ctx->ws[slot], want);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+      return BGNN_ERR_NOMEM;
+    }
+    ctx->ws_bytes[slot] = want;
+  }
+  *out = ctx->ws[slot];
+  return BGNN_OK;
+}
+
+int ctx_upload(bgnn_ctx *ctx, const void *host, size_t bytes, void *dev) {
+  BGNN_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return BGNN_OK;
+}
+
+ProfScope::ProfScope(bgnn_ctx *c, int kernel) : ctx(c), idx(-1) {
+  if (!(c->prof_mask & (1u << kernel))) return;
+  ProfRecord r;
+  r.kernel = kernel;
+  hipEvent_t ev[2];
+  for (int i = 0; i < 2; ++i) {
+    if (!c->event_pool.empty()) { ev[i] = c->event_pool.back(); c->event_pool.pop_back(); }
+    else if (hipEventCreate(&ev[i]) != hipSuccess) return;
+  }
+  r.start = ev[0]; r.stop = ev[1];
+  (void)hipEventRecord(r.start, c->stream);
+  c->prof_records.push_back(r);
+  idx = (int)c->prof_records.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(ctx->prof_records[idx].stop, ctx->stream);
+}
+
+__global__ void copy_rows_kernel(const float *src, float *dst, int width, const int64_t *d_m) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < *d_m * width) dst[i] = src[i];
+}
+
+}  // namespace bgnn
+
+using namespace bgnn;
+
+extern "C" {
+
+int bgnn_abi_version(void) { return BGNN_ABI_VERSION; }
+const char *bgnn_last_error(void) { return g_err; }
+
+// ---- context ----------------------------------------------------------------------------------
+int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
+  BGNN_REQUIRE(out != nullptr, "bgnn_ctx_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return BGNN_ERR_HIP;
+  }
+  BGNN_REQUIRE(device >= 0 && device < n, "bgnn_ctx_create: device %d out of range (have %d)", device, n);
+  BGNN_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  BGNN_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  bgnn_ctx *c = new bgnn_ctx();
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+    c->owns_stream = false;
+  } else {
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+      delete c;
+      set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+      return BGNN_ERR_HIP;
+    }
+    c->owns_stream = true;
+  }
+  *out = c;
+  return BGNN_OK;
+}
+
+int bgnn_ctx_destroy(bgnn_ctx *ctx) {
+  if (!ctx) return BGNN_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &r : ctx->prof_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 6; ++i) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  ctx->pool.trim();
+  for (auto &kv : ctx->pool.live) (void)hipFree(kv.first);
+  if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return BGNN_OK;
+}
+
+int bgnn_ctx_synchronize(bgnn_ctx *ctx) {
+  BGNN_REQUIRE(ctx, "ctx is NULL");
+  BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return BGNN_OK;
+}
+
+void *bgnn_ctx_stream(bgnn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int bgnn_ctx_profile(bgnn_ctx *ctx, uint32_t kernel_mask) {
+  BGNN_REQUIRE(ctx, "ctx is NULL");
+  ctx->prof_mask = kernel_mask;
+  return BGNN_OK;
+}
+
+int bgnn_ctx_profile_read(bgnn_ctx *ctx, double *ms, int64_t *launches) {
+  BGNN_REQUIRE(ctx && ms && launches, "bgnn_ctx_profile_read: NULL argument");
+  BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (auto &r : ctx->prof_records) {
+    float t = 0.f;
+    BGNN_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
+    ms[r.kernel] += (double)t;
+    launches[r.kernel] += 1;
+    ctx->event_pool.push_back(r.start);
+    ctx->event_pool.push_back(r.stop);
+  }
+  ctx->prof_records.clear();
+  return BGNN_OK;
+}
+
+// ---- model ------------------------------------------------------------------------------------
+static int head_count(const bgnn_model_desc *d) { return d->predict_correction ? 3 : 2; }
+
+size_t bgnn_model_weight_count(const bgnn_model_desc *d) {
+  if (!d) return 0;
+  const size_t hid = d->hidden, in = d->in_channels, hh = hid / 2;
+  size_t n = hid * in + hid + hid * hid + hid;
+  for (int l = 0; l < d->num_layers; ++l) {
+    const bool last = l == d->num_layers - 1;
+    const size_t H = last ? 1 : d->heads;
+    const size_t D = l == 0 ? hid : hid * d->heads;
+    const size_t HC = H * hid, W = last ? hid : HC;
+    n += HC * D + 3 * HC + HC * d->edge_dim + W + 4 * W;
+  }
+  n += hh * hid + hh + (size_t)d->num_classes * hh + d->num_classes;
+  n += hh * hid + hh + hh + 1;
+  if (d->predict_correction) n += hh * hid + hh + hh + 1;
+  return n;
+}
+
+int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
+  BGNN_REQUIRE(ctx && d && w && out, "bgnn_model_create: NULL argument");
+  BGNN_REQUIRE(d->hidden == 32 || d->hidden == 64, "hidden_channels=%d unsupported (32 or 64)", d->hidden);
+  BGNN_REQUIRE(d->in_channels >= 1 && d->in_channels <= 8, "in_channels=%d unsupported (1..8)", d->in_channels);
+  BGNN_REQUIRE(d->num_layers >= 1 && d->num_layers <= 64, "num_gnn_layers=%d unsupported", d->num_layers);
+  BGNN_REQUIRE(d->heads >= 1 && d->heads * d->hidden <= 256 && (d->heads & (d->heads - 1)) == 0,
+               "heads=%d unsupported (power of two, heads*hidden <= 256)", d->heads);
+  BGNN_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 4, "edge_dim=%d unsupported (1..4)", d->edge_dim);
+  BGNN_REQUIRE(d->num_classes >= 1 && d->num_classes <= 16, "num_classes=%d unsupported", d->num_classes);
+  BGNN_REQUIRE(n_weights == bgnn_model_weight_count(d), "weight blob has %zu floats, expected %zu", n_weights,
+               bgnn_model_weight_count(d));
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  const int hid = d->hidden, in = d->in_channels, hh = hid / 2, L = d->num_layers, ED = d->edge_dim;
+  const int nh = head_count(d);
+  const int HT = ((nh * hh + 31) / 32) * 32;
+
+  std::vector<float> pk;
+  auto reserve = [&](size_t n) { size_t o = pk.size(); pk.resize(o + ((n + 3) & ~(size_t)3), 0.0f); return o; };
+  const float *p = w;
+  // feature extractor
+  size_t o_fe_W0t = reserve((size_t)8 * hid), o_fe_b0 = reserve(hid);
+  for (int o = 0; o < hid; ++o) for (int i = 0; i < in; ++i) pk[o_fe_W0t + (size_t)i * hid + o] = p[(size_t)o * in + i];
+  p += (size_t)hid * in;
+  std::copy(p, p + hid, pk.begin() + o_fe_b0); p += hid;
+  size_t o_fe_W1t = reserve((size_t)hid * hid), o_fe_b1 = reserve(hid);
+  for (int o = 0; o < hid; ++o) for (int i = 0; i < hid; ++i) pk[o_fe_W1t + (size_t)i * hid + o] = p[(size_t)o * hid + i];
+  p += (size_t)hid * hid;
+  std::copy(p, p + hid, pk.begin() + o_fe_b1); p += hid;
+  struct LOff { size_t Wt, as, ad, V, sc, sh; };
+  std::vector<LOff> lo(L);
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    const int H = last ? 1 : d->heads, D = l == 0 ? hid : hid * d->heads, HC = H * hid, W = last ? hid : HC;
+    lo[l].Wt = reserve((size_t)D * HC);
+    for (int o = 0; o < HC; ++o) for (int i = 0; i < D; ++i) pk[lo[l].Wt + (size_t)i * HC + o] = p[(size_t)o * D + i];
+    p += (size_t)HC * D;
+    lo[l].as = reserve(HC); std::copy(p, p + HC, pk.begin() + lo[l].as); p += HC;
+    lo[l].ad = reserve(HC); std::copy(p, p + HC, pk.begin() + lo[l].ad); p += HC;
+    const float *att_edge = p; p += HC;
+    const float *W_e = p; p += (size_t)HC * ED;
+    lo[l].V = reserve((size_t)H * ED);
+    for (int h = 0; h < H; ++h)
+      for (int f = 0; f < ED; ++f) {
+        double s = 0.0;
+        for (int c = 0; c < hid; ++c) s += (double)att_edge[h * hid + c] * (double)W_e[(size_t)(h * hid + c) * ED + f];
+        pk[lo[l].V + (size_t)h * ED + f] = (float)s;
+      }
+    const float *bias = p; p += W;
+    const float *bw = p; p += W;
+    const float *bb = p; p += W;
+    const float *rm = p; p += W;
+    const float *rv = p; p += W;
+    lo[l].sc = reserve(W); lo[l].sh = reserve(W);
+    for (int c = 0; c < W; ++c) {
+      const double s = (double)bw[c] / std::sqrt((double)rv[c] + (double)d->bn_eps);
+      pk[lo[l].sc + c] = (float)s;
+      pk[lo[l].sh + c] = (float)(((double)bias[c] - (double)rm[c]) * s + (double)bb[c]);
+    }
+  }
+  // heads: first layers concatenated column-wise, second layers packed
+  size_t o_hW0t = reserve((size_t)hid * HT), o_hb0 = reserve(HT);
+  size_t o_hW1 = reserve((size_t)d->num_classes * hh + 2 * hh), o_hb1 = reserve(d->num_classes + 2);
+  for (int k = 0; k < nh; ++k) {
+    for (int o = 0; o < hh; ++o) for (int i = 0; i < hid; ++i) pk[o_hW0t + (size_t)i * HT + k * hh + o] = p[(size_t)o * hid + i];
+    p += (size_t)hh * hid;
+    std::copy(p, p + hh, pk.begin() + o_hb0 + k * hh); p += hh;
+    const int nout = k == 0 ? d->num_classes : 1;
+    const size_t woff = k == 0 ? 0 : (size_t)d->num_classes * hh + (size_t)(k - 1) * hh;
+    std::copy(p, p + (size_t)nout * hh, pk.begin() + o_hW1 + woff); p += (size_t)nout * hh;
+    const size_t boff = k == 0 ? 0 : d->num_classes + (k - 1);
+    std::copy(p, p + nout, pk.begin() + o_hb1 + boff); p += nout;
+  }
+  if ((size_t)(p - w) != n_weights) {
+    set_error("internal: weight unpack consumed %zu of %zu floats", (size_t)(p - w), n_weights);
+    return BGNN_ERR_INVALID;
+  }
+
+  bgnn_model *m = new bgnn_model();
+  m->ctx = ctx; m->desc = *d; m->blob_floats = pk.size();
+  hipError_t e = hipMalloc((void **)&m->blob, pk.size() * sizeof(float));
+  if (e != hipSuccess) { delete m; set_error("hipMalloc(model) failed: %s", hipGetErrorString(e)); return BGNN_ERR_NOMEM; }
+  e = hipMemcpy(m->blob, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(m->blob); delete m; set_error("hipMemcpy(model) failed: %s", hipGetErrorString(e)); return BGNN_ERR_HIP; }
+  m->fe_W0t = m->blob + o_fe_W0t; m->fe_b0 = m->blob + o_fe_b0; m->fe_W1t = m->blob + o_fe_W1t; m->fe_b1 = m->blob + o_fe_b1;
+  m->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    BgnnLayer &Ly = m->layers[l];
+    Ly.heads = last ? 1 : d->heads; Ly.d_in = l == 0 ? hid : hid * d->heads;
+    Ly.width = last ? hid : Ly.heads * hid; Ly.concat = !last;
+    Ly.Wt = m->blob + lo[l].Wt; Ly.att_src = m->blob + lo[l].as; Ly.att_dst = m->blob + lo[l].ad;
+    Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
+  }
+  m->head_hidden_total = HT;
+  m->hd_W0t = m->blob + o_hW0t; m->hd_b0 = m->blob + o_hb0; m->hd_W1 = m->blob + o_hW1; m->hd_b1 = m->blob + o_hb1;
+  *out = m;
+  return BGNN_OK;
+}
+
+int bgnn_model_destroy(bgnn_model *m) {
+  if (!m) return BGNN_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  (void)hipFree(m->blob);
+  delete m;
+  return BGNN_OK;
+}
+
+// ---- graph ------------------------------------------------------------------------------------
+static void graph_free(bgnn_graph *g) {
+  DevPool &P = g->ctx->pool;
+  P.release(g->d_tiles); P.release(g->d_items); P.release(g->d_node_id); P.release(g->d_cell_of_node);
+  P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
+  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm);
+  delete g;
+}
+
+static int validate_opts(const bgnn_graph_opts *o) {
+  BGNN_REQUIRE(o->connectivity == 4 || o->connectivity == 8 || o->connectivity == 16,
+               "Unknown connectivity: %d", o->connectivity);
+  BGNN_REQUIRE(o->n_node_features >= 0 && o->n_node_features <= 8, "n_node_features=%d out of range", o->n_node_features);
+  BGNN_REQUIRE(o->n_edge_features >= 1 && o->n_edge_features <= 4, "n_edge_features=%d out of range (1..4)", o->n_edge_features);
+  for (int i = 0; i < o->n_node_features; ++i)
+    BGNN_REQUIRE(o->node_features[i] >= 0 && o->node_features[i] <= 7, "bad node feature id %d", o->node_features[i]);
+  for (int i = 0; i < o->n_edge_features; ++i)
+    BGNN_REQUIRE(o->edge_features[i] >= 0 && o->edge_features[i] <= 3, "bad edge feature id %d", o->edge_features[i]);
+  return BGNN_OK;
+}
+
+int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out) {
+  BGNN_REQUIRE(ctx && tiles && opts && out, "bgnn_graph_build: NULL argument");
+  BGNN_REQUIRE(tiles->n_tiles >= 1, "bgnn_graph_build: n_tiles=%d", tiles->n_tiles);
+  BGNN_REQUIRE(tiles->hw && tiles->resolution && tiles->depth && tiles->mask, "bgnn_graph_build: NULL tile array");
+  BGNN_TRY(validate_opts(opts));
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  bgnn_graph *g = new bgnn_graph();
+  g->ctx = ctx; g->kind = 0; g->n_tiles = tiles->n_tiles;
+  g->K = opts->connectivity; g->ED = opts->n_edge_features; g->include_self_loops = opts->include_self_loops ? 1 : 0;
+  g->has_unc = tiles->uncertainty ? 1 : 0;
+  // feature count (see launch_graph_build for the column rule)
+  {
+    int nf = 0; bool listed = false;
+    for (int i = 0; i < opts->n_node_features; ++i) {
+      if (opts->node_features[i] == BGNN_NF_UNCERTAINTY) { listed = true; if (!tiles->uncertainty) continue; }
+      ++nf;
+    }
+    if (tiles->uncertainty && !listed) ++nf;
+    if (nf > 8 || nf < 1) { delete g; set_error("node feature count %d out of range (1..8)", nf); return BGNN_ERR_INVALID; }
+    g->F = nf;
+  }
+  int64_t cells = 0;
+  std::vector<BgnnWorkItem> items;
+  g->h_tiles.resize(tiles->n_tiles);
+  for (int t = 0; t < tiles->n_tiles; ++t) {
+    const int h = tiles->hw[2 * t], w = tiles->hw[2 * t + 1];
+    if (h < 2 || w < 2) {
+      // np.gradient needs >= 2 samples per axis: the reference raises ValueError here too
+      delete g;
+      set_error("Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are "
+                "required. (tile %d is %dx%d)", t, h, w);
+      return BGNN_ERR_INVALID;
+    }
+    BgnnTileMeta &m = g->h_tiles[t];
+    m.h = h; m.w = w; m.cell_off = (int32_t)cells; m.pad = 0;
+    m.rx = tiles->resolution[2 * t]; m.ry = tiles->resolution[2 * t + 1];
+    cells += (int64_t)h * w;
+    if (cells >= ((int64_t)1 << 30)) { delete g; set_error("batch too large: 2^30 cells or more; split it"); return BGNN_ERR_INVALID; }
+    int rows_per = std::max(1, 2048 / w);
+    for (int r0 = 0; r0 < h; r0 += rows_per) items.push_back({t, r0, std::min(rows_per, h - r0), 0});
+  }
+  g->total_cells = (int32_t)cells; g->row_capacity = (int32_t)cells; g->n_items = (int32_t)items.size();
+  DevPool &P = ctx->pool;
+  int rc = BGNN_OK;
+#define GALLOC(ptr, type, count) if (rc == BGNN_OK) { void *_p = nullptr; rc = P.alloc((size_t)(count) * sizeof(type), &_p); ptr = (type *)_p; }
+  GALLOC(g->d_tiles, BgnnTileMeta, g->n_tiles)
+  GALLOC(g->d_items, BgnnWorkItem, g->n_items)
+  GALLOC(g->d_node_id, int32_t, cells)
+  GALLOC(g->d_cell_of_node, int32_t, cells)
+  GALLOC(g->d_counts, int64_t, 4)
+  GALLOC(g->d_x8, float, cells * 8)
+  GALLOC(g->d_local_std, float, cells)
+  GALLOC(g->d_nbr, int32_t, cells * g->K)
+  GALLOC(g->d_eattr, float, cells * g->K * g->ED)
+#undef GALLOC
+  if (rc == BGNN_OK) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
+  if (rc == BGNN_OK) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
+  if (rc == BGNN_OK) rc = launch_graph_build(ctx, g, tiles, opts);
+  if (rc != BGNN_OK) { graph_free(g); return rc; }
+  *out = g;
+  return BGNN_OK;
+}
+
+int bgnn_graph_from_edges(bgnn_ctx *ctx, int64_t n_nodes, int32_t n_feat, const float *x, int64_t n_edges,
+                          const int64_t *edge_index, int32_t edge_dim, const float *edge_attr, bgnn_graph **out) {
+  BGNN_REQUIRE(ctx && out, "bgnn_graph_from_edges: NULL argument");
+  BGNN_REQUIRE(n_nodes >= 0 && n_nodes < ((int64_t)1 << 31) && n_edges >= 0 && n_edges < ((int64_t)1 << 31),
+               "graph too large");
+  BGNN_REQUIRE(n_feat >= 1 && n_feat <= 8, "n_feat=%d unsupported (1..8)", n_feat);
+  BGNN_REQUIRE(edge_dim >= 1 && edge_dim <= 4, "edge_dim=%d unsupported (1..4)", edge_dim);
+  BGNN_REQUIRE((x || n_nodes == 0) && (edge_index || n_edges == 0) && (edge_attr || n_edges == 0), "NULL tensor");
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  bgnn_graph *g = new bgnn_graph();
+  g->ctx = ctx; g->kind = 1; g->F = n_feat; g->ED = edge_dim; g->K = 0;
+  g->total_cells = (int32_t)n_nodes; g->row_capacity = (int32_t)n_nodes; g->generic_E = n_edges;
+  int rc = launch_generic_build(ctx, g, n_nodes, n_feat, x, n_edges, edge_index, edge_dim, edge_attr);
+  if (rc != BGNN_OK) { graph_free(g); return rc; }
+  *out = g;
+  return BGNN_OK;
+}
+
+int bgnn_graph_destroy(bgnn_graph *g) {
+  if (!g) return BGNN_OK;
+  graph_free(g);
+  return BGNN_OK;
+}
+
+int bgnn_graph_counts(bgnn_graph *g, int64_t *n_nodes, int64_t *n_edges, int32_t *n_feat, int32_t *edge_dim,
+                      int64_t *node_off, int64_t *edge_off) {
+  BGNN_REQUIRE(g, "graph is NULL");
+  bgnn_ctx *ctx = g->ctx;
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_feat) *n_feat = g->F;
+  if (edge_dim) *edge_dim = g->ED;
+  if (g->kind == 1) {
+    if (n_nodes) *n_nodes = g->total_cells;
+    if (n_edges) *n_edges = g->generic_E;
+    if (node_off) { node_off[0] = 0; node_off[1] = g->total_cells; }
+    if (edge_off) { edge_off[0] = 0; edge_off[1] = g->generic_E; }
+    return BGNN_OK;
+  }
+  BGNN_TRY(launch_graph_count_edges(g));
+  std::vector<int64_t> tc((size_t)g->n_tiles * 2);
+  BGNN_HIP_CHECK(hipMemcpyAsync(tc.data(), ctx->ws[5], tc.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  int64_t nn = 0, ne = 0;
+  for (int t = 0; t < g->n_tiles; ++t) {
+    if (node_off) node_off[t] = nn;
+    if (edge_off) edge_off[t] = ne;
+    nn += tc[t]; ne += tc[g->n_tiles + t];
+  }
+  if (node_off) node_off[g->n_tiles] = nn;
+  if (edge_off) edge_off[g->n_tiles] = ne;
+  g->n_nodes_host = nn; g->n_edges_host = ne;
+  if (n_nodes) *n_nodes = nn;
+  if (n_edges) *n_edges = ne;
+  return BGNN_OK;
+}
+
+int bgnn_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edge_attr, float *pos,
+                      int64_t *valid_rows, int64_t *valid_cols, float *local_std, int64_t *batch) {
+  BGNN_REQUIRE(g, "graph is NULL");
+  BGNN_REQUIRE(g->kind == 0, "bgnn_graph_export: only graphs built by bgnn_graph_build can be exported");
+  BGNN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  return launch_graph_export(g, x, edge_index, edge_attr, pos, valid_rows, valid_cols, local_std, batch);
+}
+
+int bgnn_graph_scatter(bgnn_graph *g, const float *node_values, float fill, float *grid) {
+  BGNN_REQUIRE(g && node_values && grid, "bgnn_graph_scatter: NULL argument");
+  BGNN_REQUIRE(g->kind == 0, "Data object missing grid_shape metadata");
+  BGNN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  return launch_graph_scatter(g, node_values, fill, grid);
+}
+
+// ---- forward ----------------------------------------------------------------------------------
+static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, float thr_review,
+                        const bgnn_outputs *o) {
+  const bgnn_model_desc &d = m->desc;
+  BGNN_REQUIRE(g->F == d.in_channels, "mat1 and mat2 shapes cannot be multiplied (graph has %d node features, model expects %d)",
+               g->F, d.in_channels);
+  BGNN_REQUIRE(g->ED == d.edge_dim, "edge_attr has %d columns, model edge_dim is %d", g->ED, d.edge_dim);
+  const int64_t rows = g->row_capacity;
+  if (rows <= 0) return BGNN_OK;
+  const int hid = d.hidden;
+  const int maxw = std::max(hid, d.heads * hid);
+  void *pa, *pb, *pasd, *phid;
+  BGNN_TRY(ctx_workspace(ctx, 0, (size_t)rows * maxw * sizeof(float), &pa));
+  BGNN_TRY(ctx_workspace(ctx, 1, (size_t)rows * maxw * sizeof(float), &pb));
+  BGNN_TRY(ctx_workspace(ctx, 2, (size_t)rows * 2 * d.heads * sizeof(float), &pasd));
+  BGNN_TRY(ctx_workspace(ctx, 3, (size_t)rows * m->head_hidden_total * sizeof(float), &phid));
+  float *A = (float *)pa, *B = (float *)pb, *asd = (float *)pasd, *hidb = (float *)phid;
+  const int64_t *dm = g->d_counts;
+  // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid)
+  BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, A, hid, dm, rows, 8, hid, 1));
+  BGNN_TRY(launch_gemm_f32(ctx, A, hid, m->fe_W1t, m->fe_b1, B, hid, dm, rows, hid, hid, 0));
+  // GNN backbone (gnn.py:173-188)
+  for (size_t l = 0; l < m->layers.size(); ++l) {
+    const BgnnLayer &L = m->layers[l];
+    const int HC = L.heads * hid;
+    BGNN_TRY(launch_gemm_f32(ctx, B, L.d_in, L.Wt, nullptr, A, HC, dm, rows, L.d_in, HC, 0));
+    BGNN_TRY(launch_att_coef(ctx, A, L.att_src, L.att_dst, asd, dm, rows, L.heads, hid));
+    BGNN_TRY(launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0));
+  }
+  if (o->hidden) {
+    const int64_t n = rows * hid;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, B, o->hidden, hid, dm);
+  }
+  // heads (gnn.py:392-406)
+  BGNN_TRY(launch_gemm_f32(ctx, B, hid, m->hd_W0t, m->hd_b0, hidb, m->head_hidden_total, dm, rows, hid,
+                           m->head_hidden_total, 1));
+  BGNN_TRY(launch_heads_final(ctx, m, hidb, m->head_hidden_total, dm, rows, thr_auto, thr_review, o));
+  return BGNN_OK;
+}
+
+int bgnn_forward(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, float thr_review, const bgnn_outputs *o) {
+  BGNN_REQUIRE(ctx && m && g && o, "bgnn_forward: NULL argument");
+  BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward: model/graph belong to another context");
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  return forward_impl(ctx, m, g, thr_auto, thr_review, o);
+}
+
+int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, float thr_auto,
+                     float thr_review, float norm_floor, float *classification, float *confidence, float *correction,
+                     int64_t *n_nodes_out) {
+  BGNN_REQUIRE(ctx && m && tiles && opts, "bgnn_infer_tiles: NULL argument");
+  bgnn_graph *g = nullptr;
+  BGNN_TRY(bgnn_graph_build(ctx, tiles, opts, &g));
+  const int64_t rows = g->row_capacity;
+  void *p;
+  int rc = ctx_workspace(ctx, 4, (size_t)rows * (sizeof(int64_t) + 2 * sizeof(float)), &p);
+  if (rc == BGNN_OK) {
+    bgnn_outputs o{};
+    o.predicted_class = (int64_t *)p;
+    o.confidence = (float *)(o.predicted_class + rows);
+    o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
+    rc = forward_impl(ctx, m, g, thr_auto, thr_review, &o);
+    if (rc == BGNN_OK)
+      rc = launch_results_to_grids(g, o.predicted_class, o.confidence, o.correction, norm_floor, classification,
+                                   confidence, correction);
+    if (rc == BGNN_OK && n_nodes_out)
+      rc = hipMemcpyAsync(n_nodes_out, g->d_counts, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
+               ? BGNN_OK : BGNN_ERR_HIP;
+  }
+  graph_free(g);   // buffers return to the pool; stream order keeps them valid for the work already queued
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// Internal structures shared by the translation units of libbgnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/bgnn.h"
+
+namespace bgnn {
+
+void set_error(const char *fmt, ...);
+
+#define BGNN_HIP_CHECK(expr)                                                          \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      bgnn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                      __LINE__);                                                      \
+      return BGNN_ERR_HIP;                                                            \
+    }                                                                                 \
+  } while (0)
+
+#define BGNN_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      bgnn::set_error(__VA_ARGS__);    \
+      return BGNN_ERR_INVALID;         \
+    }                                  \
+  } while (0)
+
+#define BGNN_TRY(expr)          \
+  do {                          \
+    int _r = (expr);            \
+    if (_r != BGNN_OK) return _r; \
+  } while (0)
+
+// ---- device memory pool: size-keyed free lists, so steady-state batches never hipMalloc --
+struct DevPool {
+  std::multimap<size_t, void *> free_blocks;
+  std::map<void *, size_t> live;
+  size_t total_bytes = 0;
+  int alloc(size_t bytes, void **out);
+  void release(void *p);
+  void trim();
+};
+
+struct ProfRecord {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+}  // namespace bgnn
+
+// Per-tile metadata (device + host copy)
+struct BgnnTileMeta {
+  int32_t h, w;
+  int32_t cell_off;   // first cell of the tile in the concatenated cell space
+  int32_t pad;
+  double rx, ry;      // resolution (x, y)
+};
+
+// Work item of the tile-structured kernels: a band of rows of one tile
+struct BgnnWorkItem {
+  int32_t tile, r0, nr, pad;
+};
+
+struct bgnn_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  bgnn::DevPool pool;
+  // profiling
+  uint32_t prof_mask = 0;
+  std::vector<bgnn::ProfRecord> prof_records;
+  std::vector<hipEvent_t> event_pool;
+  // forward workspace (grow-only)
+  void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // pinned staging for small host->device tables
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  int num_cus = 256;
+};
+
+struct BgnnLayer {
+  int d_in, heads, width;   // width = heads*hidden (concat) or hidden (last)
+  int concat;
+  float *Wt;        // [d_in][heads*hidden]   (lin.weight transposed)
+  float *att_src;   // [heads*hidden]
+  float *att_dst;   // [heads*hidden]
+  float *V;         // [heads][edge_dim]   folded lin_edge . att_edge
+  float *scale;     // [width]  BN weight / sqrt(var + eps)
+  float *shift;     // [width]  (conv bias - mean) * scale + BN bias
+};
+
+struct bgnn_model {
+  bgnn_ctx *ctx;
+  bgnn_model_desc desc;
+  float *blob = nullptr;      // one device allocation holding everything below
+  size_t blob_floats = 0;
+  float *fe_W0t, *fe_b0, *fe_W1t, *fe_b1;     // [in8][hid], [hid], [hid][hid], [hid]
+  std::vector<BgnnLayer> layers;
+  int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
+  float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
+  float *hd_W1, *hd_b1;       // second layers packed: cls [classes][hid/2], conf [hid/2], corr [hid/2]; biases
+};
+
+struct bgnn_graph {
+  bgnn_ctx *ctx;
+  int kind;                   // 0 = stencil grid graph (ELL), 1 = generic CSR
+  int32_t n_tiles = 0;
+  int32_t total_cells = 0;    // grid: number of cells; generic: number of nodes
+  int32_t K = 0;              // ELL width (stencil size)
+  int32_t F = 0;              // node features
+  int32_t ED = 0;             // edge features
+  int32_t include_self_loops = 0;
+  int32_t has_unc = 0;
+  std::vector<BgnnTileMeta> h_tiles;
+  // device
+  BgnnTileMeta *d_tiles = nullptr;
+  BgnnWorkItem *d_items = nullptr;
+  int32_t n_items = 0;
+  int32_t *d_node_id = nullptr;       // [cells]  >=0 node id ; <0 : -(prefix+1)
+  int32_t *d_cell_of_node = nullptr;  // [cells]
+  int64_t *d_counts = nullptr;        // [0]=n_nodes [1]=n_edges(valid after export scan)
+  float *d_x8 = nullptr;              // [rows][8]
+  float *d_local_std = nullptr;       // [rows]
+  int32_t *d_nbr = nullptr;           // grid: [rows][K] ; generic: col[E]
+  float *d_eattr = nullptr;           // grid: [rows][K][ED] ; generic: [E][ED]
+  int32_t *d_rowptr = nullptr;        // generic only [N+1]
+  int32_t *d_edge_perm = nullptr;     // generic only
+  int64_t n_nodes_host = -1;          // cached after a sync
+  int64_t n_edges_host = -1;
+  int64_t generic_E = 0;
+  int32_t row_capacity = 0;           // rows allocated for node-indexed arrays
+};
+
+namespace bgnn {
+
+int ctx_workspace(bgnn_ctx *ctx, int slot, size_t bytes, void **out);
+int ctx_upload(bgnn_ctx *ctx, const void *host, size_t bytes, void *dev);
+
+// profiling scope: records events around a kernel launch when enabled for that kernel
+struct ProfScope {
+  bgnn_ctx *ctx;
+  int idx;
+  ProfScope(bgnn_ctx *c, int kernel);
+  ~ProfScope();
+};
+
+// ---- launchers implemented in the kernel translation units ------------------------------
+int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts);
+int launch_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edge_attr, float *pos,
+                        int64_t *valid_rows, int64_t *valid_cols, float *local_std, int64_t *batch);
+int launch_graph_count_edges(bgnn_graph *g);
+int launch_graph_scatter(bgnn_graph *g, const float *node_values, float fill, float *grid);
+int launch_results_to_grids(bgnn_graph *g, const int64_t *cls, const float *conf, const float *corr,
+                            float norm_floor, float *cls_grid, float *conf_grid, float *corr_grid);
+int launch_generic_build(bgnn_ctx *ctx, bgnn_graph *g, int64_t n_nodes, int32_t n_feat, const float *x,
+                         int64_t n_edges, const int64_t *edge_index, int32_t edge_dim, const float *edge_attr);
+
+// Y[M,NC] = act(X[M,K] @ Wt[K,NC] + bias); M read from d_counts[0] (bounded by max_rows)
+int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y,
+                    int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu);
+int launch_att_coef(bgnn_ctx *ctx, const float *xw, const float *att_src, const float *att_dst, float *asd,
+                    const int64_t *d_m, int64_t max_rows, int H, int C);
+int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
+                         const float *asd, float *out, int relu);
+int launch_heads_final(bgnn_ctx *ctx, const bgnn_model *m, const float *hid, int ldh, const int64_t *d_m,
+                       int64_t max_rows, float thr_auto, float thr_review, const bgnn_outputs *o);
+
+}  // namespace bgnn

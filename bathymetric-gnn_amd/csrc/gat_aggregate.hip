@@ -1,0 +1,254 @@
+// K4: GAT attention over the stencil neighbourhood -- gather, per-node softmax, weighted
+// aggregate, bias + BatchNorm (folded) + ReLU -- one pass, no [E,H,C] tensor ever materialised.
+//
+// Restates torch_geometric GATConv.forward with edge_dim (called at reference
+// models/gnn.py:176; semantics in SURVEY.md Appendix B / oracle/gat_cpu.py):
+//   e_ji   = leaky_relu(a_src[j] + a_dst[i] + ea_ji . V, 0.2)          V = lin_edge^T att_edge (folded)
+//   self   : ea_ii = mean of the node's incoming edge attributes (0 if none)   [fill_value='mean']
+//   alpha  = exp(e - max_i) / (sum_i exp(e - max_i) + 1e-16)
+//   out_i  = sum_j alpha_ji * xw[j]   (in-edges in edge order, self loop last) ; + bias ; BN ; ReLU
+//
+// Mapping: LPN = HC/4 lanes own one node (each lane a float4 of channels; its head = channel/C);
+// a wave holds 64/LPN nodes.  Every lane computes the <= K+1 logits of its head serially (degree
+// is tiny), then streams the neighbour rows with 16-byte coalesced loads.
+#include "bgnn_internal.h"
+
+namespace bgnn {
+
+// a_src[n,h] = sum_c xw[n,h,c] att_src[h,c]; a_dst likewise.  asd layout [N][2H] = (src.., dst..)
+template <int LPN>
+__global__ __launch_bounds__(256) void att_coef_kernel(const float *__restrict__ xw,
+                                                       const float *__restrict__ att_src,
+                                                       const float *__restrict__ att_dst, float *__restrict__ asd,
+                                                       const int64_t *__restrict__ d_m, int H, int C) {
+  constexpr int NPW = 64 / LPN;
+  const int64_t M = *d_m;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPN, l = lane % LPN;
+  const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n = wave_id * NPW + sub;
+  const bool ok = n < M;
+  const int HC = LPN * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) v = *reinterpret_cast<const float4 *>(xw + n * HC + l * 4);
+  const float4 s4 = *reinterpret_cast<const float4 *>(att_src + l * 4);
+  const float4 d4 = *reinterpret_cast<const float4 *>(att_dst + l * 4);
+  float ps = v.x * s4.x + v.y * s4.y + v.z * s4.z + v.w * s4.w;
+  float pd = v.x * d4.x + v.y * d4.y + v.z * d4.z + v.w * d4.w;
+  const int lph = C / 4;   // lanes per head (16 for C=64)
+  for (int o = lph >> 1; o > 0; o >>= 1) {
+    ps += __shfl_xor(ps, o);
+    pd += __shfl_xor(pd, o);
+  }
+  if (ok && (l % lph) == 0) {
+    const int hh = l / lph;
+    asd[n * 2 * H + hh] = ps;
+    asd[n * 2 * H + H + hh] = pd;
+  }
+}
+
+struct AggArgs {
+  const float *xw;        // [N][HC]
+  const float *asd;       // [N][2H]
+  const int32_t *nbr;     // ELL [N][K]  or CSR col[E]
+  const float *eattr;     // [N][K][ED] or [E][ED]
+  const int32_t *rowptr;  // CSR only (nullptr for ELL)
+  const float *V;         // [H][ED]
+  const float *scale;     // [HC]
+  const float *shift;     // [HC]
+  float *out;             // [N][HC]
+  const int64_t *d_m;
+  int K, H, C, ED, relu;
+};
+
+constexpr int AGG_MAXDEG = 16;   // ELL widths 4 / 8 / 16; longer CSR rows take the two-pass loop
+
+template <int LPN>
+__global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
+  constexpr int NPW = 64 / LPN;
+  constexpr int HC = LPN * 4;
+  const int64_t M = *a.d_m;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPN, l = lane % LPN;
+  const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t i = wave_id * NPW + sub;
+  if (i >= M) return;
+  const int H = a.H, ED = a.ED;
+  const int hh = (l * 4) / a.C;
+  int64_t beg, end;
+  if (a.rowptr) { beg = a.rowptr[i]; end = a.rowptr[i + 1]; }
+  else { beg = i * a.K; end = beg + a.K; }
+  float v[4];
+  for (int f = 0; f < 4; ++f) v[f] = f < ED ? a.V[hh * ED + f] : 0.0f;
+  const float ad = a.asd[i * 2 * H + H + hh];
+
+  // pass 1: logits, running max, self-loop attribute = mean of incoming attributes
+  float ea_sum[4] = {0.f, 0.f, 0.f, 0.f};
+  int deg = 0;
+  float mx = -__builtin_inff();
+  float ev[AGG_MAXDEG];
+  const bool small = (end - beg) <= AGG_MAXDEG;
+#pragma unroll
+  for (int b = 0; b < AGG_MAXDEG; ++b) {
+    ev[b] = -__builtin_inff();
+    if (small && beg + b < end) {
+      const int j = a.nbr[beg + b];
+      if (j >= 0) {
+        float lg = a.asd[(int64_t)j * 2 * H + hh] + ad;
+        float dot = 0.0f;
+        for (int f = 0; f < ED; ++f) {
+          const float e = a.eattr[(beg + b) * ED + f];
+          ea_sum[f] += e;
+          dot += e * v[f];
+        }
+        lg += dot;
+        lg = lg > 0.0f ? lg : 0.2f * lg;
+        ev[b] = lg;
+        mx = fmaxf(mx, lg);
+        ++deg;
+      }
+    }
+  }
+  if (!small) {
+    for (int64_t p = beg; p < end; ++p) {
+      const int j = a.nbr[p];
+      if (j < 0) continue;
+      float lg = a.asd[(int64_t)j * 2 * H + hh] + ad;
+      float dot = 0.0f;
+      for (int f = 0; f < ED; ++f) {
+        const float e = a.eattr[p * ED + f];
+        ea_sum[f] += e;
+        dot += e * v[f];
+      }
+      lg += dot;
+      lg = lg > 0.0f ? lg : 0.2f * lg;
+      mx = fmaxf(mx, lg);
+      ++deg;
+    }
+  }
+  float self_lg;
+  {
+    const float cnt = (float)(deg > 0 ? deg : 1);      // scatter(..., reduce='mean'): sum / max(count, 1)
+    float dot = 0.0f;
+    for (int f = 0; f < ED; ++f) dot += (ea_sum[f] / cnt) * v[f];
+    self_lg = a.asd[i * 2 * H + hh] + ad + dot;
+    self_lg = self_lg > 0.0f ? self_lg : 0.2f * self_lg;
+    mx = fmaxf(mx, self_lg);
+  }
+  // pass 2: exp and denominator
+  float den = 0.0f;
+  if (small) {
+#pragma unroll
+    for (int b = 0; b < AGG_MAXDEG; ++b) {
+      const float p = ev[b] == -__builtin_inff() ? 0.0f : expf(ev[b] - mx);
+      ev[b] = p;
+      den += p;
+    }
+  } else {
+    for (int64_t p = beg; p < end; ++p) {
+      const int j = a.nbr[p];
+      if (j < 0) continue;
+      float lg = a.asd[(int64_t)j * 2 * H + hh] + ad;
+      float dot = 0.0f;
+      for (int f = 0; f < ED; ++f) dot += a.eattr[p * ED + f] * v[f];
+      lg += dot;
+      lg = lg > 0.0f ? lg : 0.2f * lg;
+      den += expf(lg - mx);
+    }
+  }
+  const float pself = expf(self_lg - mx);
+  den += pself;
+  den += 1e-16f;
+  // pass 3: weighted aggregate of neighbour rows
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *xwl = a.xw + l * 4;
+  if (small) {
+#pragma unroll
+    for (int b = 0; b < AGG_MAXDEG; ++b) {
+      if (beg + b < end) {
+        const int j = a.nbr[beg + b];
+        if (j >= 0) {
+          const float al = ev[b] / den;
+          const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HC);
+          acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
+        }
+      }
+    }
+  } else {
+    for (int64_t p = beg; p < end; ++p) {
+      const int j = a.nbr[p];
+      if (j < 0) continue;
+      float lg = a.asd[(int64_t)j * 2 * H + hh] + ad;
+      float dot = 0.0f;
+      for (int f = 0; f < ED; ++f) dot += a.eattr[p * ED + f] * v[f];
+      lg += dot;
+      lg = lg > 0.0f ? lg : 0.2f * lg;
+      const float al = expf(lg - mx) / den;
+      const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HC);
+      acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
+    }
+  }
+  {
+    const float al = pself / den;
+    const float4 x = *reinterpret_cast<const float4 *>(xwl + i * HC);
+    acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
+  }
+  // epilogue: (+bias, BatchNorm eval) folded into scale/shift, ReLU
+  const float4 sc = *reinterpret_cast<const float4 *>(a.scale + l * 4);
+  const float4 sh = *reinterpret_cast<const float4 *>(a.shift + l * 4);
+  float4 o;
+  o.x = acc.x * sc.x + sh.x; o.y = acc.y * sc.y + sh.y; o.z = acc.z * sc.z + sh.z; o.w = acc.w * sc.w + sh.w;
+  if (a.relu) {
+    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+  }
+  *reinterpret_cast<float4 *>(a.out + i * HC + l * 4) = o;
+}
+
+int launch_att_coef(bgnn_ctx *ctx, const float *xw, const float *att_src, const float *att_dst, float *asd,
+                    const int64_t *d_m, int64_t max_rows, int H, int C) {
+  if (max_rows <= 0) return BGNN_OK;
+  ProfScope ps(ctx, BGNN_K_ATTCOEF);
+  const int HC = H * C, LPN = HC / 4;
+  BGNN_REQUIRE(C % 4 == 0 && (C / 4) <= 64 && ((C / 4) & (C / 4 - 1)) == 0 && (LPN == 64 || LPN == 32 || LPN == 16 || LPN == 8),
+               "att_coef: unsupported H=%d C=%d", H, C);
+  const int npw = 64 / LPN;
+  const int64_t waves = (max_rows + npw - 1) / npw;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  switch (LPN) {
+    case 64: hipLaunchKernelGGL(att_coef_kernel<64>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
+    case 32: hipLaunchKernelGGL(att_coef_kernel<32>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
+    case 16: hipLaunchKernelGGL(att_coef_kernel<16>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
+    case 8: hipLaunchKernelGGL(att_coef_kernel<8>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
+  }
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
+                         const float *asd, float *out, int relu) {
+  const int64_t max_rows = g->row_capacity;
+  if (max_rows <= 0) return BGNN_OK;
+  ProfScope ps(ctx, BGNN_K_AGGREGATE);
+  AggArgs a{};
+  a.xw = xw; a.asd = asd; a.nbr = g->d_nbr; a.eattr = g->d_eattr;
+  a.rowptr = g->kind == 1 ? g->d_rowptr : nullptr;
+  a.V = L.V; a.scale = L.scale; a.shift = L.shift; a.out = out; a.d_m = g->d_counts;
+  a.K = g->K; a.H = L.heads; a.C = C; a.ED = ED; a.relu = relu;
+  const int HC = L.heads * C, LPN = HC / 4;
+  const int npw = 64 / LPN;
+  const int64_t waves = (max_rows + npw - 1) / npw;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  switch (LPN) {
+    case 64: hipLaunchKernelGGL(gat_aggregate_kernel<64>, grid, block, 0, ctx->stream, a); break;
+    case 32: hipLaunchKernelGGL(gat_aggregate_kernel<32>, grid, block, 0, ctx->stream, a); break;
+    case 16: hipLaunchKernelGGL(gat_aggregate_kernel<16>, grid, block, 0, ctx->stream, a); break;
+    case 8: hipLaunchKernelGGL(gat_aggregate_kernel<8>, grid, block, 0, ctx->stream, a); break;
+    default:
+      set_error("gat_aggregate: unsupported heads*hidden = %d", HC);
+      return BGNN_ERR_UNSUPPORTED;
+  }
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+}  // namespace bgnn

@@ -1,0 +1,626 @@
+// Graph construction on the GPU (gfx950): grid tiles -> stencil graph.
+//
+// Replaces GraphBuilder.build_graph and helpers (reference data/graph_construction.py:91-505).
+// Compiled with -ffp-contract=off: the float sequences below restate, operation by operation,
+// what numpy / scipy.ndimage do on the CPU (see oracle/graph_cpu.py), so that node features
+// and edge attributes come out bit-identical to the reference, not merely close.
+//
+// Layout in HBM (cells = all cells of all tiles, concatenated row-major; rows = compacted valid
+// cells = graph nodes, in np.where order per tile, tiles in batch order):
+//   node_id[cells] i32      >= 0: node id;  < 0: -(number of valid cells before it + 1)
+//   cell_of_node[rows] i32
+//   x8[rows][8] f32         node features, padded to 8 columns (32-byte rows)
+//   local_std[rows] f32
+//   nbr[rows][K] i32        slot b = node at grid offset -offset[b] (the SOURCE of the block-b
+//                           edge whose target is this node), -1 if absent; ascending b is the
+//                           order torch_geometric's scatter sees this node's in-edges
+//   eattr[rows][K][ED] f32  attributes of that edge
+#include "bgnn_internal.h"
+
+namespace bgnn {
+
+struct Stencil {
+  int K;
+  int dr[16], dc[16];
+};
+
+static Stencil make_stencil(int connectivity) {
+  Stencil s{};
+  static const int o4[4][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}};                      // :79-81
+  static const int o8[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};  // :83-87
+  if (connectivity == 4) {
+    s.K = 4;
+    for (int i = 0; i < 4; ++i) { s.dr[i] = o4[i][0]; s.dc[i] = o4[i][1]; }
+  } else {
+    s.K = connectivity == 16 ? 16 : 8;
+    for (int i = 0; i < 8; ++i) { s.dr[i] = o8[i][0]; s.dc[i] = o8[i][1]; }
+    for (int i = 8; i < s.K; ++i) { s.dr[i] = 2 * o8[i - 8][0]; s.dc[i] = 2 * o8[i - 8][1]; }
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of small integer values (3 kernels: reduce / spine / apply)
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD;
+
+struct MaskValue {
+  const uint8_t *mask;
+  __device__ int operator()(int64_t i) const { return mask[i] ? 1 : 0; }
+};
+
+__device__ __forceinline__ int find_tile(const BgnnTileMeta *tiles, int n_tiles, int64_t cell) {
+  int lo = 0, hi = n_tiles - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)tiles[mid].cell_off <= cell) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// value(i) for the edge-export scan: index space [tile][block b (K, +1 if self loops)][cell]
+struct EdgeValue {
+  const BgnnTileMeta *tiles;
+  int n_tiles, K, KS;
+  const int32_t *node_id;
+  const int32_t *nbr;
+  __device__ void decode(int64_t i, int &cell, int &b) const {
+    int lo = 0, hi = n_tiles - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if ((int64_t)tiles[mid].cell_off * KS <= i) lo = mid; else hi = mid - 1;
+    }
+    const BgnnTileMeta &t = tiles[lo];
+    int64_t rel = i - (int64_t)t.cell_off * KS;
+    int ncell = t.h * t.w;
+    b = (int)(rel / ncell);
+    cell = t.cell_off + (int)(rel - (int64_t)b * ncell);
+  }
+  __device__ int operator()(int64_t i) const {
+    int cell, b;
+    decode(i, cell, b);
+    int id = node_id[cell];
+    if (id < 0) return 0;
+    if (b >= K) return 1;
+    return nbr[(int64_t)id * K + b] >= 0 ? 1 : 0;
+  }
+};
+
+template <class V>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(V val, int64_t n, int32_t *block_sums) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_PER_THREAD; ++j)
+    if (base + j < n) s += val(base + j);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  __shared__ int wsum[SCAN_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wsum[w];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// single block: exclusive scan of block_sums in place, total -> *total (int64)
+__global__ __launch_bounds__(1024) void scan_spine_kernel(int32_t *block_sums, int n_blocks, int64_t *total) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_blocks; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < n_blocks ? block_sums[i] : 0;
+    int incl = v;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wsum[w];
+    int carry = carry_s;
+    if (i < n_blocks) block_sums[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = (int64_t)carry_s;
+}
+
+// block-local exclusive prefix of the thread's first element; returns it
+template <class V>
+__device__ __forceinline__ int block_exclusive(V &val, int64_t n, int64_t base, int (&v)[SCAN_PER_THREAD]) {
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+    v[j] = (base + j < n) ? val(base + j) : 0;
+    s += v[j];
+  }
+  int incl = s;
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __shared__ int wsum[SCAN_THREADS / 64];
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  return woff + incl - s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_nodes_kernel(MaskValue val, int64_t n,
+                                                                        const int32_t *block_off, int32_t *node_id,
+                                                                        int32_t *cell_of_node) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+  int v[SCAN_PER_THREAD];
+  int p = block_off[blockIdx.x] + block_exclusive(val, n, base, v);
+#pragma unroll
+  for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+    if (base + j < n) {
+      if (v[j]) {
+        node_id[base + j] = p;
+        cell_of_node[p] = (int32_t)(base + j);
+        ++p;
+      } else {
+        node_id[base + j] = -(p + 1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a: masked 5x5 box statistics, float64, same operation order as scipy.ndimage.uniform_filter
+// (graph_construction.py:378-432): axis 0 then axis 1, each a zero-extended running sum
+//   tmp = x[-2]+x[-1]+x[0]+x[1]+x[2];  out[0] = tmp/5;  tmp += (x[l+2] - x[l-3]); out[l] = tmp/5
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void masked_vals(const float *depth, const uint8_t *mask, int64_t i, double &v,
+                                            double &c, double &q) {
+  if (mask[i]) {
+    double d = (double)depth[i];
+    v = d; c = 1.0; q = d * d;
+  } else {
+    v = 0.0; c = 0.0; q = 0.0;
+  }
+}
+
+// one thread per (tile, column): vertical pass
+__global__ __launch_bounds__(64) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
+                                                     const uint8_t *mask, double *vs, double *vc, double *vq) {
+  const BgnnTileMeta t = tiles[blockIdx.y];
+  int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= t.w) return;
+  const int h = t.h, w = t.w;
+  const int64_t base = (int64_t)t.cell_off + c;
+  double s = 0.0, n = 0.0, q = 0.0;
+  // initial window: rows -2..2 in ascending order (rows < 0 contribute +0.0)
+  for (int r = 0; r <= 2; ++r) {
+    double a = 0.0, b = 0.0, d = 0.0;
+    if (r < h) masked_vals(depth, mask, base + (int64_t)r * w, a, b, d);
+    s += a; n += b; q += d;
+  }
+  vs[base] = s / 5.0; vc[base] = n / 5.0; vq[base] = q / 5.0;
+  for (int l = 1; l < h; ++l) {
+    double a1 = 0.0, b1 = 0.0, d1 = 0.0, a0 = 0.0, b0 = 0.0, d0 = 0.0;
+    if (l + 2 < h) masked_vals(depth, mask, base + (int64_t)(l + 2) * w, a1, b1, d1);
+    if (l - 3 >= 0) masked_vals(depth, mask, base + (int64_t)(l - 3) * w, a0, b0, d0);
+    s += (a1 - a0); n += (b1 - b0); q += (d1 - d0);
+    int64_t o = base + (int64_t)l * w;
+    vs[o] = s / 5.0; vc[o] = n / 5.0; vq[o] = q / 5.0;
+  }
+}
+
+// one thread per (tile, row): horizontal pass + finalisation to float32 mean / std
+__global__ __launch_bounds__(64) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
+                                                     const double *vq, float *local_mean, float *local_std) {
+  const BgnnTileMeta t = tiles[blockIdx.y];
+  int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= t.h) return;
+  const int w = t.w;
+  const int64_t base = (int64_t)t.cell_off + (int64_t)r * w;
+  double s = 0.0, n = 0.0, q = 0.0;
+  for (int c = 0; c <= 2; ++c) {
+    if (c < w) { s += vs[base + c]; n += vc[base + c]; q += vq[base + c]; }
+    else { s += 0.0; n += 0.0; q += 0.0; }
+  }
+  for (int l = 0; l < w; ++l) {
+    if (l > 0) {
+      double a1 = 0.0, b1 = 0.0, d1 = 0.0, a0 = 0.0, b0 = 0.0, d0 = 0.0;
+      if (l + 2 < w) { a1 = vs[base + l + 2]; b1 = vc[base + l + 2]; d1 = vq[base + l + 2]; }
+      if (l - 3 >= 0) { a0 = vs[base + l - 3]; b0 = vc[base + l - 3]; d0 = vq[base + l - 3]; }
+      s += (a1 - a0); n += (b1 - b0); q += (d1 - d0);
+    }
+    // uniform_filter(...) * 25.0   (graph_construction.py:408-425)
+    double sum_vals = (s / 5.0) * 25.0;
+    double count = (n / 5.0) * 25.0;
+    double sum_sq = (q / 5.0) * 25.0;
+    double safe = count > 1.0 ? count : 1.0;       // np.maximum(count, 1.0)
+    double mean = sum_vals / safe;
+    double mean_sq = sum_sq / safe;
+    double var = mean_sq - mean * mean;
+    var = var > 0.0 ? var : 0.0;                    // np.maximum(variance, 0.0) (NaN -> NaN in numpy; inputs finite)
+    local_mean[base + l] = (float)mean;
+    local_std[base + l] = (float)sqrt(var);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b + K2: per valid cell -> node features, neighbour table, edge attributes
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nan_to_num_f32(float v) {   // np.nan_to_num(v, nan=0.0) for float32
+  if (v != v) return 0.0f;
+  if (v == __builtin_inff()) return 3.4028234663852886e38f;
+  if (v == -__builtin_inff()) return -3.4028234663852886e38f;
+  return v;
+}
+
+struct FeatureArgs {
+  const BgnnTileMeta *tiles;
+  const BgnnWorkItem *items;
+  const float *depth;
+  const uint8_t *mask;
+  const float *unc;
+  const float *local_mean;
+  const float *local_std;
+  const int32_t *node_id;
+  float *x8;
+  float *node_local_std;
+  int32_t *nbr;
+  float *eattr;
+  int F;
+  int feat_ids[8];
+  int ED;
+  int edge_ids[4];
+};
+
+__device__ __forceinline__ float filled_at(const FeatureArgs &a, int64_t i) {
+  // depth_filled = nan_to_num(where(valid, depth, local_mean), nan=0)   (:281-282)
+  float v = a.mask[i] ? a.depth[i] : a.local_mean[i];
+  return nan_to_num_f32(v);
+}
+
+__global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st) {
+  const BgnnWorkItem it = a.items[blockIdx.x];
+  const BgnnTileMeta t = a.tiles[it.tile];
+  const int h = t.h, w = t.w;
+  const int ncell = it.nr * w;
+  for (int li = threadIdx.x; li < ncell; li += blockDim.x) {
+    const int r = it.r0 + li / w, c = li % w;
+    const int64_t tb = t.cell_off;
+    const int64_t idx = tb + (int64_t)r * w + c;
+    const int id = a.node_id[idx];
+    if (id < 0) continue;
+    // ---- node features -------------------------------------------------------------
+    const float f0 = filled_at(a, idx);
+    // np.gradient, unit spacing, float32 (:284): central differences, one-sided at the ends
+    float gy, gx;
+    if (r == 0) gy = filled_at(a, idx + w) - f0;
+    else if (r == h - 1) gy = f0 - filled_at(a, idx - w);
+    else gy = (filled_at(a, idx + w) - filled_at(a, idx - w)) / 2.0f;
+    if (c == 0) gx = filled_at(a, idx + 1) - f0;
+    else if (c == w - 1) gx = f0 - filled_at(a, idx - 1);
+    else gx = (filled_at(a, idx + 1) - filled_at(a, idx - 1)) / 2.0f;
+    const float gmag = sqrtf(gx * gx + gy * gy);   // contraction is off: two roundings, as numpy
+    // ndimage.laplace, mode='reflect': per axis in float64, cast to float32, float32 add (:447)
+    const double up = (double)(r > 0 ? filled_at(a, idx - w) : f0);
+    const double dn = (double)(r < h - 1 ? filled_at(a, idx + w) : f0);
+    const double lf = (double)(c > 0 ? filled_at(a, idx - 1) : f0);
+    const double rt = (double)(c < w - 1 ? filled_at(a, idx + 1) : f0);
+    const double c0 = (double)f0 * -2.0;
+    float lap = (float)(c0 + (up + dn)) + (float)(c0 + (lf + rt));
+    // zero-padded 3x3 valid count (:451-456)
+    int cnt = 0;
+    for (int dr = -1; dr <= 1; ++dr)
+      for (int dc = -1; dc <= 1; ++dc) {
+        int rr = r + dr, cc = c + dc;
+        if (rr >= 0 && rr < h && cc >= 0 && cc < w) cnt += a.mask[tb + (int64_t)rr * w + cc] ? 1 : 0;
+      }
+    if (cnt < 3) lap = 0.0f;
+    const float lstd = a.local_std[idx];
+    float cand[8];
+    cand[BGNN_NF_DEPTH] = a.depth[idx];
+    cand[BGNN_NF_LOCAL_MEAN] = a.local_mean[idx];
+    cand[BGNN_NF_LOCAL_STD] = lstd;
+    cand[BGNN_NF_GRADIENT_X] = gx;
+    cand[BGNN_NF_GRADIENT_Y] = gy;
+    cand[BGNN_NF_GRADIENT_MAGNITUDE] = gmag;
+    cand[BGNN_NF_CURVATURE] = lap;
+    cand[BGNN_NF_UNCERTAINTY] = a.unc ? a.unc[idx] : 0.0f;
+    float xo[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      float v = 0.0f;
+      if (f < a.F) {
+        const int fid = a.feat_ids[f];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (fid == k) v = cand[k];
+        v = nan_to_num_f32(v);
+      }
+      xo[f] = v;
+    }
+    float4 *xp = reinterpret_cast<float4 *>(a.x8 + (int64_t)id * 8);
+    xp[0] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    xp[1] = make_float4(xo[4], xo[5], xo[6], xo[7]);
+    a.node_local_std[id] = nan_to_num_f32(lstd);
+    // ---- in-edges: slot b <- source cell (r - dr[b], c - dc[b])  (:196-223, :329-376) ----
+    const float dz_tgt = a.depth[idx];
+    for (int b = 0; b < st.K; ++b) {
+      const int sr = r - st.dr[b], sc = c - st.dc[b];
+      int sid = -1;
+      int64_t sidx = 0;
+      if (sr >= 0 && sr < h && sc >= 0 && sc < w) {
+        sidx = tb + (int64_t)sr * w + sc;
+        sid = a.node_id[sidx];
+        if (sid < 0) sid = -1;
+      }
+      a.nbr[(int64_t)id * st.K + b] = sid;
+      float ev[4] = {0.f, 0.f, 0.f, 0.f};
+      if (sid >= 0) {
+        const double dx = (double)st.dc[b] * t.rx;       // (tgt_c - src_c) * res_x
+        const double dy = (double)st.dr[b] * t.ry;
+        const double dist = sqrt(dx * dx + dy * dy);
+        const float dz = dz_tgt - a.depth[sidx];          // float32 subtract
+        double slope = 0.0;
+        if (dist > 0.0) slope = atan((double)dz / dist) * 57.29577951308232;   // np.degrees
+        for (int f = 0; f < a.ED; ++f) {
+          const int eid = a.edge_ids[f];
+          float v = 0.0f;
+          if (eid == BGNN_EF_DISTANCE) { double d = dist; v = (d != d) ? 0.0f : (float)d; }
+          else if (eid == BGNN_EF_DEPTH_DIFFERENCE) v = nan_to_num_f32(dz);
+          else if (eid == BGNN_EF_SLOPE) v = (slope != slope) ? 0.0f : (float)slope;
+          ev[f] = v;
+        }
+      }
+      for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// counts per tile (nodes, edges)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_counts_kernel(const BgnnTileMeta *tiles, const int32_t *node_id,
+                                                          const int32_t *nbr, int K, int self_loops,
+                                                          int64_t *tile_nodes, int64_t *tile_edges) {
+  const BgnnTileMeta t = tiles[blockIdx.x];
+  const int ncell = t.h * t.w;
+  int nn = 0, ne = 0;
+  for (int i = threadIdx.x; i < ncell; i += blockDim.x) {
+    int id = node_id[t.cell_off + i];
+    if (id >= 0) {
+      ++nn;
+      for (int b = 0; b < K; ++b) ne += nbr[(int64_t)id * K + b] >= 0 ? 1 : 0;
+      ne += self_loops ? 1 : 0;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { nn += __shfl_down(nn, o); ne += __shfl_down(ne, o); }
+  __shared__ int sn[4], se[4];
+  if ((threadIdx.x & 63) == 0) { sn[threadIdx.x >> 6] = nn; se[threadIdx.x >> 6] = ne; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_nodes[blockIdx.x] = (int64_t)sn[0] + sn[1] + sn[2] + sn[3];
+    tile_edges[blockIdx.x] = (int64_t)se[0] + se[1] + se[2] + se[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// export to the PyG layout
+// ------------------------------------------------------------------------------------------
+__global__ void export_nodes_kernel(const BgnnTileMeta *tiles, int n_tiles, const int64_t *counts,
+                                    const int32_t *cell_of_node, const float *x8, const float *lstd, int F,
+                                    float *x, float *pos, int64_t *rows, int64_t *cols, float *local_std,
+                                    int64_t *batch) {
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= counts[0]) return;
+  int cell = cell_of_node[n];
+  int ti = find_tile(tiles, n_tiles, cell);
+  const BgnnTileMeta t = tiles[ti];
+  int rel = cell - t.cell_off;
+  int r = rel / t.w, c = rel % t.w;
+  if (x) for (int f = 0; f < F; ++f) x[n * F + f] = x8[n * 8 + f];
+  if (pos) { pos[n * 2] = (float)c; pos[n * 2 + 1] = (float)r; }   // pos = (col, row)  (:144-147)
+  if (rows) rows[n] = r;
+  if (cols) cols[n] = c;
+  if (local_std) local_std[n] = lstd[n];
+  if (batch) batch[n] = ti;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_edges_kernel(EdgeValue val, int64_t n,
+                                                                        const int32_t *block_off,
+                                                                        const int64_t *counts, const float *eattr,
+                                                                        int ED, int64_t *edge_index,
+                                                                        float *edge_attr) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+  int v[SCAN_PER_THREAD];
+  int64_t p = (int64_t)block_off[blockIdx.x] + block_exclusive(val, n, base, v);
+  const int64_t E = counts[1];
+#pragma unroll
+  for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+    if (base + j < n && v[j]) {
+      int cell, b;
+      val.decode(base + j, cell, b);
+      const int tgt = val.node_id[cell];
+      if (b < val.K) {
+        // block-b edge: src = node, tgt = node + offset[b]; stored at its target's slot b
+        const int64_t slot = (int64_t)tgt * val.K + b;
+        if (edge_index) { edge_index[p] = val.nbr[slot]; edge_index[E + p] = tgt; }
+        if (edge_attr) for (int f = 0; f < ED; ++f) edge_attr[p * ED + f] = eattr[slot * ED + f];
+      } else {  // appended self loops, attributes all 0 (:226-229, :361-364)
+        if (edge_index) { edge_index[p] = tgt; edge_index[E + p] = tgt; }
+        if (edge_attr) for (int f = 0; f < ED; ++f) edge_attr[p * ED + f] = 0.0f;
+      }
+      ++p;
+    }
+  }
+}
+
+__global__ void scatter_kernel(const int32_t *node_id, int64_t n_cells, const float *vals, float fill, float *grid) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cells) return;
+  int id = node_id[i];
+  grid[i] = id >= 0 ? vals[id] : fill;
+}
+
+__global__ void results_to_grids_kernel(const int32_t *node_id, int64_t n_cells, const int64_t *cls,
+                                        const float *conf, const float *corr, const float *lstd, float norm_floor,
+                                        float *cls_grid, float *conf_grid, float *corr_grid) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cells) return;
+  int id = node_id[i];
+  float a = 0.f, b = 0.f, c = 0.f;
+  if (id >= 0) {
+    a = (float)cls[id];
+    b = conf[id];
+    if (corr) {                                   // models/pipeline.py:294-307
+      float s = lstd[id];
+      s = s > norm_floor ? s : norm_floor;        // np.maximum(local_std_grid, FLOOR)
+      c = corr[id] * s;
+    }
+  } else if (corr) {
+    c = 0.0f * norm_floor;                        // 0.0 * max(0.0, floor) = 0.0
+  }
+  if (cls_grid) cls_grid[i] = a;
+  if (conf_grid) conf_grid[i] = b;
+  if (corr_grid) corr_grid[i] = c;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <class V>
+static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_out, int64_t *total_dev) {
+  int n_blocks = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  if (n_blocks < 1) n_blocks = 1;
+  void *bs;
+  BGNN_TRY(ctx_workspace(ctx, 5, (size_t)n_blocks * sizeof(int32_t), &bs));
+  hipLaunchKernelGGL(scan_reduce_kernel<V>, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, val, n,
+                     (int32_t *)bs);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)bs, n_blocks, total_dev);
+  *block_off_out = (int32_t *)bs;
+  return BGNN_OK;
+}
+
+int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts) {
+  const Stencil st = make_stencil(opts->connectivity);
+  const int64_t cells = g->total_cells;
+  // 1. compaction scan
+  {
+    ProfScope ps(ctx, BGNN_K_SCAN);
+    MaskValue mv{tiles->mask};
+    int32_t *block_off;
+    BGNN_TRY(run_scan_counts(ctx, mv, cells, &block_off, g->d_counts));
+    int n_blocks = (int)((cells + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(scan_apply_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
+                       block_off, g->d_node_id, g->d_cell_of_node);
+  }
+  // 2. box statistics
+  double *vs, *vc, *vq;
+  float *lmean, *lstd;
+  {
+    void *p;
+    BGNN_TRY(ctx_workspace(ctx, 0, (size_t)cells * sizeof(double) * 3, &p));
+    vs = (double *)p; vc = vs + cells; vq = vc + cells;
+    BGNN_TRY(ctx_workspace(ctx, 1, (size_t)cells * sizeof(float) * 2, &p));
+    lmean = (float *)p; lstd = lmean + cells;
+  }
+  int max_h = 0, max_w = 0;
+  for (auto &t : g->h_tiles) { if (t.h > max_h) max_h = t.h; if (t.w > max_w) max_w = t.w; }
+  {
+    ProfScope ps(ctx, BGNN_K_STATS);
+    hipLaunchKernelGGL(stats_v_kernel, dim3((max_w + 63) / 64, g->n_tiles), dim3(64), 0, ctx->stream, g->d_tiles,
+                       tiles->depth, tiles->mask, vs, vc, vq);
+    hipLaunchKernelGGL(stats_h_kernel, dim3((max_h + 63) / 64, g->n_tiles), dim3(64), 0, ctx->stream, g->d_tiles,
+                       vs, vc, vq, lmean, lstd);
+  }
+  // 3. features + neighbour table + edge attributes
+  {
+    ProfScope ps(ctx, BGNN_K_FEATURES);
+    FeatureArgs a{};
+    a.tiles = g->d_tiles; a.items = g->d_items; a.depth = tiles->depth; a.mask = tiles->mask;
+    a.unc = tiles->uncertainty; a.local_mean = lmean; a.local_std = lstd; a.node_id = g->d_node_id;
+    a.x8 = g->d_x8; a.node_local_std = g->d_local_std; a.nbr = g->d_nbr; a.eattr = g->d_eattr;
+    a.F = g->F; a.ED = g->ED;
+    // final column list: requested features (uncertainty skipped when absent), then
+    // uncertainty appended when given and not listed (:288-316)
+    int nf = 0; bool listed_unc = false;
+    for (int i = 0; i < opts->n_node_features; ++i) {
+      int fid = opts->node_features[i];
+      if (fid == BGNN_NF_UNCERTAINTY) { listed_unc = true; if (!tiles->uncertainty) continue; }
+      a.feat_ids[nf++] = fid;
+    }
+    if (tiles->uncertainty && !listed_unc) a.feat_ids[nf++] = BGNN_NF_UNCERTAINTY;
+    for (int i = 0; i < opts->n_edge_features; ++i) a.edge_ids[i] = opts->edge_features[i];
+    hipLaunchKernelGGL(features_kernel, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+  }
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+int launch_graph_count_edges(bgnn_graph *g) {
+  // per-tile node / edge counts -> host prefix offsets (synchronises)
+  bgnn_ctx *ctx = g->ctx;
+  void *p;
+  BGNN_TRY(ctx_workspace(ctx, 5, (size_t)g->n_tiles * sizeof(int64_t) * 2, &p));
+  int64_t *tn = (int64_t *)p, *te = tn + g->n_tiles;
+  hipLaunchKernelGGL(tile_counts_kernel, dim3(g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles, g->d_node_id,
+                     g->d_nbr, g->K, g->include_self_loops, tn, te);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+int launch_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edge_attr, float *pos,
+                        int64_t *valid_rows, int64_t *valid_cols, float *local_std, int64_t *batch) {
+  bgnn_ctx *ctx = g->ctx;
+  ProfScope ps(ctx, BGNN_K_EXPORT);
+  const int64_t rows = g->total_cells;
+  if (x || pos || valid_rows || valid_cols || local_std || batch) {
+    int nb = (int)((rows + 255) / 256);
+    hipLaunchKernelGGL(export_nodes_kernel, dim3(nb), dim3(256), 0, ctx->stream, g->d_tiles, g->n_tiles,
+                       g->d_counts, g->d_cell_of_node, g->d_x8, g->d_local_std, g->F, x, pos, valid_rows,
+                       valid_cols, local_std, batch);
+  }
+  if (edge_index || edge_attr) {
+    const int KS = g->K + (g->include_self_loops ? 1 : 0);
+    EdgeValue ev{g->d_tiles, g->n_tiles, g->K, KS, g->d_node_id, g->d_nbr};
+    const int64_t n = (int64_t)g->total_cells * KS;
+    BGNN_REQUIRE(n < ((int64_t)1 << 31), "edge export of %lld stencil slots exceeds 2^31; export in smaller batches", (long long)n);
+    int32_t *block_off;
+    BGNN_TRY(run_scan_counts(ctx, ev, n, &block_off, g->d_counts + 1));
+    int n_blocks = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(scan_apply_edges_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, ev, n,
+                       block_off, g->d_counts, g->d_eattr, g->ED, edge_index, edge_attr);
+  }
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+int launch_graph_scatter(bgnn_graph *g, const float *node_values, float fill, float *grid) {
+  bgnn_ctx *ctx = g->ctx;
+  ProfScope ps(ctx, BGNN_K_SCATTER);
+  const int64_t n = g->total_cells;
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g->d_node_id, n,
+                     node_values, fill, grid);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+int launch_results_to_grids(bgnn_graph *g, const int64_t *cls, const float *conf, const float *corr,
+                            float norm_floor, float *cls_grid, float *conf_grid, float *corr_grid) {
+  bgnn_ctx *ctx = g->ctx;
+  ProfScope ps(ctx, BGNN_K_SCATTER);
+  const int64_t n = g->total_cells;
+  hipLaunchKernelGGL(results_to_grids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     g->d_node_id, n, cls, conf, corr, g->d_local_std, norm_floor, cls_grid, conf_grid, corr_grid);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+}  // namespace bgnn

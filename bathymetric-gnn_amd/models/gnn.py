@@ -1,0 +1,293 @@
+"""BathymetricGNN -- drop-in for the reference's ``models/gnn.py`` (GAT backbone).
+
+The module tree and parameter names equal the reference's (and torch_geometric's ``GATConv`` /
+``BatchNorm`` wrappers), so ``load_state_dict`` takes a reference checkpoint unchanged and
+``model.feature_extractor.mlp[0].in_features`` (read at ``scripts/inference_native.py:147``) works.
+The torch parameters are only the weight container: ``forward`` packs them once into the library's
+blob (``bgnn_model_create``) and runs the hand-written HIP kernels (``bgnn_forward``).  Inference
+(eval) semantics only -- dropout is the identity and BatchNorm uses running statistics.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import runtime as rt
+from ..data.graph_construction import GraphData
+
+logger = logging.getLogger(__name__)
+
+
+class LocalFeatureExtractor(nn.Module):
+    """Per-node MLP: Linear, ReLU, Dropout, [hidden blocks], Linear (reference :34-71)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers: int = 2, dropout: float = 0.1):
+        super().__init__()
+        seq = [nn.Linear(in_channels, hidden_channels), nn.ReLU(), nn.Dropout(dropout)]
+        for _ in range(num_layers - 2):
+            seq += [nn.Linear(hidden_channels, hidden_channels), nn.ReLU(), nn.Dropout(dropout)]
+        seq.append(nn.Linear(hidden_channels, out_channels))
+        self.mlp = nn.Sequential(*seq)
+
+
+def _glorot_(t: torch.Tensor):
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+
+
+class GATConv(nn.Module):
+    """Parameter container with torch_geometric ``GATConv``'s names and shapes (edge_dim variant):
+    ``lin.weight [H*C, D]``, ``att_src/att_dst/att_edge [1,H,C]``, ``lin_edge.weight [H*C, edge_dim]``,
+    ``bias [H*C]`` (concat) or ``[C]``.  Initialised like upstream (glorot / zeros)."""
+
+    def __init__(self, in_channels, out_channels, heads=1, dropout=0.0, edge_dim=None, concat=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.dropout, self.edge_dim = concat, dropout, edge_dim
+        self.negative_slope = 0.2
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        if edge_dim is not None:
+            self.lin_edge = nn.Linear(edge_dim, heads * out_channels, bias=False)
+            self.att_edge = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels))
+        _glorot_(self.lin.weight); _glorot_(self.att_src); _glorot_(self.att_dst)
+        if edge_dim is not None:
+            _glorot_(self.lin_edge.weight); _glorot_(self.att_edge)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # older torch_geometric releases store the shared projection as lin_src (+ alias lin_dst)
+        src = prefix + "lin_src.weight"
+        if src in state_dict and prefix + "lin.weight" not in state_dict:
+            state_dict[prefix + "lin.weight"] = state_dict.pop(src)
+            state_dict.pop(prefix + "lin_dst.weight", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class BatchNorm(nn.Module):
+    """torch_geometric's ``BatchNorm`` wrapper: parameters live under ``.module``."""
+
+    def __init__(self, in_channels, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels, eps=eps, momentum=momentum)
+
+
+class GNNBackbone(nn.Module):
+    """L x (GATConv, BatchNorm[, ReLU, Dropout]) (reference :74-188).  Only ``gnn_type='GAT'`` is on
+    the accelerated path; the other conv types of the reference are outside it."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers, gnn_type="GAT", heads=4, dropout=0.1, edge_dim=None):
+        super().__init__()
+        if gnn_type in ("GCN", "GraphSAGE", "GIN"):
+            raise NotImplementedError(f"gnn_type={gnn_type!r}: only the GAT backbone is built on the MI355X path")
+        if gnn_type != "GAT":
+            raise ValueError(f"Unknown GNN type: {gnn_type}")
+        self.gnn_type, self.num_layers, self.dropout = gnn_type, num_layers, dropout
+        self.convs, self.norms = nn.ModuleList(), nn.ModuleList()
+        for i in range(num_layers):
+            last = i == num_layers - 1
+            layer_in = in_channels if i == 0 else hidden_channels * heads
+            self.convs.append(GATConv(layer_in, hidden_channels, heads=1 if last else heads, dropout=dropout,
+                                      edge_dim=edge_dim, concat=not last))
+            self.norms.append(BatchNorm(hidden_channels if last else hidden_channels * heads))
+
+
+class _Head(nn.Module):
+    def __init__(self, in_channels, hidden_channels, out_features, dropout, sigmoid=False):
+        super().__init__()
+        seq = [nn.Linear(in_channels, hidden_channels), nn.ReLU(), nn.Dropout(dropout),
+               nn.Linear(hidden_channels, out_features)]
+        if sigmoid:
+            seq.append(nn.Sigmoid())
+        self.mlp = nn.Sequential(*seq)
+
+
+class ClassificationHead(_Head):
+    def __init__(self, in_channels, hidden_channels, num_classes, dropout=0.1):
+        super().__init__(in_channels, hidden_channels, num_classes, dropout)
+
+
+class ConfidenceHead(_Head):
+    def __init__(self, in_channels, hidden_channels, dropout=0.1):
+        super().__init__(in_channels, hidden_channels, 1, dropout, sigmoid=True)
+
+
+class CorrectionHead(_Head):
+    def __init__(self, in_channels, hidden_channels, dropout=0.1):
+        super().__init__(in_channels, hidden_channels, 1, dropout)
+
+
+class BathymetricGNN(nn.Module):
+    CLASS_SEAFLOOR = 0
+    CLASS_FEATURE = 1
+    CLASS_NOISE = 2
+
+    def __init__(self, in_channels: int, hidden_channels: int = 64, num_gnn_layers: int = 4, gnn_type: str = "GAT",
+                 heads: int = 4, num_classes: int = 3, predict_correction: bool = True, dropout: float = 0.1,
+                 edge_dim: Optional[int] = None):
+        super().__init__()
+        if edge_dim is None:
+            raise NotImplementedError("edge_dim=None (GATConv without edge features) is outside the built path; "
+                                      "the reference always passes edge_dim=3")
+        self.predict_correction = predict_correction
+        self.num_classes = num_classes
+        self.in_channels, self.hidden_channels, self.heads = in_channels, hidden_channels, heads
+        self.num_gnn_layers, self.edge_dim = num_gnn_layers, edge_dim
+        self.feature_extractor = LocalFeatureExtractor(in_channels, hidden_channels, hidden_channels, 2, dropout)
+        self.gnn = GNNBackbone(hidden_channels, hidden_channels, num_gnn_layers, gnn_type, heads, dropout, edge_dim)
+        self.classification_head = ClassificationHead(hidden_channels, hidden_channels // 2, num_classes, dropout)
+        self.confidence_head = ConfidenceHead(hidden_channels, hidden_channels // 2, dropout)
+        self.correction_head = CorrectionHead(hidden_channels, hidden_channels // 2, dropout) if predict_correction else None
+        self._native = None          # (ctx, handle)
+        self._native_key = None
+        logger.info(f"Created BathymetricGNN: {gnn_type} with {num_gnn_layers} layers, {hidden_channels} hidden channels")
+
+    # ---- weights -> library ------------------------------------------------------------------
+    def _desc(self) -> rt.ModelDesc:
+        d = rt.ModelDesc()
+        d.in_channels, d.hidden, d.num_layers = self.in_channels, self.hidden_channels, self.num_gnn_layers
+        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, self.edge_dim
+        d.predict_correction = 1 if self.predict_correction else 0
+        d.bn_eps = float(self.gnn.norms[0].module.eps)
+        return d
+
+    def pack_weights(self) -> np.ndarray:
+        """Flat float32 blob in the order ``bgnn_model_weight_count`` documents (include/bgnn.h)."""
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy().ravel() for k, v in self.state_dict().items()
+              if v.dtype.is_floating_point}
+        parts = []
+        for p in ("feature_extractor.mlp.0", "feature_extractor.mlp.3"):
+            parts += [sd[p + ".weight"], sd[p + ".bias"]]
+        for l in range(self.num_gnn_layers):
+            c, n = f"gnn.convs.{l}.", f"gnn.norms.{l}.module."
+            parts += [sd[c + "lin.weight"], sd[c + "att_src"], sd[c + "att_dst"], sd[c + "att_edge"],
+                      sd[c + "lin_edge.weight"], sd[c + "bias"],
+                      sd[n + "weight"], sd[n + "bias"], sd[n + "running_mean"], sd[n + "running_var"]]
+        heads = ["classification_head", "confidence_head"] + (["correction_head"] if self.predict_correction else [])
+        for h in heads:
+            parts += [sd[h + ".mlp.0.weight"], sd[h + ".mlp.0.bias"], sd[h + ".mlp.3.weight"], sd[h + ".mlp.3.bias"]]
+        return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+    def _weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _drop_native(self):
+        if self._native is not None:
+            ctx, h = self._native
+            try:
+                ctx.lib.bgnn_model_destroy(h)
+            except Exception:
+                pass
+        self._native, self._native_key = None, None
+
+    def native(self, ctx: rt.Context):
+        key = (ctx.device.index, self._weights_version())
+        if self._native is None or self._native_key != key:
+            self._drop_native()
+            blob = self.pack_weights()
+            desc = self._desc()
+            n = ctx.lib.bgnn_model_weight_count(C.byref(desc))
+            if n != blob.size:
+                raise ValueError(f"weight blob has {blob.size} floats, library expects {n}")
+            h = C.c_void_p()
+            rt.check(ctx.lib.bgnn_model_create(ctx.handle, C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)),
+                                               blob.size, C.byref(h)))
+            self._native, self._native_key = (ctx, h), key
+        return self._native[1]
+
+    def __del__(self):
+        try:
+            self._drop_native()
+        except Exception:
+            pass
+
+    # ---- forward -----------------------------------------------------------------------------
+    def _device_of(self, data):
+        if isinstance(data, GraphData):
+            return data.device
+        p = next(self.parameters())
+        return p.device if p.device.type == "cuda" else None
+
+    def _graph_of(self, data, ctx):
+        if isinstance(data, GraphData):
+            return data, None
+        # a Data built elsewhere: x / edge_index / edge_attr tensors (gnn.py:381-383)
+        x = data.x.detach().to(ctx.device, torch.float32).contiguous()
+        ei = data.edge_index.detach().to(ctx.device, torch.int64).contiguous()
+        ea = getattr(data, "edge_attr", None)
+        if ea is None:
+            raise NotImplementedError("edge_attr=None is outside the built path")
+        ea = ea.detach().to(ctx.device, torch.float32).contiguous()
+        h = C.c_void_p()
+        ctx.begin()
+        rt.check(ctx.lib.bgnn_graph_from_edges(ctx.handle, x.shape[0], x.shape[1], rt.ptr(x), ei.shape[1], rt.ptr(ei),
+                                               ea.shape[1], rt.ptr(ea), C.byref(h)))
+        ctx.end()
+        hw = np.zeros((1, 2), np.int32)
+        g = GraphData(ctx, h, hw, x.shape[1], ea.shape[1])
+        del g.grid_shape
+        g._sizes = (x.shape[0], ei.shape[1], np.array([0, x.shape[0]]), np.array([0, ei.shape[1]]))
+        return g, (x, ei, ea)
+
+    def _run(self, data, thr_auto: float, thr_review: float, with_flags: bool, want_hidden: bool = False):
+        ctx = rt.get_context(self._device_of(data))
+        g, keep = self._graph_of(data, ctx)
+        if g.num_features != self.in_channels:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({g.num_nodes}x{g.num_features} and "
+                               f"{self.in_channels}x{self.hidden_channels})")
+        N, dev = g.num_nodes, ctx.device
+        out = {
+            "class_logits": torch.empty((N, self.num_classes), dtype=torch.float32, device=dev),
+            "class_probs": torch.empty((N, self.num_classes), dtype=torch.float32, device=dev),
+            "predicted_class": torch.empty((N,), dtype=torch.int64, device=dev),
+            "confidence": torch.empty((N,), dtype=torch.float32, device=dev),
+        }
+        if self.predict_correction:
+            out["correction"] = torch.empty((N,), dtype=torch.float32, device=dev)
+        extra = {}
+        if with_flags:
+            extra["action"] = torch.empty((N,), dtype=torch.int64, device=dev)
+            extra["needs_review"] = torch.empty((N,), dtype=torch.bool, device=dev)
+            extra["auto_correct"] = torch.empty((N,), dtype=torch.bool, device=dev)
+        hidden = torch.empty((N, self.hidden_channels), dtype=torch.float32, device=dev) if want_hidden else None
+        o = rt.Outputs()
+        o.class_logits, o.class_probs = out["class_logits"].data_ptr(), out["class_probs"].data_ptr()
+        o.predicted_class, o.confidence = out["predicted_class"].data_ptr(), out["confidence"].data_ptr()
+        o.correction = out["correction"].data_ptr() if self.predict_correction else None
+        if with_flags:
+            o.action, o.needs_review = extra["action"].data_ptr(), extra["needs_review"].data_ptr()
+            o.auto_correct = extra["auto_correct"].data_ptr()
+        if hidden is not None:
+            o.hidden = hidden.data_ptr()
+        model_h = self.native(ctx)
+        if N > 0:
+            ctx.begin()
+            rt.check(ctx.lib.bgnn_forward(ctx.handle, model_h, g._handle, C.c_float(thr_auto), C.c_float(thr_review),
+                                          C.byref(o)))
+            ctx.end()
+        out.update(extra)
+        if hidden is not None:
+            out["hidden"] = hidden
+        return out
+
+    def forward(self, data) -> Dict[str, torch.Tensor]:
+        """class_logits [N,C], class_probs [N,C], predicted_class [N] i64, confidence [N],
+        correction [N] (reference :360-408).  Always eval semantics."""
+        if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
+            logger.warning("BathymetricGNN.forward in training mode: the MI355X path implements inference "
+                           "(eval) semantics only; dropout / batch statistics are not applied")
+        return self._run(data, 0.85, 0.6, with_flags=False)
+
+    def predict(self, data, auto_correct_threshold: float = 0.85, review_threshold: float = 0.6):
+        """forward + deployment flags (reference :410-451)."""
+        self.eval()
+        with torch.no_grad():
+            return self._run(data, auto_correct_threshold, review_threshold, with_flags=True)

@@ -1,0 +1,211 @@
+"""Tile-batch inference -- drop-in for the reference's ``models/pipeline.py``.
+
+``TileBatchEngine`` is the MI355X-native core: a batch of tiles goes through ONE fused call
+(``bgnn_infer_tiles``: graph build -> forward -> node-to-grid scatter + correction
+de-normalisation) and comes back as three [h, w] grids per tile.  ``BathymetricPipeline`` keeps the
+reference's class surface (``__init__``, ``load_model``, ``process``, ``_process_tile``,
+``_apply_corrections``) on top of it; ``process_grid`` is the in-memory entry (file I/O needs GDAL,
+which is outside the path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import runtime as rt
+from ..config import Config
+from ..config.constants import CORRECTION_NORM_FLOOR
+from ..data import BathymetricGrid, GraphBuilder, TileManager, TileMerger
+from .gnn import BathymetricGNN
+
+logger = logging.getLogger(__name__)
+
+
+class TileBatchEngine:
+    """Fused per-batch inference on one GPU (one engine per worker / device)."""
+
+    def __init__(self, model: BathymetricGNN, graph_builder: GraphBuilder, device=None,
+                 auto_correct_threshold: float = 0.85, review_threshold: float = 0.6,
+                 norm_floor: float = CORRECTION_NORM_FLOOR):
+        self.model = model
+        self.graph_builder = graph_builder
+        self.ctx = rt.get_context(device if device is not None else graph_builder._device)
+        self.auto_correct_threshold = auto_correct_threshold
+        self.review_threshold = review_threshold
+        self.norm_floor = norm_floor
+
+    def infer_device(self, hw: np.ndarray, res: np.ndarray, depth_t: torch.Tensor, mask_t: torch.Tensor,
+                     unc_t: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+                     n_nodes_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device-resident tiles in, device-resident grids out: returns float32 [3, cells]
+        (classification, confidence, correction), same cell layout as ``depth_t``.  Asynchronous
+        with respect to the host."""
+        ctx = self.ctx
+        cells = depth_t.numel()
+        if out is None:
+            out = torch.empty((3, cells), dtype=torch.float32, device=ctx.device)
+        tiles, keep = rt.make_tiles(hw, res, depth_t, mask_t, unc_t)
+        model_h = self.model.native(ctx)
+        ctx.begin()
+        rt.check(ctx.lib.bgnn_infer_tiles(
+            ctx.handle, model_h, C.byref(tiles), C.byref(self.graph_builder._opts),
+            C.c_float(self.auto_correct_threshold), C.c_float(self.review_threshold), C.c_float(self.norm_floor),
+            rt.ptr(out[0]), rt.ptr(out[1]), rt.ptr(out[2]), rt.ptr(n_nodes_out)))
+        ctx.end()
+        return out
+
+    def infer(self, depths: Sequence[np.ndarray], masks: Sequence[Optional[np.ndarray]],
+              uncs: Optional[Sequence[Optional[np.ndarray]]], resolutions) -> List[Dict[str, np.ndarray]]:
+        """Host grids in, per-tile dicts of host grids out."""
+        if len(depths) == 0:
+            return []
+        use_unc = uncs if (uncs is not None and self.model.in_channels == self.graph_builder.n_node_columns(True)
+                           and any(u is not None for u in uncs)) else None
+        hw, res, d, m, u = self.graph_builder.upload_tiles(depths, masks, use_unc, resolutions)
+        out = self.infer_device(hw, res, d, m, u).cpu().numpy()
+        results, off = [], 0
+        for i in range(hw.shape[0]):
+            h, w = int(hw[i, 0]), int(hw[i, 1])
+            n = h * w
+            results.append({"classification": out[0, off:off + n].reshape(h, w).copy(),
+                            "confidence": out[1, off:off + n].reshape(h, w).copy(),
+                            "correction": out[2, off:off + n].reshape(h, w).copy()})
+            off += n
+        return results
+
+
+class BathymetricPipeline:
+    """Complete inference pipeline (reference ``BathymetricPipeline``, models/pipeline.py:36-382)."""
+
+    def __init__(self, config: Config, vr_bag_mode: str = "resampled", tile_batch: int = 16):
+        self.config = config
+        self.vr_bag_mode = vr_bag_mode
+        self.tile_batch = max(1, int(tile_batch))
+        self.tile_manager = TileManager(tile_size=config.tile.tile_size, overlap=config.tile.overlap,
+                                        min_valid_ratio=config.tile.min_valid_ratio)
+        # like the reference (:64-67), include_self_loops is not forwarded
+        self.graph_builder = GraphBuilder(connectivity=config.graph.connectivity,
+                                          edge_features=config.graph.edge_features)
+        self.model: Optional[BathymetricGNN] = None
+        self._engine: Optional[TileBatchEngine] = None
+        if config.device != "cuda" or not torch.cuda.is_available():
+            raise rt.BgnnError(f"config.device={config.device!r}: this pipeline runs on an MI355X only "
+                               "(there is no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        logger.info(f"Pipeline initialized, device: {self.device}")
+
+    # ---- model -----------------------------------------------------------------------------
+    def set_model(self, model: BathymetricGNN):
+        self.model = model.to(self.device).eval()
+        self._engine = TileBatchEngine(self.model, self.graph_builder, self.device,
+                                       self.config.inference.auto_correct_threshold,
+                                       self.config.inference.review_threshold)
+
+    def load_model(self, model_path: Union[str, Path]):
+        """Checkpoint -> model (reference :92-132).  Accepts the trainer's dict
+        (``model_state_dict`` + ``in_channels`` / ``edge_dim`` / optional ``model_config`` or
+        pickled ``config``) and a plain ``{state_dict, meta}`` form.  Loaded with
+        ``weights_only=True`` first; a checkpoint that pickles the reference's ``Config`` object needs
+        the reference's ``config`` package importable and is then loaded the reference's way."""
+        model_path = Path(model_path)
+        if not model_path.exists():
+            raise FileNotFoundError(f"Model not found: {model_path}")
+        try:
+            ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+        except Exception:
+            ckpt = torch.load(model_path, map_location="cpu", weights_only=False)
+        mc = ckpt.get("model_config", None)
+        if mc is None and ckpt.get("config", None) is not None:
+            mc = getattr(ckpt["config"], "model", None)
+        if mc is None:
+            mc = self.config.model
+        get = (lambda k, dflt=None: mc.get(k, dflt)) if isinstance(mc, dict) else (lambda k, dflt=None: getattr(mc, k, dflt))
+        sd = ckpt.get("model_state_dict", ckpt.get("state_dict"))
+        model = BathymetricGNN(
+            in_channels=ckpt.get("in_channels", 7), hidden_channels=get("gnn_hidden_channels", 64),
+            num_gnn_layers=get("gnn_num_layers", 4), gnn_type=get("gnn_type", "GAT"), heads=get("gnn_heads", 4),
+            num_classes=get("num_classes", 3), predict_correction=get("predict_correction", True), dropout=0.0,
+            edge_dim=ckpt.get("edge_dim", 3))
+        model.load_state_dict(sd)
+        self.set_model(model)
+        logger.info(f"Model loaded from {model_path}")
+
+    # ---- per tile ----------------------------------------------------------------------------
+    def _tile_uncertainty(self, tile):
+        # The reference passes tile.uncertainty unconditionally (:253), which makes x 8 columns wide
+        # and fails for a 7-channel model; like NativeVRProcessor we drop the band when the model
+        # does not take it.
+        return tile.uncertainty if self.model.in_channels == 8 else None
+
+    def _process_tiles(self, tiles, grid: BathymetricGrid) -> List[Dict[str, np.ndarray]]:
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        res = self._engine.infer([t.data for t in tiles], [t.valid_mask for t in tiles],
+                                 [self._tile_uncertainty(t) for t in tiles], [grid.resolution] * len(tiles))
+        for r, t in zip(res, tiles):
+            r["cleaned_depth"] = t.data       # original; corrections are applied after stitching (:310)
+        return res
+
+    def _process_tile(self, tile, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
+        """One tile -> {'cleaned_depth', 'classification', 'confidence', 'correction'} (reference :243-314)."""
+        return self._process_tiles([tile], grid)[0]
+
+    # ---- whole grid ----------------------------------------------------------------------------
+    def process_grid(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
+        """The body of ``process`` between load and save (reference :163-211), tiles batched."""
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        merger = TileMerger(self.tile_manager)
+        merger.initialize(grid_shape=grid.shape, channels=["cleaned_depth", "classification", "confidence", "correction"])
+        _, _, specs = self.tile_manager.compute_tile_grid(grid.shape)
+        by_pos = {(s.tile_row, s.tile_col): s for s in specs}
+        num_tiles, pending = 0, []
+
+        def flush():
+            nonlocal num_tiles
+            for t, r in zip(pending, self._process_tiles(pending, grid)):
+                merger.add_tile(by_pos[(t.tile_row, t.tile_col)], r)   # ascending spec order
+                num_tiles += 1
+            pending.clear()
+
+        for tile in self.tile_manager.iterate_tiles(grid, skip_empty=True):
+            pending.append(tile)
+            if len(pending) >= self.tile_batch:
+                flush()
+        if pending:
+            flush()
+        logger.info(f"Processed {num_tiles} tiles ({len(specs) - num_tiles} skipped below min_valid_ratio)")
+        results = merger.finalize()
+        valid_mask = grid.valid_mask
+        results["valid_mask"] = valid_mask.astype(np.float32)
+        unprocessed = valid_mask & np.isnan(results["classification"])
+        if np.any(unprocessed):                      # :198-207
+            logger.info(f"Preserving {int(np.sum(unprocessed)):,} valid cells from unprocessed tiles")
+            results["cleaned_depth"][unprocessed] = grid.depth[unprocessed]
+            for ch in ("classification", "confidence", "correction"):
+                results[ch][unprocessed] = 0.0
+        results["cleaned_depth"] = self._apply_corrections(grid, results)
+        return results
+
+    def process(self, input_path, output_path, export_extras: bool = True) -> Dict[str, np.ndarray]:
+        """File in, file out (reference :134-241).  Reading / writing BAG / GeoTIFF is the
+        reference's GDAL code and is not part of this package."""
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        raise ImportError("GDAL is required to read/write survey files; load the grid with the reference's "
+                          "BathymetricLoader and call process_grid(grid) instead")
+
+    def _apply_corrections(self, grid: BathymetricGrid, results: Dict[str, np.ndarray]) -> np.ndarray:
+        """cleaned = depth - correction where class == NOISE, confidence > threshold, valid (:316-349)."""
+        cleaned = grid.depth.copy()
+        apply = ((results["classification"] == BathymetricGNN.CLASS_NOISE)
+                 & (results["confidence"] > self.config.inference.auto_correct_threshold) & grid.valid_mask)
+        cleaned[apply] = grid.depth[apply] - results["correction"][apply]
+        nvalid = max(int(np.sum(grid.valid_mask)), 1)
+        logger.info(f"Applied corrections to {int(np.sum(apply))} cells ({100 * np.sum(apply) / nvalid:.1f}% of valid)")
+        return cleaned

@@ -1,0 +1,198 @@
+/*
+ * bgnn.h -- C ABI of libbgnn_hip.so: the MI355X-native hot path of Bathymetric-GNN.
+ *
+ * The reference (grant-froelich/Bathymetric-GNN) is pure Python and has no FFI of its
+ * own; the drop-in boundary is its Python class API.  Each entry point below names the
+ * reference interface it replaces (file:line into the reference tree).  The Python
+ * mirror of that API (bathymetric-gnn_amd/{data,models,scripts}) binds these symbols
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked DEVICE is a HIP device pointer on the
+ *     context's GPU (a torch tensor's data_ptr()); HOST pointers are ordinary memory.
+ *   - all calls return 0 (BGNN_OK) or a negative error code; bgnn_last_error() gives the
+ *     thread-local message of the last failure.
+ *   - all work is enqueued on the context's HIP stream and is asynchronous unless the
+ *     function is documented to synchronise.  A context is not re-entrant; different
+ *     contexts (one per GPU / per worker) are independent.
+ *   - caller owns every buffer it passes in; the library owns handles it returns and the
+ *     context-scoped arenas behind them (freed by the *_destroy calls).
+ */
+#ifndef BGNN_H
+#define BGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGNN_ABI_VERSION 1
+
+#define BGNN_OK 0
+#define BGNN_ERR_INVALID (-1)     /* bad argument (-> ValueError in the Python mirror)   */
+#define BGNN_ERR_HIP (-2)         /* HIP runtime failure (-> RuntimeError)               */
+#define BGNN_ERR_NOMEM (-3)       /* device allocation failed                            */
+#define BGNN_ERR_UNSUPPORTED (-4) /* valid in the reference, not built here              */
+
+typedef struct bgnn_ctx bgnn_ctx;
+typedef struct bgnn_model bgnn_model;
+typedef struct bgnn_graph bgnn_graph;
+
+int bgnn_abi_version(void);
+const char *bgnn_last_error(void);
+
+/* ---- context: one per GPU worker --------------------------------------------------- */
+/* stream == NULL: the context creates and owns a non-blocking HIP stream; otherwise it
+ * enqueues on the caller's hipStream_t (e.g. torch.cuda.Stream().cuda_stream).
+ * Replaces: the device selection in models/pipeline.py:73-88 and
+ * scripts/inference_native.py:381-394. */
+int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out);
+int bgnn_ctx_destroy(bgnn_ctx *ctx);
+int bgnn_ctx_synchronize(bgnn_ctx *ctx);
+void *bgnn_ctx_stream(bgnn_ctx *ctx);
+
+/* Per-kernel device timing with HIP events on the context's stream.  kernel_mask selects
+ * kernels by (1u << BGNN_K_*); 0 switches profiling off.  bgnn_ctx_profile_read
+ * synchronises, adds the elapsed time of every recorded launch to ms[BGNN_K_COUNT] /
+ * launches[BGNN_K_COUNT] (HOST arrays) and clears the record list. */
+enum {
+  BGNN_K_SCAN = 0,      /* valid-cell compaction scans                                  */
+  BGNN_K_STATS = 1,     /* K1a masked 5x5 box statistics (fp64)                         */
+  BGNN_K_FEATURES = 2,  /* K1b/K2 node features + stencil neighbour table + edge attrs  */
+  BGNN_K_EXPORT = 3,    /* PyG-layout materialisation (edge_index int64, ...)           */
+  BGNN_K_GEMM = 4,      /* K3 dense node-feature x weight GEMM (f32 MFMA)               */
+  BGNN_K_ATTCOEF = 5,   /* alpha_src / alpha_dst dot products                           */
+  BGNN_K_AGGREGATE = 6, /* K4 gather - per-node softmax - weighted aggregate (+BN+ReLU) */
+  BGNN_K_HEADS = 7,     /* K5 output heads                                              */
+  BGNN_K_SCATTER = 8,   /* K6 node -> grid scatter + correction de-normalisation        */
+  BGNN_K_COUNT = 9
+};
+int bgnn_ctx_profile(bgnn_ctx *ctx, uint32_t kernel_mask);
+int bgnn_ctx_profile_read(bgnn_ctx *ctx, double *ms, int64_t *launches);
+
+/* ---- model: BathymetricGNN (models/gnn.py:263-358), GAT backbone only --------------- */
+typedef struct bgnn_model_desc {
+  int32_t in_channels;        /* 7, or 8 with the uncertainty column                     */
+  int32_t hidden;             /* 64 (must be a multiple of 32, <= 64)                    */
+  int32_t num_layers;         /* num_gnn_layers (>= 1)                                   */
+  int32_t heads;              /* 4; last layer always uses 1 head, mean (gnn.py:125-132) */
+  int32_t num_classes;        /* 3                                                       */
+  int32_t edge_dim;           /* 3                                                       */
+  int32_t predict_correction; /* correction head present                                 */
+  float bn_eps;               /* torch BatchNorm1d eps, 1e-5                             */
+} bgnn_model_desc;
+
+/* Number of float32 values bgnn_model_create expects in `weights`, in this order
+ * (torch / torch_geometric state_dict names, each tensor row-major as torch stores it):
+ *   feature_extractor.mlp.0.{weight[hid,in],bias[hid]}, feature_extractor.mlp.3.{weight[hid,hid],bias[hid]}
+ *   for l in 0..L-1 (H_l = heads, or 1 for the last layer; D_l = hid for l=0 else hid*heads;
+ *                    W_l = H_l*hid, or hid for the last layer):
+ *     gnn.convs.l.lin.weight[H_l*hid, D_l], att_src[H_l*hid], att_dst[H_l*hid], att_edge[H_l*hid],
+ *     gnn.convs.l.lin_edge.weight[H_l*hid, edge_dim], gnn.convs.l.bias[W_l],
+ *     gnn.norms.l.module.{weight, bias, running_mean, running_var}[W_l]
+ *   classification_head.mlp.0.{weight[hid/2,hid],bias}, classification_head.mlp.3.{weight[classes,hid/2],bias}
+ *   confidence_head.mlp.0.{..}, confidence_head.mlp.3.{weight[1,hid/2],bias[1]}
+ *   correction_head.mlp.0.{..}, correction_head.mlp.3.{..}     (only if predict_correction)
+ */
+size_t bgnn_model_weight_count(const bgnn_model_desc *desc);
+
+/* Replaces BathymetricGNN.__init__ + load_state_dict + .to(device).eval()
+ * (models/pipeline.py:115-130, scripts/inference_native.py:406-419).  `weights` is HOST
+ * memory; the library folds lin_edge.att_edge -> V[H,edge_dim] and BatchNorm(+conv bias)
+ * -> scale/shift in float64 and uploads the packed result.  Synchronises. */
+int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *desc, const float *weights,
+                      size_t n_weights, bgnn_model **out);
+int bgnn_model_destroy(bgnn_model *model);
+
+/* ---- graph construction: GraphBuilder.build_graph (data/graph_construction.py:91-174) */
+enum { /* node feature ids, graph_construction.py:288-306 */
+  BGNN_NF_DEPTH = 0, BGNN_NF_LOCAL_MEAN = 1, BGNN_NF_LOCAL_STD = 2, BGNN_NF_GRADIENT_X = 3,
+  BGNN_NF_GRADIENT_Y = 4, BGNN_NF_GRADIENT_MAGNITUDE = 5, BGNN_NF_CURVATURE = 6,
+  BGNN_NF_UNCERTAINTY = 7
+};
+enum { /* edge feature ids, graph_construction.py:346-367 (anything else is 0.0) */
+  BGNN_EF_DISTANCE = 0, BGNN_EF_DEPTH_DIFFERENCE = 1, BGNN_EF_SLOPE = 2, BGNN_EF_ZERO = 3
+};
+
+typedef struct bgnn_tiles { /* a batch of independent grids (tiles / refinement grids) */
+  int32_t n_tiles;
+  const int32_t *hw;         /* HOST [n_tiles][2] = (height, width), each >= 2           */
+  const double *resolution;  /* HOST [n_tiles][2] = (res_x, res_y)                       */
+  const float *depth;        /* DEVICE, tiles concatenated, each row-major [h][w]        */
+  const uint8_t *mask;       /* DEVICE, 1 = valid cell (GraphBuilder's valid_mask)       */
+  const float *uncertainty;  /* DEVICE or NULL                                           */
+} bgnn_tiles;
+
+typedef struct bgnn_graph_opts {
+  int32_t connectivity;       /* 4 or 8 (graph_construction.py:78-89); 16 = dilated ext. */
+  int32_t include_self_loops; /* appended last in the exported edge list (:226-229)      */
+  int32_t n_node_features;    /* <= 8, ids above in output column order; uncertainty is  */
+  int32_t node_features[8];   /*   appended by the library when given and not listed     */
+  int32_t n_edge_features;    /* 1..4                                                    */
+  int32_t edge_features[4];
+} bgnn_graph_opts;
+
+/* Builds the device-resident graph for every tile of the batch: row-major valid-cell
+ * compaction, stencil neighbour table, node features, edge attributes.  Asynchronous. */
+int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts,
+                     bgnn_graph **out);
+
+/* A graph given as PyG tensors (a `Data` built elsewhere): x[N,F], edge_index[2,E] int64
+ * (row 0 = source, row 1 = target), edge_attr[E,edge_dim]; all DEVICE.  Replaces the
+ * (x, edge_index, edge_attr) triple read at models/gnn.py:381-383.  Synchronises. */
+int bgnn_graph_from_edges(bgnn_ctx *ctx, int64_t n_nodes, int32_t n_feat, const float *x,
+                          int64_t n_edges, const int64_t *edge_index, int32_t edge_dim,
+                          const float *edge_attr, bgnn_graph **out);
+int bgnn_graph_destroy(bgnn_graph *graph);
+
+/* Sizes (synchronises).  node_off / edge_off: HOST [n_tiles+1] prefix offsets of each
+ * tile's nodes / edges in the batch (PyG Batch.from_data_list order); may be NULL. */
+int bgnn_graph_counts(bgnn_graph *graph, int64_t *n_nodes, int64_t *n_edges, int32_t *n_feat,
+                      int32_t *edge_dim, int64_t *node_off, int64_t *edge_off);
+
+/* Materialise the PyG-compatible tensors of the Data object (graph_construction.py:144-167,
+ * batched as torch_geometric Batch.from_data_list does): any pointer may be NULL.
+ * All DEVICE: x[N,F] f32, edge_index[2,E] i64 (offset-major, node-ascending per tile;
+ * bit-exact with the reference), edge_attr[E,edge_dim] f32, pos[N,2] f32 = (col,row),
+ * valid_rows/valid_cols[N] i64, local_std[N] f32, batch[N] i64. */
+int bgnn_graph_export(bgnn_graph *graph, float *x, int64_t *edge_index, float *edge_attr,
+                      float *pos, int64_t *valid_rows, int64_t *valid_cols, float *local_std,
+                      int64_t *batch);
+
+/* GraphBuilder.graph_to_grid (graph_construction.py:471-505) for every tile of the batch:
+ * grid (DEVICE, same layout as bgnn_tiles.depth) = fill, then grid[valid cell] = value. */
+int bgnn_graph_scatter(bgnn_graph *graph, const float *node_values, float fill, float *grid);
+
+/* ---- forward: BathymetricGNN.forward / .predict (models/gnn.py:360-451) ------------- */
+typedef struct bgnn_outputs { /* all DEVICE, any may be NULL */
+  float *class_logits;      /* [N, classes]                                              */
+  float *class_probs;       /* [N, classes]                                              */
+  int64_t *predicted_class; /* [N]                                                       */
+  float *confidence;        /* [N]                                                       */
+  float *correction;        /* [N] (normalised units)                                    */
+  int64_t *action;          /* [N] 0 keep / 1 auto-correct / 2 review (gnn.py:436-445)   */
+  uint8_t *needs_review;    /* [N]                                                       */
+  uint8_t *auto_correct;    /* [N]                                                       */
+  float *hidden;            /* [N, hidden] backbone output (diagnostics / parity tests)  */
+} bgnn_outputs;
+
+int bgnn_forward(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, float auto_correct_threshold,
+                 float review_threshold, const bgnn_outputs *out);
+
+/* BathymetricPipeline._process_tile (models/pipeline.py:243-314) and
+ * NativeVRProcessor._extract_results_from_outputs (scripts/inference_native.py:181-204)
+ * for a whole batch, fused: build -> predict -> scatter.  Output grids (DEVICE, layout of
+ * bgnn_tiles.depth, fill 0.0): classification (class id as float), confidence,
+ * correction = normalised correction * max(local_std, norm_floor).  Asynchronous.
+ * n_nodes_out: optional DEVICE int64[1] receiving the number of classified nodes. */
+int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *model, const bgnn_tiles *tiles,
+                     const bgnn_graph_opts *opts, float auto_correct_threshold, float review_threshold,
+                     float norm_floor, float *classification, float *confidence, float *correction,
+                     int64_t *n_nodes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGNN_H */

@@ -1,0 +1,196 @@
+"""GPU parity, model forward (K3-K5) and the fused tile path (K6), through the C ABI, against the
+CPU oracle (oracle/gat_cpu.py -- parity unpinned, see oracle/__init__.py).
+
+Tolerance (north_star): class logits within 1e-4 absolute, float32.  Probabilities / confidence /
+correction get the same absolute bar; predicted_class / action must agree wherever the oracle's
+top-2 probability gap (or distance to a threshold) exceeds 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gat_cpu, graph_cpu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _model(sd, in_channels=7, num_layers=4, heads=4, hidden=64, predict_correction=True):
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    m = BathymetricGNN(in_channels=in_channels, hidden_channels=hidden, num_gnn_layers=num_layers, heads=heads,
+                       predict_correction=predict_correction, edge_dim=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return m.to(torch.device("cuda:0")).eval()
+
+
+def _compare(out, ref, check_flags=True):
+    err = (out["class_logits"].cpu() - ref["class_logits"]).abs().max().item()
+    assert err < TOL, f"logits differ by {err}"
+    assert (out["class_probs"].cpu() - ref["class_probs"]).abs().max().item() < TOL
+    assert (out["confidence"].cpu() - ref["confidence"]).abs().max().item() < TOL
+    if "correction" in ref:
+        assert (out["correction"].cpu() - ref["correction"]).abs().max().item() < TOL
+    top2 = torch.topk(ref["class_probs"], 2, dim=-1).values
+    sure = (top2[:, 0] - top2[:, 1]) > TOL
+    assert out["predicted_class"].dtype == torch.int64
+    assert torch.equal(out["predicted_class"].cpu()[sure], ref["predicted_class"][sure])
+    if check_flags and "action" in ref:
+        c = ref["confidence"]
+        sure_a = sure & ((c - 0.85).abs() > TOL) & ((c - 0.6).abs() > TOL)
+        assert torch.equal(out["action"].cpu()[sure_a], ref["action"][sure_a])
+        assert torch.equal(out["needs_review"].cpu()[sure_a], ref["needs_review"][sure_a])
+        assert torch.equal(out["auto_correct"].cpu()[sure_a], ref["auto_correct"][sure_a])
+    return err
+
+
+@pytest.mark.parametrize("shape,variant,layers,unc,seed", [
+    ((64, 64), "V0", 3, False, 0),      # BASELINE config 1 shape
+    ((64, 64), "V1", 4, False, 1),
+    ((50, 37), "V1", 4, True, 4),       # in_channels = 8
+    ((24, 40), "V1", 1, False, 6),      # single (last-layer-only) GNN layer
+    ((3, 3), "V0", 4, False, 7),
+])
+def test_predict_matches_oracle(shape, variant, layers, unc, seed, gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, u = synthetic.synthetic_tile(shape[0], shape[1], seed, variant if min(shape) >= 16 else "V0", unc)
+    sd = synthetic.synthetic_state_dict(in_channels=8 if unc else 7, num_layers=layers, seed=1234)
+    model = _model(sd, in_channels=8 if unc else 7, num_layers=layers)
+    g = GraphBuilder().build_graph(d, m, u, (0.5, 0.5))
+    out = model.predict(g)
+    og = graph_cpu.build_graph(d, m, u, (0.5, 0.5))
+    ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+    _compare(out, ref)
+
+
+def test_config2_256_tile_logits_and_fp64_distance(gpu_device):
+    """BASELINE config 2: single 256x256 tile, k=8, 4 layers, fp32, logits vs CPU reference."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(256, 256, 1, "V1")
+    sd = synthetic.synthetic_state_dict(seed=1234)
+    model = _model(sd)
+    g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
+    out = model.predict(g)
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    ref32 = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+    _compare(out, ref32)
+    ref64 = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr, dtype=torch.float64)
+    e_gpu = (out["class_logits"].cpu().double() - ref64["class_logits"]).abs().max().item()
+    e_cpu = (ref32["class_logits"].double() - ref64["class_logits"]).abs().max().item()
+    print(f"max |logit - fp64|: gpu {e_gpu:.2e}  cpu-fp32 {e_cpu:.2e}")
+    assert e_gpu < TOL
+
+
+def test_hidden_backbone_output(gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(40, 40, 12, "V1")
+    sd = synthetic.synthetic_state_dict(seed=77)
+    model = _model(sd)
+    g = GraphBuilder().build_graph(d, m, None, (1.0, 1.0))
+    out = model._run(g, 0.85, 0.6, with_flags=False, want_hidden=True)
+    og = graph_cpu.build_graph(d, m, None, (1.0, 1.0))
+    ref = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr)
+    assert (out["hidden"].cpu() - ref["hidden"]).abs().max().item() < TOL
+
+
+def test_variants_heads_hidden_nocorr_legacy_keys(gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(30, 30, 21, "V1")
+    g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    for kw in (dict(heads=2, hidden=64), dict(heads=4, hidden=32), dict(heads=1, hidden=64),
+               dict(predict_correction=False), dict(legacy=True)):
+        legacy = kw.pop("legacy", False)
+        heads, hidden, pc = kw.get("heads", 4), kw.get("hidden", 64), kw.get("predict_correction", True)
+        sd = synthetic.synthetic_state_dict(hidden=hidden, heads=heads, predict_correction=pc, seed=5, legacy_lin_src=legacy)
+        model = _model(sd, heads=heads, hidden=hidden, predict_correction=pc)
+        out = model.predict(g)
+        ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+        _compare(out, ref)
+        assert ("correction" in out) == pc
+
+
+def test_batched_equals_per_graph_and_vr_processor(gpu_device):
+    """NativeVRProcessor semantics (scripts/inference_native.py:249-342): batched flush == per-grid
+    processing == oracle; empty grids return zeros immediately."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor
+    sd = synthetic.synthetic_state_dict(in_channels=8, seed=1234)
+    model = _model(sd, in_channels=8)
+    gb = GraphBuilder()
+    proc = NativeVRProcessor(model, gb, torch.device("cuda:0"))
+    assert proc.expected_in_channels == 8
+    grids = synthetic.vr_grid_stream(24, seed0=2000)
+    dead = np.full((5, 6), 1.0e6, np.float32)
+    assert proc.add_to_batch(dead, np.zeros_like(dead), (1.0, 1.0)) is not None
+    for d, u, r in grids:
+        assert proc.add_to_batch(d, u, r) is None
+    assert proc.batch_pending and not proc.batch_ready
+    res = proc.flush_batch()
+    assert len(res) == len(grids) and not proc.batch_pending
+    for (d, u, r), (cls, conf, corr) in zip(grids[:8], res[:8]):
+        m = (d != 1.0e6) & np.isfinite(d)
+        og = graph_cpu.build_graph(d, m, u, r)
+        ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
+        single = proc.process_grid(d, u, r)
+        assert cls.shape == d.shape and cls.dtype == np.float32
+        assert np.abs(conf - ref["confidence"]).max() < TOL and np.abs(corr - ref["correction"]).max() < 2e-4
+        assert np.abs(single[1] - conf).max() < 1e-6 and np.array_equal(single[0], cls)
+        top2 = np.sort(gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr)["class_probs"].numpy(), axis=1)
+        sure = graph_cpu.graph_to_grid(og, (top2[:, -1] - top2[:, -2]) > TOL, 0.0).astype(bool)
+        assert np.array_equal(cls[sure], ref["classification"][sure])
+        assert np.all(cls[~m] == 0) and np.all(conf[~m] == 0) and np.all(corr[~m] == 0)
+
+
+def test_seven_channel_model_drops_uncertainty(gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor
+    sd = synthetic.synthetic_state_dict(in_channels=7, seed=3)
+    proc = NativeVRProcessor(_model(sd), GraphBuilder(), torch.device("cuda:0"))
+    d, u, r = synthetic.vr_grid_stream(1, seed0=5)[0]
+    cls, conf, corr = proc.process_grid(d, u, r)
+    m = (d != 1.0e6) & np.isfinite(d)
+    og = graph_cpu.build_graph(d, m, None, r)
+    ref = gat_cpu.process_tile(sd, og)
+    assert np.abs(conf - ref["confidence"]).max() < TOL
+    # and a graph with the wrong number of feature columns fails like the reference's matmul would
+    g8 = GraphBuilder().build_graph(d, m, u, r)
+    with pytest.raises(RuntimeError):
+        _model(sd).predict(g8)
+
+
+def test_full_batch_properties(gpu_device):
+    """BASELINE-sized batch through the fused path: permuting the tiles of a batch permutes the
+    outputs bit-for-bit (tiles are independent), repeat runs are bitwise identical, invalid cells
+    are exactly 0, probabilities sum to 1."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    sd = synthetic.synthetic_state_dict(seed=1234)
+    model = _model(sd)
+    gb = GraphBuilder()
+    eng = TileBatchEngine(model, gb, torch.device("cuda:0"))
+    B, n = 8, 256
+    depth, mask, _ = synthetic.synthetic_tile_batch(B, n, n, 100, "V1")
+    hw = np.tile(np.array([[n, n]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
+    d_t = torch.from_numpy(depth).cuda().reshape(-1); m_t = torch.from_numpy(mask.view(np.uint8)).cuda().reshape(-1)
+    nn = torch.zeros(1, dtype=torch.int64, device="cuda")
+    out = eng.infer_device(hw, res, d_t, m_t, None, n_nodes_out=nn).clone()
+    out2 = eng.infer_device(hw, res, d_t, m_t, None)
+    assert torch.equal(out, out2)
+    assert int(nn.item()) == int(mask.sum())
+    perm = np.random.default_rng(0).permutation(B)
+    d_p = torch.from_numpy(depth[perm]).cuda().reshape(-1); m_p = torch.from_numpy(mask[perm].view(np.uint8)).cuda().reshape(-1)
+    out_p = eng.infer_device(hw, res, d_p, m_p, None)
+    assert torch.equal(out.reshape(3, B, n * n)[:, perm], out_p.reshape(3, B, n * n))
+    inval = ~torch.from_numpy(mask).cuda().reshape(-1)
+    assert float(out[:, inval].abs().max()) == 0.0
+    g = gb.build_graphs(list(depth), list(mask), None, [(0.5, 0.5)] * B)
+    o = model.predict(g)
+    assert (o["class_probs"].sum(-1) - 1).abs().max().item() < 1e-5
+    cls_grid = out[0].reshape(-1)[torch.from_numpy(mask).cuda().reshape(-1)]
+    assert torch.equal(cls_grid, o["predicted_class"].float())

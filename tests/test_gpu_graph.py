@@ -1,0 +1,162 @@
+"""GPU parity, graph construction (K1/K2): the HIP path through the C ABI vs the golden vectors
+produced by the reference's own GraphBuilder, and vs the CPU oracle on seeded inputs.
+
+Bars: edge_index bit-exact (integer work).  x / edge_attr / local_std: the kernels restate the
+numpy/scipy float sequences operation by operation and are expected bit-exact too; the asserted
+tolerance is <= 1 float32 ulp for the two quantities that go through a float64 libm call on the
+device (slope: atan; local_std: sqrt of a cancelling difference), 0 ulp for everything else."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, ulp_diff_f32
+from oracle import graph_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _builder(g):
+    from bathymetric_gnn_amd.data import GraphBuilder
+    return GraphBuilder(connectivity=g["conn"], include_self_loops=g["loops"])
+
+
+def _check_x(x, ref, names=graph_cpu.DEFAULT_NODE_FEATURES):
+    assert x.shape == ref.shape
+    u = ulp_diff_f32(x, ref)
+    for c in range(ref.shape[1]):
+        tol = 1 if (c < len(names) and names[c] == "local_std") else 0
+        assert u[:, c].max(initial=0) <= tol, f"column {c}: {u[:, c].max()} ulp (max abs {np.abs(x[:, c] - ref[:, c]).max()})"
+
+
+def _check_ea(ea, ref):
+    assert ea.shape == ref.shape
+    u = ulp_diff_f32(ea, ref)
+    assert u[:, 0].max(initial=0) == 0 and u[:, 1].max(initial=0) == 0
+    assert u[:, 2].max(initial=0) <= 1
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_graph_matches_reference_golden(name, gpu_device):
+    g = load_golden(name)
+    gb = _builder(g)
+    graph = gb.build_graph(g["depth"], g["mask_arg"], g["unc_arg"], g["res"])
+    N, E = int(g["num_nodes"]), int(g["num_edges"])
+    assert graph.num_nodes == N
+    if N == 0:
+        assert graph.x.shape == (0, 7) and graph.edge_index.shape == (2, 0) and not hasattr(graph, "grid_shape")
+        return
+    assert graph.num_edges == E
+    ei = graph.edge_index.cpu().numpy()
+    assert ei.dtype == np.int64 and ei.shape == (2, E)
+    assert hashlib.sha256(np.ascontiguousarray(ei).tobytes()).hexdigest() == str(g["edge_index_sha256"])
+    x = graph.x.cpu().numpy(); ea = graph.edge_attr.cpu().numpy(); ls = graph.local_std.cpu().numpy()
+    if "x" in g:
+        assert np.array_equal(ei, g["edge_index"].astype(np.int64))
+        _check_x(x, g["x"]); _check_ea(ea, g["edge_attr"])
+        assert ulp_diff_f32(ls, g["local_std"]).max(initial=0) <= 1
+        assert np.array_equal(graph.pos.cpu().numpy(), g["pos"])
+        assert np.array_equal(graph.valid_rows.cpu().numpy(), g["valid_rows"])
+        assert np.array_equal(graph.valid_cols.cpu().numpy(), g["valid_cols"])
+        assert graph.grid_shape == g["depth"].shape and graph.num_valid_cells == N
+    else:
+        _check_x(x[:1024], g["x_head"]); _check_x(x[-1024:], g["x_tail"])
+        _check_ea(ea[:1024], g["ea_head"]); _check_ea(ea[-1024:], g["ea_tail"])
+        o = graph_cpu.build_graph(g["depth"], g["mask_arg"], g["unc_arg"], g["res"])
+        _check_x(x, o.x); _check_ea(ea, o.edge_attr)
+
+
+@pytest.mark.parametrize("shape,variant,unc,seed", [((33, 70), "V1", False, 5), ((128, 96), "V1", True, 6),
+                                                     ((50, 50), "V0", True, 7), ((2, 2), "V0", False, 8),
+                                                     ((300, 17), "V1", False, 9)])
+def test_graph_matches_oracle_seeded(shape, variant, unc, seed, gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, u = synthetic.synthetic_tile(shape[0], shape[1], seed, variant if min(shape) >= 16 else "V0", unc)
+    res = (0.5, 2.0)
+    o = graph_cpu.build_graph(d, m, u, res)
+    g = GraphBuilder().build_graph(d, m, u, res)
+    assert g.num_nodes == o.num_nodes and g.num_edges == o.num_edges
+    assert np.array_equal(g.edge_index.cpu().numpy(), o.edge_index)
+    names = graph_cpu.DEFAULT_NODE_FEATURES + (["uncertainty"] if unc else [])
+    _check_x(g.x.cpu().numpy(), o.x, names)
+    _check_ea(g.edge_attr.cpu().numpy(), o.edge_attr)
+
+
+def test_batched_graph_equals_concatenation(gpu_device):
+    """Batch.from_data_list semantics: node / edge tensors concatenated, edge_index offset by the
+    cumulative node count, batch[N] = graph id."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    grids = synthetic.vr_grid_stream(40, seed0=1000)
+    gb = GraphBuilder()
+    depths = [g[0] for g in grids]; uncs = [g[1] for g in grids]; ress = [g[2] for g in grids]
+    masks = [(d != 1.0e6) & np.isfinite(d) for d in depths]
+    batch = gb.build_graphs(depths, masks, uncs, ress)
+    os_ = [graph_cpu.build_graph(d, m, u, r) for d, m, u, r in zip(depths, masks, uncs, ress)]
+    bx, bei, bea, bls, bb = graph_cpu.batch_graphs(os_)
+    assert batch.num_nodes == bx.shape[0] and batch.num_edges == bei.shape[1]
+    assert np.array_equal(batch.edge_index.cpu().numpy(), bei)
+    assert np.array_equal(batch.batch.cpu().numpy(), bb)
+    _check_x(batch.x.cpu().numpy(), bx, graph_cpu.DEFAULT_NODE_FEATURES + ["uncertainty"])
+    _check_ea(batch.edge_attr.cpu().numpy(), bea)
+    assert np.array_equal(batch.ptr.numpy(), np.cumsum([0] + [o.num_nodes for o in os_]))
+
+
+def test_feature_selection_and_edge_feature_order(gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, u = synthetic.synthetic_tile(20, 24, 3, "V1", True)
+    nf = ["curvature", "depth", "uncertainty", "bogus", "gradient_x"]
+    ef = ["slope", "distance", "other"]
+    o = graph_cpu.build_graph(d, m, u, (1.0, 0.5), node_feature_names=nf, edge_feature_names=ef)
+    g = GraphBuilder(node_features=nf, edge_features=ef).build_graph(d, m, u, (1.0, 0.5))
+    x = g.x.cpu().numpy(); ea = g.edge_attr.cpu().numpy()
+    assert x.shape == o.x.shape == (o.num_nodes, 4)
+    assert ulp_diff_f32(x, o.x).max() == 0
+    assert ulp_diff_f32(ea[:, 1:], o.edge_attr[:, 1:]).max() == 0 and ulp_diff_f32(ea[:, 0], o.edge_attr[:, 0]).max() <= 1
+
+
+def test_graph_to_grid_and_errors(gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(19, 23, 2, "V1")
+    gb = GraphBuilder()
+    g = gb.build_graph(d, m, None, (1.0, 1.0))
+    vals = torch.arange(g.num_nodes, dtype=torch.float32)
+    grid = gb.graph_to_grid(g, vals)                       # default fill NaN
+    o = graph_cpu.build_graph(d, m, None, (1.0, 1.0))
+    exp = graph_cpu.graph_to_grid(o, vals.numpy())
+    assert grid.dtype == np.float32 and np.array_equal(np.isnan(grid), np.isnan(exp))
+    assert np.array_equal(np.nan_to_num(grid), np.nan_to_num(exp))
+    grid0 = gb.graph_to_grid(g.cpu(), vals, fill_value=0.0)   # CPU copy path, as models/pipeline.py:278-303
+    assert np.array_equal(grid0, graph_cpu.graph_to_grid(o, vals.numpy(), 0.0))
+    with pytest.raises(ValueError):
+        gb.graph_to_grid(g, torch.zeros(g.num_nodes, 2))
+    empty = gb.build_graph(np.full((4, 4), np.nan, np.float32))
+    with pytest.raises(ValueError):
+        gb.graph_to_grid(empty, torch.zeros(0))
+    with pytest.raises(ValueError):
+        GraphBuilder(connectivity="6-connected")
+    with pytest.raises(ValueError):                        # np.gradient needs >= 2 samples (behaviour.json)
+        gb.build_graph(np.zeros((1, 5), np.float32))
+
+
+def test_full_tile_properties_256(gpu_device):
+    """BASELINE size: size-independent properties -- E = 4(n-1)(2n-1), symmetric edge set, in-degree
+    histogram of a full 8-connected tile, repeat-run determinism."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    n = 256
+    d, m, _ = synthetic.synthetic_tile(n, n, 1, "V0")
+    gb = GraphBuilder()
+    g = gb.build_graph(d, m, None, (0.5, 0.5))
+    assert g.num_nodes == n * n and g.num_edges == 4 * (n - 1) * (2 * n - 1)
+    ei = g.edge_index
+    key = ei[0] * (n * n) + ei[1]; rkey = ei[1] * (n * n) + ei[0]
+    assert torch.equal(torch.sort(key).values, torch.sort(rkey).values)
+    deg = torch.bincount(ei[1], minlength=n * n)
+    assert int((deg == 8).sum()) == (n - 2) ** 2 and int((deg == 5).sum()) == 4 * (n - 2) and int((deg == 3).sum()) == 4
+    g2 = gb.build_graph(d, m, None, (0.5, 0.5))
+    assert torch.equal(g.x, g2.x) and torch.equal(g.edge_attr, g2.edge_attr) and torch.equal(ei, g2.edge_index)
