@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: classified tile-nodes/s of the fused hot path on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tiles B] [--tile-size S]
+
+A step = one pass of the hot path over one batch of synthetic tiles already resident in HBM:
+``bgnn_infer_tiles`` = graph build (compaction, 5x5 stats, node features, stencil table, edge
+attributes) -> 4-layer GAT forward -> heads -> node-to-grid scatter.  Workload at every N: per GPU
+a batch of B=128 tiles of 256x256 (BASELINE config[1]'s tile: k=8 / 8-connected, fp32, 4 layers,
+all-valid synthetic depth; batched as the metric's "tile-batch").  Tiles are independent, so ranks
+share nothing: weak scaling, no data-path collective (only the timing barrier / max).
+
+Prints ONE JSON line (rank 0).  Extra objects: ``roofline`` (dominant kernel, HIP-event timed on the
+library's stream during the timed steps), ``kernels`` (all kernel classes), ``cpu_baseline`` (the CPU
+oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA (= vector fp32 peak)
+
+
+def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3):
+    """SURVEY.md 8(d) per-node figures (fp32, compulsory traffic: each tensor read once + written once)."""
+    agg_bytes = 0
+    gemm_flops = 2 * (in_ch * hidden + hidden * hidden)            # feature extractor
+    gemm_bytes = 4 * (8 + hidden) + 4 * (hidden + hidden)
+    for l in range(num_layers):
+        last = l == num_layers - 1
+        H = 1 if last else heads
+        d_in = hidden if l == 0 else hidden * heads
+        hc = H * hidden
+        # read xW + write out + alpha_src/alpha_dst + edge attributes
+        agg_bytes += 4 * hc + 4 * hc + 4 * 2 * H + 4 * deg * edge_dim
+        gemm_flops += 2 * d_in * hc
+        gemm_bytes += 4 * (d_in + hc)
+    nh = 3
+    gemm_flops += 2 * hidden * nh * (hidden // 2)
+    gemm_bytes += 4 * (hidden + nh * (hidden // 2))
+    build_bytes = 5 + 28 + 4 + 4 * deg * edge_dim                   # native-internal graph form (133 B)
+    return {"aggregate_bytes": agg_bytes, "gemm_flops": gemm_flops, "gemm_bytes": gemm_bytes, "build_bytes": build_bytes}
+
+
+def cpu_baseline(n_tiles, tile, sd, seed0):
+    """The CPU oracle (vectorised numpy graph build + fp32 torch forward issuing torch_geometric's op
+    sequence + scatter) on `n_tiles` tiles of the same workload.  kind = "port"."""
+    from bathymetric_gnn_amd import synthetic
+    from oracle import gat_cpu, graph_cpu
+    tiles = [synthetic.synthetic_tile(tile, tile, seed0 + i, "V0") for i in range(n_tiles)]
+    # warm-up on a small tile (thread pools, allocator)
+    d, m, _ = synthetic.synthetic_tile(64, 64, 1, "V0")
+    gat_cpu.process_tile(sd, graph_cpu.build_graph(d, m, None, (0.5, 0.5)))
+    nodes = 0
+    t0 = time.perf_counter()
+    tg = 0.0
+    for d, m, _ in tiles:
+        a = time.perf_counter()
+        g = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+        tg += time.perf_counter() - a
+        gat_cpu.process_tile(sd, g)
+        nodes += g.num_nodes
+    dt = time.perf_counter() - t0
+    return {"value": nodes / dt, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_tiles} tiles of {tile}x{tile} (k=8, 4-layer GAT, fp32): numpy graph build + torch CPU forward "
+                      f"+ scatter, {dt:.1f} s wall ({tg:.1f} s of it graph build); os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tiles", type=int, default=128, help="tiles per batch per GPU")
+    ap.add_argument("--tile-size", type=int, default=256)
+    ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # RCCL; used only for the timing barrier / max
+
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+
+    B, S = args.tiles, args.tile_size
+    sd = synthetic.synthetic_state_dict(in_channels=7, num_layers=args.layers, seed=1234)
+    model = BathymetricGNN(in_channels=7, num_gnn_layers=args.layers, edge_dim=3, dropout=0.0)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model.to(dev).eval()
+    gb = GraphBuilder(device=dev)
+    eng = TileBatchEngine(model, gb, dev)
+    ctx = eng.ctx
+
+    # synthetic batch, resident in HBM before the timed region (a few distinct tiles, tiled to B)
+    n_distinct = min(B, 8)
+    depth, mask, _ = synthetic.synthetic_tile_batch(n_distinct, S, S, 100 + 1000 * rank, args.variant)
+    reps = (B + n_distinct - 1) // n_distinct
+    depth = np.concatenate([depth] * reps)[:B]; mask = np.concatenate([mask] * reps)[:B]
+    d_t = torch.from_numpy(depth).to(dev).reshape(-1)
+    m_t = torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
+    hw = np.tile(np.array([[S, S]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
+    out = torch.empty((3, d_t.numel()), dtype=torch.float32, device=dev)
+    nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    nodes_per_step = int(mask.sum())
+
+    def step():
+        eng.infer_device(hw, res, d_t, m_t, None, out=out, n_nodes_out=nn_dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile(rt.K_NAMES)                                  # HIP events around every kernel class
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile([])
+    assert int(nn_dev.item()) == nodes_per_step
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        am = algorithmic_model(num_layers=args.layers)
+        nodes_total = nodes_per_step * args.steps * world
+        value = nodes_total / elapsed
+        kernels = {}
+        for k, v in prof.items():
+            if v["launches"]:
+                kernels[k] = {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps}
+        agg_s = prof["aggregate"]["ms"] / 1e3
+        gemm_s = prof["gemm"]["ms"] / 1e3
+        n_local = nodes_per_step * args.steps
+        agg = {"kernel": "gat_aggregate_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+               "achieved": am["aggregate_bytes"] * n_local / agg_s / 1e9 if agg_s > 0 else None,
+               "avg_launch_ms": prof["aggregate"]["ms"] / max(prof["aggregate"]["launches"], 1),
+               "algorithmic_bytes_per_node_per_forward": am["aggregate_bytes"], "traffic": None}
+        gem = {"kernel": "gemm_f32_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
+               "achieved": am["gemm_flops"] * n_local / gemm_s / 1e12 if gemm_s > 0 else None,
+               "avg_launch_ms": prof["gemm"]["ms"] / max(prof["gemm"]["launches"], 1),
+               "algorithmic_flops_per_node_per_forward": am["gemm_flops"], "traffic": None}
+        for r in (agg, gem):
+            r["frac"] = r["achieved"] / r["peak"] if r["achieved"] else None
+        # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach if present
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                t = json.load(open(pmc))
+                agg["traffic"] = t.get("gat_aggregate_kernel", {}).get("bytes_per_launch")
+                gem["traffic"] = t.get("gemm_f32_kernel", {}).get("bytes_per_launch")
+            except Exception:
+                pass
+        dominant = agg if agg_s >= gemm_s else gem
+        line = {
+            "metric": "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)",
+            "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B} tiles of {S}x{S} per GPU per step, 8-connected (k=8), {args.layers}-layer GAT "
+                                   f"(hidden 64, heads 4), mask {args.variant}, inputs resident in HBM",
+                       "tiles_per_gpu": B, "tile": S, "nodes_per_step_per_gpu": nodes_per_step,
+                       "parallelism": f"tile-sharded x{world}, no collective"},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")},
+            "roofline_aggregate": agg, "roofline_gemm": gem, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
