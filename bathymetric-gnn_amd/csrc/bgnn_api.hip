@@ -338,7 +338,7 @@ static void graph_free(bgnn_graph *g) {
   DevPool &P = g->ctx->pool;
   P.release(g->d_tiles); P.release(g->d_items); P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
-  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm);
+  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm); P.release(g->d_items2);
   delete g;
 }
 
@@ -376,7 +376,8 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
     g->F = nf;
   }
   int64_t cells = 0;
-  std::vector<BgnnWorkItem> items;
+  std::vector<BgnnWorkItem> items, items2;
+  bool uniform = true;
   g->h_tiles.resize(tiles->n_tiles);
   for (int t = 0; t < tiles->n_tiles; ++t) {
     const int h = tiles->hw[2 * t], w = tiles->hw[2 * t + 1];
@@ -394,6 +395,17 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
     if (cells >= ((int64_t)1 << 30)) { delete g; set_error("batch too large: 2^30 cells or more; split it"); return BGNN_ERR_INVALID; }
     int rows_per = std::max(1, 2048 / w);
     for (int r0 = 0; r0 < h; r0 += rows_per) items.push_back({t, r0, std::min(rows_per, h - r0), 0});
+    if (h != tiles->hw[0] || w != tiles->hw[1]) uniform = false;
+  }
+  if (uniform) {
+    g->uni_h = tiles->hw[0]; g->uni_w = tiles->hw[1];
+    g->bh2 = (g->uni_h + 15) / 16; g->bw2 = (g->uni_w + 15) / 16;
+    g->n_blocks2 = g->n_tiles * g->bh2 * g->bw2;
+  } else {
+    for (int t = 0; t < tiles->n_tiles; ++t)
+      for (int r0 = 0; r0 < g->h_tiles[t].h; r0 += 16)
+        for (int c0 = 0; c0 < g->h_tiles[t].w; c0 += 16) items2.push_back({t, r0, c0, 0});
+    g->n_blocks2 = (int32_t)items2.size();
   }
   g->total_cells = (int32_t)cells; g->row_capacity = (int32_t)cells; g->n_items = (int32_t)items.size();
   DevPool &P = ctx->pool;
@@ -408,7 +420,9 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
   GALLOC(g->d_local_std, float, cells)
   GALLOC(g->d_nbr, int32_t, cells * g->K)
   GALLOC(g->d_eattr, float, cells * g->K * g->ED)
+  if (!uniform) GALLOC(g->d_items2, BgnnWorkItem, items2.size())
 #undef GALLOC
+  if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items2.data(), sizeof(BgnnWorkItem) * items2.size(), g->d_items2);
   if (rc == BGNN_OK) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
   if (rc == BGNN_OK) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
   if (rc == BGNN_OK) rc = launch_graph_build(ctx, g, tiles, opts);
@@ -515,7 +529,9 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     const int HC = L.heads * hid;
     BGNN_TRY(launch_gemm_f32(ctx, B, L.d_in, L.Wt, nullptr, A, HC, dm, rows, L.d_in, HC, 0));
     BGNN_TRY(launch_att_coef(ctx, A, L.att_src, L.att_dst, asd, dm, rows, L.heads, hid));
-    BGNN_TRY(launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0));
+    int arc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0);
+    if (arc == BGNN_ERR_UNSUPPORTED) arc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0);
+    BGNN_TRY(arc);
   }
   if (o->hidden) {
     const int64_t n = rows * hid;

@@ -136,6 +136,11 @@ struct bgnn_graph {
   int64_t n_edges_host = -1;
   int64_t generic_E = 0;
   int32_t row_capacity = 0;           // rows allocated for node-indexed arrays
+  // 2-D cell blocks (16x16) for the LDS-tiled aggregate
+  BgnnWorkItem *d_items2 = nullptr;   // {tile, r0, c0}; unused when every tile has the same shape
+  int32_t n_blocks2 = 0;
+  int32_t uni_h = 0, uni_w = 0;       // common tile shape, 0 if ragged
+  int32_t bh2 = 0, bw2 = 0;           // blocks per tile (uniform case)
 };
 
 namespace bgnn {
@@ -169,6 +174,8 @@ int launch_att_coef(bgnn_ctx *ctx, const float *xw, const float *att_src, const 
                     const int64_t *d_m, int64_t max_rows, int H, int C);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                          const float *asd, float *out, int relu);
+int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
+                               const float *asd, float *out, int relu);
 int launch_heads_final(bgnn_ctx *ctx, const bgnn_model *m, const float *hid, int ldh, const int64_t *d_m,
                        int64_t max_rows, float thr_auto, float thr_review, const bgnn_outputs *o);
 
