@@ -527,8 +527,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   for (size_t l = 0; l < m->layers.size(); ++l) {
     const BgnnLayer &L = m->layers[l];
     const int HC = L.heads * hid;
-    BGNN_TRY(launch_gemm_f32(ctx, B, L.d_in, L.Wt, nullptr, A, HC, dm, rows, L.d_in, HC, 0));
-    BGNN_TRY(launch_att_coef(ctx, A, L.att_src, L.att_dst, asd, dm, rows, L.heads, hid));
+    BGNN_TRY(launch_gemm_f32(ctx, B, L.d_in, L.Wt, nullptr, A, HC, dm, rows, L.d_in, HC, 0, L.att_src, L.att_dst, asd,
+                             L.heads, hid));
     int arc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0);
     if (arc == BGNN_ERR_UNSUPPORTED) arc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0);
     BGNN_TRY(arc);

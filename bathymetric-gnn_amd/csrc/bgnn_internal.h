@@ -168,10 +168,11 @@ int launch_generic_build(bgnn_ctx *ctx, bgnn_graph *g, int64_t n_nodes, int32_t 
                          int64_t n_edges, const int64_t *edge_index, int32_t edge_dim, const float *edge_attr);
 
 // Y[M,NC] = act(X[M,K] @ Wt[K,NC] + bias); M read from d_counts[0] (bounded by max_rows)
+// optional fused epilogue: asd[M][2H] = (Y . att_src, Y . att_dst) per head (att_src == nullptr: off)
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y,
-                    int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu);
-int launch_att_coef(bgnn_ctx *ctx, const float *xw, const float *att_src, const float *att_dst, float *asd,
-                    const int64_t *d_m, int64_t max_rows, int H, int C);
+                    int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu,
+                    const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
+                    int H = 0, int C = 0);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                          const float *asd, float *out, int relu);
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,

@@ -15,38 +15,6 @@
 
 namespace bgnn {
 
-// a_src[n,h] = sum_c xw[n,h,c] att_src[h,c]; a_dst likewise.  asd layout [N][2H] = (src.., dst..)
-template <int LPN>
-__global__ __launch_bounds__(256) void att_coef_kernel(const float *__restrict__ xw,
-                                                       const float *__restrict__ att_src,
-                                                       const float *__restrict__ att_dst, float *__restrict__ asd,
-                                                       const int64_t *__restrict__ d_m, int H, int C) {
-  constexpr int NPW = 64 / LPN;
-  const int64_t M = *d_m;
-  const int lane = threadIdx.x & 63;
-  const int sub = lane / LPN, l = lane % LPN;
-  const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n = wave_id * NPW + sub;
-  const bool ok = n < M;
-  const int HC = LPN * 4;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (ok) v = *reinterpret_cast<const float4 *>(xw + n * HC + l * 4);
-  const float4 s4 = *reinterpret_cast<const float4 *>(att_src + l * 4);
-  const float4 d4 = *reinterpret_cast<const float4 *>(att_dst + l * 4);
-  float ps = v.x * s4.x + v.y * s4.y + v.z * s4.z + v.w * s4.w;
-  float pd = v.x * d4.x + v.y * d4.y + v.z * d4.z + v.w * d4.w;
-  const int lph = C / 4;   // lanes per head (16 for C=64)
-  for (int o = lph >> 1; o > 0; o >>= 1) {
-    ps += __shfl_xor(ps, o);
-    pd += __shfl_xor(pd, o);
-  }
-  if (ok && (l % lph) == 0) {
-    const int hh = l / lph;
-    asd[n * 2 * H + hh] = ps;
-    asd[n * 2 * H + H + hh] = pd;
-  }
-}
-
 struct AggArgs {
   const float *xw;        // [N][HC]
   const float *asd;       // [N][2H]
@@ -202,26 +170,6 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
   }
   *reinterpret_cast<float4 *>(a.out + i * HC + l * 4) = o;
-}
-
-int launch_att_coef(bgnn_ctx *ctx, const float *xw, const float *att_src, const float *att_dst, float *asd,
-                    const int64_t *d_m, int64_t max_rows, int H, int C) {
-  if (max_rows <= 0) return BGNN_OK;
-  ProfScope ps(ctx, BGNN_K_ATTCOEF);
-  const int HC = H * C, LPN = HC / 4;
-  BGNN_REQUIRE(C % 4 == 0 && (C / 4) <= 64 && ((C / 4) & (C / 4 - 1)) == 0 && (LPN == 64 || LPN == 32 || LPN == 16 || LPN == 8),
-               "att_coef: unsupported H=%d C=%d", H, C);
-  const int npw = 64 / LPN;
-  const int64_t waves = (max_rows + npw - 1) / npw;
-  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  switch (LPN) {
-    case 64: hipLaunchKernelGGL(att_coef_kernel<64>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
-    case 32: hipLaunchKernelGGL(att_coef_kernel<32>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
-    case 16: hipLaunchKernelGGL(att_coef_kernel<16>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
-    case 8: hipLaunchKernelGGL(att_coef_kernel<8>, grid, block, 0, ctx->stream, xw, att_src, att_dst, asd, d_m, H, C); break;
-  }
-  BGNN_HIP_CHECK(hipGetLastError());
-  return BGNN_OK;
 }
 
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,

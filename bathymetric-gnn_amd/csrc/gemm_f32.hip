@@ -1,18 +1,23 @@
 // K3: dense node-feature x weight GEMM in exact float32 on the matrix cores (gfx950).
 //
-//   Y[M, NC] = act( X[M, K] @ Wt[K, NC] + bias )
+//   Y[M, NC] = act( X[M, K] @ Wt[K, NC] + bias )          (+ fused attention dot products)
 //
-// Replaces the `lin(x)` GEMM of torch_geometric GATConv (reference models/gnn.py:176) and the
-// Linear layers of the feature extractor / heads (models/gnn.py:52-68, 203-208).
-// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain, so results stay within float32
-// rounding of the reference's CPU sgemm (no bf16 / xf32 shortcut exists or is wanted here).
+// Replaces the `lin(x)` GEMM of torch_geometric GATConv and its alpha_src / alpha_dst reductions
+// (reference models/gnn.py:176) and the Linear layers of the feature
+// extractor / heads (models/gnn.py:52-68, 203-208).  v_mfma_f32_32x32x2_f32 is bit-for-bit a
+// k-ordered fmaf chain, so results stay within float32 rounding of the reference's CPU sgemm.
 //
-// Decomposition: one wave owns 32 rows x all NC columns (NT = NC/32 accumulator tiles);
-// a 256-thread workgroup = 4 waves = 128 rows.  The A operand needs one f32 per lane
-// (lane l: row l&31, k-slot l>>5): each lane reads 16 contiguous bytes of ITS OWN row straight
-// from global memory and the two lane halves are assigned k = 4h..4h+3 of every 8-wide k-step,
-// so no LDS transpose of X is needed.  The shared Wt chunk (32 k x NC) is staged through LDS and
-// read conflict-free (lanes 0-31 read 32 consecutive floats).
+// Decomposition: one wave owns 32 rows x all NC columns (NT = NC/32 accumulator tiles); a
+// 256-thread workgroup = 4 waves = 128 rows, two workgroups per CU.
+//   * X operand: one f32 per lane (lane l: row l&31, k-slot l>>5).  Each lane reads 16 contiguous
+//     bytes of ITS OWN row straight from global memory; the two lane halves take k = 4h..4h+3 of
+//     every 8-wide k-step, so X never needs an LDS transpose.  Next chunk prefetched in registers.
+//   * W operand: the [32 k][NC] chunk of Wt is contiguous in memory, so it is streamed into a
+//     double-buffered LDS image by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) while
+//     the previous chunk is being multiplied; fragment reads are conflict-free ds_read_b32.
+//   * The product is computed TRANSPOSED (W fragment as the A operand, X fragment as B): each lane
+//     then holds 16 output CHANNELS of ONE row (4 groups of 4 consecutive channels), so bias /
+//     ReLU / the attention dot products are in-lane work and stores are float4.
 #include "bgnn_internal.h"
 
 namespace bgnn {
@@ -21,21 +26,47 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GEMM_KC = 32;   // k-chunk staged in LDS
 
+struct GemmArgs {
+  const float *X;
+  const float *Wt;
+  const float *bias;
+  float *Y;
+  const int64_t *d_m;
+  const float *att_src;   // [NC] or nullptr
+  const float *att_dst;   // [NC]
+  float *asd;             // [M][2H]
+  int ldx, ldy, K, relu, H, C;
+};
+
 template <int NT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ X, int ldx,
-                                                       const float *__restrict__ Wt,
-                                                       const float *__restrict__ bias, float *__restrict__ Y,
-                                                       int ldy, const int64_t *__restrict__ d_m, int K, int relu) {
+__device__ __forceinline__ void stage_w(const float *Wt, float *dst, int kc, int kn, int wave, int lane) {
+  // chunk = rows kc..kc+kn-1 of Wt: kn*NC contiguous floats; one wave-instruction moves 1 KiB
   constexpr int NC = NT * 32;
-  __shared__ float wl[GEMM_KC * NC];
-  const int64_t M = *d_m;
+  const char *src = reinterpret_cast<const char *>(Wt + (int64_t)kc * NC);
+  const int bytes = kn * NC * 4;
+  constexpr int NQ = GEMM_KC * NC * 4 / 1024;       // 1-KiB pieces in a full chunk
+#pragma unroll
+  for (int j = 0; j < NQ / 4; ++j) {
+    const int q = j * 4 + wave;
+    if (q * 1024 + lane * 16 < bytes)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void *)(dst + q * 256), 16, 0, 0);
+  }
+}
+
+template <int NT, bool ATT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
+  constexpr int NC = NT * 32;
+  __shared__ float wl[2][GEMM_KC * NC];
+  const int64_t M = *a.d_m;
   const int64_t row_block = (int64_t)blockIdx.x * 128;
   if (row_block >= M) return;                       // uniform per block
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  int64_t row = row_block + wave * 32 + r;
+  const int64_t row = row_block + wave * 32 + r;
   const int64_t row_ld = row < M ? row : M - 1;     // clamp loads, mask stores
-  const float *xp = X + row_ld * ldx + 4 * h;
+  const float *xp = a.X + row_ld * a.ldx + 4 * h;
+  const int K = a.K;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -43,61 +74,109 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-  for (int kc = 0; kc < K; kc += GEMM_KC) {
-    const int kn = (K - kc) < GEMM_KC ? (K - kc) : GEMM_KC;   // multiple of 8
-    // A fragments for this chunk: issue before staging W so the latency overlaps
-    float4 a[GEMM_KC / 8];
+  float4 a_cur[GEMM_KC / 8], a_nxt[GEMM_KC / 8];
+  {
+    const int kn = K < GEMM_KC ? K : GEMM_KC;
+    stage_w<NT>(a.Wt, wl[0], 0, kn, wave, lane);
 #pragma unroll
     for (int s = 0; s < GEMM_KC / 8; ++s)
-      if (s * 8 < kn) a[s] = *reinterpret_cast<const float4 *>(xp + kc + s * 8);
-    __syncthreads();                                // previous chunk fully consumed
-    {
-      const float4 *src = reinterpret_cast<const float4 *>(Wt + (int64_t)kc * NC);
-      float4 *dst = reinterpret_cast<float4 *>(wl);
-      const int n4 = kn * NC / 4;
-      for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+      if (s * 8 < kn) a_cur[s] = *reinterpret_cast<const float4 *>(xp + s * 8);
+  }
+  __syncthreads();                                  // (emits vmcnt(0): chunk 0 has landed)
+
+  int buf = 0;
+  for (int kc = 0; kc < K; kc += GEMM_KC) {
+    const int kn = (K - kc) < GEMM_KC ? (K - kc) : GEMM_KC;   // multiple of 8
+    const int kc2 = kc + GEMM_KC;
+    if (kc2 < K) {
+      const int kn2 = (K - kc2) < GEMM_KC ? (K - kc2) : GEMM_KC;
+      stage_w<NT>(a.Wt, wl[buf ^ 1], kc2, kn2, wave, lane);
+#pragma unroll
+      for (int s = 0; s < GEMM_KC / 8; ++s)
+        if (s * 8 < kn2) a_nxt[s] = *reinterpret_cast<const float4 *>(xp + kc2 + s * 8);
     }
-    __syncthreads();
+    const float *wb = wl[buf];
 #pragma unroll
     for (int s = 0; s < GEMM_KC / 8; ++s) {
       if (s * 8 < kn) {
-        const float av[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
+        const float av[4] = {a_cur[s].x, a_cur[s].y, a_cur[s].z, a_cur[s].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float *wrow = wl + (s * 8 + 4 * h + i) * NC + r;
+          const float *wrow = wb + (s * 8 + 4 * h + i) * NC + r;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wrow[t * 32], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 32], av[i], acc[t], 0, 0, 0);
         }
       }
     }
+    __syncthreads();        // all waves done with wl[buf]; vmcnt(0): next chunk + a_nxt have landed
+#pragma unroll
+    for (int s = 0; s < GEMM_KC / 8; ++s) a_cur[s] = a_nxt[s];
+    buf ^= 1;
   }
-  // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int64_t wrow0 = row_block + wave * 32;
+
+  // epilogue.  Transposed C/D layout: lane (r, h) holds row r; reg i -> channel
+  // t*32 + 8*(i>>2) + 4*h + (i&3)
+  const bool ok = row < M;
+  if (ATT) {
+    const int H = a.H, tph = a.C / 32;              // tiles per head
+    for (int hd = 0; hd < H; ++hd) {
+      float ps = 0.0f, pd = 0.0f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = t * 32 + r;
-    const float b = bias ? bias[col] : 0.0f;
+      for (int t = 0; t < NT; ++t) {
+        if (t / tph == hd) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int64_t orow = wrow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      float v = acc[t][i] + b;
-      if (relu) v = v > 0.0f ? v : 0.0f;
-      if (orow < M) Y[orow * ldy + col] = v;
+          for (int g = 0; g < 4; ++g) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(a.att_src + t * 32 + 8 * g + 4 * h);
+            const float4 d4 = *reinterpret_cast<const float4 *>(a.att_dst + t * 32 + 8 * g + 4 * h);
+            ps += acc[t][4 * g] * s4.x + acc[t][4 * g + 1] * s4.y + acc[t][4 * g + 2] * s4.z + acc[t][4 * g + 3] * s4.w;
+            pd += acc[t][4 * g] * d4.x + acc[t][4 * g + 1] * d4.y + acc[t][4 * g + 2] * d4.z + acc[t][4 * g + 3] * d4.w;
+          }
+        }
+      }
+      ps += __shfl_xor(ps, 32);
+      pd += __shfl_xor(pd, 32);
+      if (ok && h == 0) {
+        a.asd[row * 2 * H + hd] = ps;
+        a.asd[row * 2 * H + H + hd] = pd;
+      }
+    }
+  }
+  if (ok) {
+    float *yp = a.Y + row * a.ldy + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4 *>(a.bias + t * 32 + 8 * g + 4 * h);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (a.relu) {
+          v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+          v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(yp + t * 32 + 8 * g) = v;
+      }
     }
   }
 }
 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
-                    const int64_t *d_m, int64_t max_rows, int K, int NC, int relu) {
-  BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0, "gemm_f32: unsupported shape K=%d NC=%d ldx=%d",
-               K, NC, ldx);
+                    const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
+                    const float *att_dst, float *asd, int H, int C) {
+  BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0 && ldy % 4 == 0,
+               "gemm_f32: unsupported shape K=%d NC=%d ldx=%d ldy=%d", K, NC, ldx, ldy);
+  if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
+  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ldx, ldy, K, relu, H, C};
   dim3 grid((unsigned)((max_rows + 127) / 128)), block(256);
-#define BGNN_GEMM_CASE(NT)                                                                                   \
-  case NT:                                                                                                   \
-    hipLaunchKernelGGL(gemm_f32_kernel<NT>, grid, block, 0, ctx->stream, X, ldx, Wt, bias, Y, ldy, d_m, K, relu); \
+#define BGNN_GEMM_CASE(NT)                                                                         \
+  case NT:                                                                                         \
+    if (att_src) hipLaunchKernelGGL((gemm_f32_kernel<NT, true>), grid, block, 0, ctx->stream, a);  \
+    else hipLaunchKernelGGL((gemm_f32_kernel<NT, false>), grid, block, 0, ctx->stream, a);         \
     break;
   switch (NC / 32) {
     BGNN_GEMM_CASE(1) BGNN_GEMM_CASE(2) BGNN_GEMM_CASE(3) BGNN_GEMM_CASE(4) BGNN_GEMM_CASE(5) BGNN_GEMM_CASE(6)
