@@ -2,6 +2,7 @@
 // forward / fused-inference orchestration.  Host code only; kernels live in the other TUs.
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -158,6 +159,11 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     }
     c->owns_stream = true;
   }
+  if (hipMalloc((void **)&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+    set_error("zero page allocation failed");
+    delete c;
+    return BGNN_ERR_NOMEM;
+  }
   *out = c;
   return BGNN_OK;
 }
@@ -169,6 +175,7 @@ int bgnn_ctx_destroy(bgnn_ctx *ctx) {
   for (auto &r : ctx->prof_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 6; ++i) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   ctx->pool.trim();
   for (auto &kv : ctx->pool.live) (void)hipFree(kv.first);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -503,8 +510,14 @@ int bgnn_graph_scatter(bgnn_graph *g, const float *node_values, float fill, floa
 }
 
 // ---- forward ----------------------------------------------------------------------------------
+struct GridOut {             // optional fused node -> grid outputs (bgnn_infer_tiles)
+  float *cls = nullptr, *conf = nullptr, *corr = nullptr;
+  float norm_floor = 0.01f;
+  bool done = false;         // set when the fused tail wrote the grids
+};
+
 static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, float thr_review,
-                        const bgnn_outputs *o) {
+                        const bgnn_outputs *o, GridOut *grids) {
   const bgnn_model_desc &d = m->desc;
   BGNN_REQUIRE(g->F == d.in_channels, "mat1 and mat2 shapes cannot be multiplied (graph has %d node features, model expects %d)",
                g->F, d.in_channels);
@@ -516,29 +529,53 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   void *pa, *pb, *pasd, *phid;
   BGNN_TRY(ctx_workspace(ctx, 0, (size_t)rows * maxw * sizeof(float), &pa));
   BGNN_TRY(ctx_workspace(ctx, 1, (size_t)rows * maxw * sizeof(float), &pb));
-  BGNN_TRY(ctx_workspace(ctx, 2, (size_t)rows * 2 * d.heads * sizeof(float), &pasd));
+  BGNN_TRY(ctx_workspace(ctx, 2, (size_t)rows * 4 * d.heads * sizeof(float), &pasd));
   BGNN_TRY(ctx_workspace(ctx, 3, (size_t)rows * m->head_hidden_total * sizeof(float), &phid));
-  float *A = (float *)pa, *B = (float *)pb, *asd = (float *)pasd, *hidb = (float *)phid;
+  float *X = (float *)pa, *Y = (float *)pb, *hidb = (float *)phid;
+  float *asdX = (float *)pasd, *asdY = asdX + rows * 2 * d.heads;
   const int64_t *dm = g->d_counts;
-  // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid)
-  BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, A, hid, dm, rows, 8, hid, 1));
-  BGNN_TRY(launch_gemm_f32(ctx, A, hid, m->fe_W1t, m->fe_b1, B, hid, dm, rows, hid, hid, 0));
-  // GNN backbone (gnn.py:173-188)
-  for (size_t l = 0; l < m->layers.size(); ++l) {
+  const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr;
+  // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid); then lin of layer 0
+  BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
+  BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));
+  {
+    const BgnnLayer &L0 = m->layers[0];
+    BGNN_TRY(launch_gemm_f32(ctx, Y, L0.d_in, L0.Wt, nullptr, X, L0.heads * hid, dm, rows, L0.d_in, L0.heads * hid, 0,
+                             L0.att_src, L0.att_dst, asdX, L0.heads, hid));
+  }
+  // GNN backbone (gnn.py:173-188).  Invariant at the top of each iteration: X = lin_l(h_l), asdX = its dots.
+  const size_t nl = m->layers.size();
+  for (size_t l = 0; l < nl; ++l) {
     const BgnnLayer &L = m->layers[l];
-    const int HC = L.heads * hid;
-    BGNN_TRY(launch_gemm_f32(ctx, B, L.d_in, L.Wt, nullptr, A, HC, dm, rows, L.d_in, HC, 0, L.att_src, L.att_dst, asd,
-                             L.heads, hid));
-    int arc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0);
-    if (arc == BGNN_ERR_UNSUPPORTED) arc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, A, asd, B, L.concat ? 1 : 0);
-    BGNN_TRY(arc);
+    const int relu = L.concat ? 1 : 0;
+    if (l + 1 < nl) {
+      const BgnnLayer &Ln = m->layers[l + 1];
+      int rc = use_fused ? launch_fused_layer_next(ctx, g, L, Ln, hid, d.edge_dim, X, asdX, Y, asdY) : BGNN_ERR_UNSUPPORTED;
+      if (rc == BGNN_OK) { std::swap(X, Y); std::swap(asdX, asdY); continue; }
+      if (rc != BGNN_ERR_UNSUPPORTED) return rc;
+      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
+      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
+      BGNN_TRY(rc);
+      BGNN_TRY(launch_gemm_f32(ctx, Y, Ln.d_in, Ln.Wt, nullptr, X, Ln.heads * hid, dm, rows, Ln.d_in, Ln.heads * hid, 0,
+                               Ln.att_src, Ln.att_dst, asdX, Ln.heads, hid));
+    } else {
+      int rc = use_fused ? launch_fused_layer_heads(ctx, g, m, L, hid, d.edge_dim, X, asdX, thr_auto, thr_review,
+                                                    grids ? grids->norm_floor : 0.01f, o, grids ? grids->cls : nullptr,
+                                                    grids ? grids->conf : nullptr, grids ? grids->corr : nullptr)
+                         : BGNN_ERR_UNSUPPORTED;
+      if (rc == BGNN_OK) { if (grids) grids->done = true; return BGNN_OK; }
+      if (rc != BGNN_ERR_UNSUPPORTED) return rc;
+      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
+      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
+      BGNN_TRY(rc);
+    }
   }
   if (o->hidden) {
     const int64_t n = rows * hid;
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, B, o->hidden, hid, dm);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, Y, o->hidden, hid, dm);
   }
   // heads (gnn.py:392-406)
-  BGNN_TRY(launch_gemm_f32(ctx, B, hid, m->hd_W0t, m->hd_b0, hidb, m->head_hidden_total, dm, rows, hid,
+  BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->hd_W0t, m->hd_b0, hidb, m->head_hidden_total, dm, rows, hid,
                            m->head_hidden_total, 1));
   BGNN_TRY(launch_heads_final(ctx, m, hidb, m->head_hidden_total, dm, rows, thr_auto, thr_review, o));
   return BGNN_OK;
@@ -548,7 +585,7 @@ int bgnn_forward(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, fl
   BGNN_REQUIRE(ctx && m && g && o, "bgnn_forward: NULL argument");
   BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward: model/graph belong to another context");
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
-  return forward_impl(ctx, m, g, thr_auto, thr_review, o);
+  return forward_impl(ctx, m, g, thr_auto, thr_review, o, nullptr);
 }
 
 int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, float thr_auto,
@@ -558,17 +595,26 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
   bgnn_graph *g = nullptr;
   BGNN_TRY(bgnn_graph_build(ctx, tiles, opts, &g));
   const int64_t rows = g->row_capacity;
+  GridOut go;
+  go.cls = classification; go.conf = confidence; go.corr = correction; go.norm_floor = norm_floor;
+  // first try the fully fused tail (no per-node outputs at all); otherwise per-node outputs + K6
   void *p;
   int rc = ctx_workspace(ctx, 4, (size_t)rows * (sizeof(int64_t) + 2 * sizeof(float)), &p);
   if (rc == BGNN_OK) {
+    bgnn_outputs none{};
     bgnn_outputs o{};
     o.predicted_class = (int64_t *)p;
     o.confidence = (float *)(o.predicted_class + rows);
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
-    rc = forward_impl(ctx, m, g, thr_auto, thr_review, &o);
-    if (rc == BGNN_OK)
-      rc = launch_results_to_grids(g, o.predicted_class, o.confidence, o.correction, norm_floor, classification,
-                                   confidence, correction);
+    const bool try_fused = getenv("BGNN_NO_FUSED") == nullptr && g->kind == 0 && (g->K == 4 || g->K == 8) &&
+                           m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
+    rc = forward_impl(ctx, m, g, thr_auto, thr_review, try_fused ? &none : &o, &go);
+    if (rc == BGNN_OK && !go.done) {
+      if (try_fused) rc = forward_impl(ctx, m, g, thr_auto, thr_review, &o, nullptr);   // (not reached in practice)
+      if (rc == BGNN_OK)
+        rc = launch_results_to_grids(g, o.predicted_class, o.confidence, o.correction, norm_floor, classification,
+                                     confidence, correction);
+    }
     if (rc == BGNN_OK && n_nodes_out)
       rc = hipMemcpyAsync(n_nodes_out, g->d_counts, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
                ? BGNN_OK : BGNN_ERR_HIP;

@@ -83,6 +83,7 @@ struct bgnn_ctx {
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
   int num_cus = 256;
+  float *zero_page = nullptr;   // 4 KiB of zeros
 };
 
 struct BgnnLayer {
@@ -177,6 +178,12 @@ int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L,
                          const float *asd, float *out, int relu);
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                                const float *asd, float *out, int relu);
+// fused K4 + next K3 (EPI_NEXT) / K4(last) + K5 + K6 (EPI_HEADS); BGNN_ERR_UNSUPPORTED when no instance fits
+int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, int ED,
+                            const float *xw, const float *asd, float *xw_next, float *asd_next);
+int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
+                             const float *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
+                             const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);
 int launch_heads_final(bgnn_ctx *ctx, const bgnn_model *m, const float *hid, int ldh, const int64_t *d_m,
                        int64_t max_rows, float thr_auto, float thr_review, const bgnn_outputs *o);
 

@@ -1,0 +1,152 @@
+// Shared device code of the LDS-tiled stencil kernels (gat_aggregate_tiled.hip, gat_layer_fused.hip):
+// block -> (tile, 16x16 cell block) decode, halo node ids, per-cell attention coefficients.
+#pragma once
+#include "bgnn_internal.h"
+
+namespace bgnn {
+
+template <int K> struct StencilOffsets;
+template <> struct StencilOffsets<4> {   // graph_construction.py:79-81
+  static constexpr int dr[4] = {-1, 1, 0, 0};
+  static constexpr int dc[4] = {0, 0, -1, 1};
+};
+template <> struct StencilOffsets<8> {   // graph_construction.py:83-87
+  static constexpr int dr[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+  static constexpr int dc[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+};
+
+constexpr int TILE_H = 16, TILE_W = 16;
+constexpr int HALO_W = TILE_W + 2, HALO_ROWS = (TILE_H + 2) * (TILE_W + 2);   // 18, 324
+constexpr int TILED_PITCH = 36;   // dwords per staged 32-channel row slab (32 + 4 pad)
+
+// halo-index offset (dr*HALO_W + dc) of stencil slot b, computed arithmetically for runtime b;
+// b == K is the self loop (offset 0)
+template <int K>
+__device__ __forceinline__ int slot_halo_offset(int b) {
+  if (b >= K) return 0;
+  if (K == 8) {
+    const int k = b < 4 ? b : b + 1;            // position in the 3x3 stencil, centre skipped
+    return (k / 3 - 1) * (TILE_W + 2) + (k % 3 - 1);
+  }
+  // K == 4: (-1,0), (1,0), (0,-1), (0,1)
+  return b == 0 ? -(TILE_W + 2) : b == 1 ? (TILE_W + 2) : b == 2 ? -1 : 1;
+}
+
+struct TileBlocks {               // how workgroups map to (tile, cell block)
+  const BgnnTileMeta *tiles;
+  const BgnnWorkItem *items2;     // {tile, r0, c0}; nullptr when every tile has one shape
+  int bh, bw;                     // blocks per tile (uniform case)
+  int n_blocks;
+};
+
+struct BlockPos {
+  int tile, r0, c0, h, w;
+  int64_t cell_off;
+};
+
+// XCD-aware block order: consecutive work items (adjacent cell blocks, which share halo rows) run on
+// the same XCD and hit its L2.  Bijective for any n_blocks.
+__device__ __forceinline__ BlockPos decode_block(const TileBlocks &tb) {
+  const int nb = tb.n_blocks;
+  const int bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+  const int wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  BlockPos p;
+  if (tb.items2) {
+    const BgnnWorkItem it = tb.items2[wid];
+    p.tile = it.tile; p.r0 = it.r0; p.c0 = it.nr;
+  } else {
+    const int bpt = tb.bh * tb.bw;
+    p.tile = wid / bpt;
+    const int rem = wid - p.tile * bpt;
+    p.r0 = (rem / tb.bw) * TILE_H; p.c0 = (rem % tb.bw) * TILE_W;
+  }
+  const BgnnTileMeta t = tb.tiles[p.tile];
+  p.h = t.h; p.w = t.w; p.cell_off = t.cell_off;
+  return p;
+}
+
+// phase 0: node ids of the 18x18 halo (-1 = outside the tile or invalid) and their alpha_src
+template <int H, int NTHREADS>
+__device__ __forceinline__ void load_halo_ids(const BlockPos &p, const int32_t *node_id, const float *asd, int *hid,
+                                              float *has) {
+  for (int idx = threadIdx.x; idx < HALO_ROWS; idx += NTHREADS) {
+    const int gr = p.r0 + idx / HALO_W - 1, gc = p.c0 + idx % HALO_W - 1;
+    int id = -1;
+    if (gr >= 0 && gr < p.h && gc >= 0 && gc < p.w) {
+      id = node_id[p.cell_off + (int64_t)gr * p.w + gc];
+      if (id < 0) id = -1;
+    }
+    hid[idx] = id;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) has[idx * H + hh] = id >= 0 ? asd[(int64_t)id * 2 * H + hh] : 0.0f;
+  }
+}
+
+// phase A: attention coefficients of cell `self_idx` (node `my`) for heads [H0, H0+NH):
+//   e = leaky_relu(a_src[j] + a_dst[i] + ea . V, 0.2); self loop uses the mean incoming attribute;
+//   alpha = exp(e - max) / (sum + 1e-16).   out[b*NH + (hh-H0)], b = 0..K (K = self loop)
+template <int H, int K, int H0, int NH>
+__device__ __forceinline__ void attention_coefficients(int my, int self_idx, const int *hid, const float *has,
+                                                       const float *asd, const float *eattr, const float *V, int ED,
+                                                       float *out) {
+  using Off = StencilOffsets<K>;
+  float ea[K][4];
+  float ea_sum[4] = {0.f, 0.f, 0.f, 0.f};
+  int deg = 0;
+  bool present[K];
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    const int nidx = self_idx - Off::dr[b] * HALO_W - Off::dc[b];   // slot b <- source at -offset[b]
+    present[b] = hid[nidx] >= 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      ea[b][f] = (f < ED && present[b]) ? eattr[((int64_t)my * K + b) * ED + f] : 0.0f;
+      if (present[b]) ea_sum[f] += ea[b][f];
+    }
+    deg += present[b] ? 1 : 0;
+  }
+  const float cnt = (float)(deg > 0 ? deg : 1);      // scatter(..., reduce='mean'): sum / max(count, 1)
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int hh = H0 + k;
+    float v[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) v[f] = f < ED ? V[hh * ED + f] : 0.0f;
+    const float ad = asd[(int64_t)my * 2 * H + H + hh];
+    float mx = -__builtin_inff();
+    float lg[K + 1];
+#pragma unroll
+    for (int b = 0; b < K; ++b) {
+      const int nidx = self_idx - Off::dr[b] * HALO_W - Off::dc[b];
+      float dot = 0.0f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) dot += ea[b][f] * v[f];
+      float x = has[nidx * H + hh] + ad + dot;
+      x = x > 0.0f ? x : 0.2f * x;
+      lg[b] = x;
+      if (present[b]) mx = fmaxf(mx, x);
+    }
+    {
+      float dot = 0.0f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) dot += (ea_sum[f] / cnt) * v[f];
+      float x = has[self_idx * H + hh] + ad + dot;
+      x = x > 0.0f ? x : 0.2f * x;
+      lg[K] = x;
+      mx = fmaxf(mx, x);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int b = 0; b <= K; ++b) {
+      const bool on = b == K ? true : present[b];
+      const float pe = on ? expf(lg[b] - mx) : 0.0f;
+      lg[b] = pe;
+      den += pe;
+    }
+    den += 1e-16f;
+#pragma unroll
+    for (int b = 0; b <= K; ++b) out[b * NH + k] = lg[b] / den;
+  }
+}
+
+}  // namespace bgnn

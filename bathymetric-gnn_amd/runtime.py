@@ -17,7 +17,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libbgnn_hip.so")
 
-K_NAMES = ["scan", "stats", "features", "export", "gemm", "attcoef", "aggregate", "heads", "scatter"]
+K_NAMES = ["scan", "stats", "features", "export", "gemm", "attcoef", "aggregate", "heads", "scatter", "fused"]
 K_INDEX = {n: i for i, n in enumerate(K_NAMES)}
 
 NODE_FEATURE_IDS = {"depth": 0, "local_mean": 1, "local_std": 2, "gradient_x": 3, "gradient_y": 4,

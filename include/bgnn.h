@@ -63,11 +63,12 @@ enum {
   BGNN_K_FEATURES = 2,  /* K1b/K2 node features + stencil neighbour table + edge attrs  */
   BGNN_K_EXPORT = 3,    /* PyG-layout materialisation (edge_index int64, ...)           */
   BGNN_K_GEMM = 4,      /* K3 dense node-feature x weight GEMM (f32 MFMA)               */
-  BGNN_K_ATTCOEF = 5,   /* alpha_src / alpha_dst dot products                           */
+  BGNN_K_ATTCOEF = 5,   /* alpha_src / alpha_dst dot products (fused into K3's epilogue) */
   BGNN_K_AGGREGATE = 6, /* K4 gather - per-node softmax - weighted aggregate (+BN+ReLU) */
   BGNN_K_HEADS = 7,     /* K5 output heads                                              */
   BGNN_K_SCATTER = 8,   /* K6 node -> grid scatter + correction de-normalisation        */
-  BGNN_K_COUNT = 9
+  BGNN_K_FUSED = 9,     /* K4 fused with the next layer's K3 (or with K5 + K6 for the last) */
+  BGNN_K_COUNT = 10
 };
 int bgnn_ctx_profile(bgnn_ctx *ctx, uint32_t kernel_mask);
 int bgnn_ctx_profile_read(bgnn_ctx *ctx, double *ms, int64_t *launches);
