@@ -345,7 +345,7 @@ static void graph_free(bgnn_graph *g) {
   DevPool &P = g->ctx->pool;
   P.release(g->d_tiles); P.release(g->d_items); P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
-  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm); P.release(g->d_items2);
+  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm); P.release(g->d_items2); P.release(g->d_items3);
   delete g;
 }
 
@@ -383,7 +383,7 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
     g->F = nf;
   }
   int64_t cells = 0;
-  std::vector<BgnnWorkItem> items, items2;
+  std::vector<BgnnWorkItem> items, items2, items3;
   bool uniform = true;
   g->h_tiles.resize(tiles->n_tiles);
   for (int t = 0; t < tiles->n_tiles; ++t) {
@@ -403,16 +403,23 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
     int rows_per = std::max(1, 2048 / w);
     for (int r0 = 0; r0 < h; r0 += rows_per) items.push_back({t, r0, std::min(rows_per, h - r0), 0});
     if (h != tiles->hw[0] || w != tiles->hw[1]) uniform = false;
+    if (w > g->max_w) g->max_w = w;
   }
   if (uniform) {
     g->uni_h = tiles->hw[0]; g->uni_w = tiles->hw[1];
     g->bh2 = (g->uni_h + 15) / 16; g->bw2 = (g->uni_w + 15) / 16;
     g->n_blocks2 = g->n_tiles * g->bh2 * g->bw2;
+    g->bh3 = (g->uni_h + 7) / 8; g->bw3 = g->bw2;
+    g->n_blocks3 = g->n_tiles * g->bh3 * g->bw3;
   } else {
     for (int t = 0; t < tiles->n_tiles; ++t)
       for (int r0 = 0; r0 < g->h_tiles[t].h; r0 += 16)
         for (int c0 = 0; c0 < g->h_tiles[t].w; c0 += 16) items2.push_back({t, r0, c0, 0});
     g->n_blocks2 = (int32_t)items2.size();
+    for (int t = 0; t < tiles->n_tiles; ++t)
+      for (int r0 = 0; r0 < g->h_tiles[t].h; r0 += 8)
+        for (int c0 = 0; c0 < g->h_tiles[t].w; c0 += 16) items3.push_back({t, r0, c0, 0});
+    g->n_blocks3 = (int32_t)items3.size();
   }
   g->total_cells = (int32_t)cells; g->row_capacity = (int32_t)cells; g->n_items = (int32_t)items.size();
   DevPool &P = ctx->pool;
@@ -428,8 +435,10 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
   GALLOC(g->d_nbr, int32_t, cells * g->K)
   GALLOC(g->d_eattr, float, cells * g->K * g->ED)
   if (!uniform) GALLOC(g->d_items2, BgnnWorkItem, items2.size())
+  if (!uniform) GALLOC(g->d_items3, BgnnWorkItem, items3.size())
 #undef GALLOC
   if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items2.data(), sizeof(BgnnWorkItem) * items2.size(), g->d_items2);
+  if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items3.data(), sizeof(BgnnWorkItem) * items3.size(), g->d_items3);
   if (rc == BGNN_OK) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
   if (rc == BGNN_OK) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
   if (rc == BGNN_OK) rc = launch_graph_build(ctx, g, tiles, opts);

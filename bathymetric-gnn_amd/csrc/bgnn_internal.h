@@ -142,6 +142,10 @@ struct bgnn_graph {
   int32_t n_blocks2 = 0;
   int32_t uni_h = 0, uni_w = 0;       // common tile shape, 0 if ragged
   int32_t bh2 = 0, bw2 = 0;           // blocks per tile (uniform case)
+  // 8x16 cell blocks for the fused layer kernel
+  BgnnWorkItem *d_items3 = nullptr;
+  int32_t n_blocks3 = 0, bh3 = 0, bw3 = 0;
+  int32_t max_w = 0;
 };
 
 namespace bgnn {

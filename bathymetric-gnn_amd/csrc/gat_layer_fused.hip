@@ -1,6 +1,6 @@
 // Fused GAT layer for stencil graphs (gfx950):  aggregate_l  ->  BN/ReLU  ->  GEMM_{l+1}
 //
-// One workgroup (256 threads = 4 waves, one per SIMD, one workgroup per CU) owns a 16x16 block of cells of one tile and
+// One workgroup (256 threads = 4 waves; two workgroups per CU) owns an 8x16 block of cells of one tile and
 // produces, for those 256 nodes, what the NEXT stage needs:
 //   EPI_NEXT : xw_{l+1} = h_{l+1} @ W_{l+1}^T  and its attention dots (alpha_src, alpha_dst)
 //   EPI_HEADS: the three output heads, softmax / argmax / sigmoid, the predict() flags and
@@ -105,174 +105,198 @@ __device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k
   }
 }
 
+constexpr int FT_H = 8;                                  // fused kernel: 8 x 16 cell blocks
+constexpr int FHR = (FT_H + 2) * HALO_W;                 // 180 halo rows
+
 template <int HC, int C, int K, int NT, int EPI>
-__global__ __launch_bounds__(256, 1) void gat_layer_fused_kernel(FusedArgs a) {
-  // 4 waves, ONE per SIMD, each with the whole 512-register budget: a wave's accumulator is
-  // 64 nodes x NC channels (2 row groups x NT tiles x 16 regs = 256 registers at NC = 256).
+__global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
+  // 4 waves; wave w owns cells 32w..32w+31 (two tile rows).  Lane (r, hl): node r of the wave, k-half hl.
+  // TWO workgroups per CU (2 waves per SIMD, 256 registers each): while one runs its MFMA phase the other
+  // gathers / waits for its DMA, so the matrix pipe stays fed without hand interleaving.
   constexpr int H = HC / C;
   constexpr int NC = NT * 32;
   constexpr int NSLAB = HC / 32, SPH = C / 32;
-  constexpr int HR = HALO_ROWS, HW_ = HALO_W;
+  constexpr int HR = FHR, HW_ = HALO_W;
   using Off = StencilOffsets<K>;
   extern __shared__ __attribute__((aligned(128))) float lds[];
-  float *slab = lds;                                   // [2][HR][32]  halo rows of slab s / s+1, 16-B chunks XOR-swizzled
-  float *wbuf = slab + 2 * HR * 32;                    // [2][32][NC]  W_{l+1} rows of slab s / s+1
-  float *scsh = wbuf + 2 * 32 * NC;                    // [2][HC]      folded scale / shift
+  float *slab = lds;                                   // [HR][32]  halo rows of the current slab, 16-B chunks XOR-swizzled
+  float *wbuf = slab + HR * 32;                        // [32][NC]  W_{l+1} rows of the current slab
+  float *scsh = wbuf + 32 * NC;                        // [2][HC]   folded scale / shift
   int *hid = reinterpret_cast<int *>(scsh + 2 * HC);   // [HR]
   float *has = reinterpret_cast<float *>(hid + HR);    // [HR][H]
+  int *minid = reinterpret_cast<int *>(has + HR * H);  // [4]
+  float *alx = reinterpret_cast<float *>(minid + 4);   // [128][36]  alpha[cell][head][K+1]
 
-  const BlockPos pos = decode_block(a.tb);
+  const BlockPos pos = decode_block<FT_H>(a.tb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tr = tid / TILE_W, tc = tid % TILE_W;      // thread = cell in the gather phase
+  const int r = lane & 31, hl = lane >> 5;
+  const int cell = wave * 32 + r;                      // block-local cell of this lane (both halves)
+  const int tr = cell / TILE_W, tc = cell % TILE_W;
   const int self_idx = (tr + 1) * HW_ + tc + 1;
 
-  load_halo_ids<H, 256>(pos, a.node_id, a.asd, hid, has);
+  if (tid == 0) *minid = 0x7fffffff;
+  // rows without a node are never written by the DMA: zero them once
+  for (int i = tid; i < HR * 8; i += 256) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  load_halo_ids<H, 256, HR>(pos, a.node_id, a.asd, hid, has);
   for (int i = tid; i < HC; i += 256) { scsh[i] = a.scale[i]; scsh[HC + i] = a.shift[i]; }
   __syncthreads();
+  {
+    int m = 0x7fffffff;
+    for (int i = tid; i < HR; i += 256) { const int v = hid[i]; if (v >= 0 && v < m) m = v; }
+    if (m != 0x7fffffff) atomicMin(minid, m);
+  }
+  __syncthreads();
+  const int id0 = *minid;                              // smallest node id of the halo (0x7fffffff: block has no node)
 
-  // Halo rows go global -> LDS by LDS-DMA (no VGPR staging, nothing live across the MFMA phase).  A
-  // wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B, so rows are unpadded and the bank
-  // spreading is an XOR swizzle applied on the SOURCE side: LDS chunk p of a row holds channel chunk
-  // p ^ ((row >> 1) & 7).  Rows that have no node read a zero page.
+  // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B;
+  // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk
+  // p ^ ((row >> 1) & 7).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
+  // offsets (relative to node id0, 32 bits) are computed once.
   constexpr int NPIECE = (HR * 8 + 255) / 256;
-  auto issue_slab = [&](int s, float *dst) {
-#pragma unroll 1                                         // (unrolled, hipcc hoists + spills the addresses and
-    for (int j = 0; j < NPIECE; ++j) {                   //  every reload's vmcnt(0) serialises the DMAs)
-      const int idx = j * 256 + tid;
-      if (idx < HR * 8) {
-        const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
-        const int id = hid[row];
-        const float *src = id >= 0 ? a.xw + (int64_t)id * HC + s * 32 + c * 4 : a.zero_page;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src),
-                                         (__attribute__((address_space(3))) void *)(dst + (j * 256 + wave * 64) * 4), 16, 0, 0);
-      }
+  uint32_t doff[NPIECE];
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) {
+    const int idx = p * 256 + tid;
+    doff[p] = 0xffffffffu;
+    if (idx < HR * 8) {
+      const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
+      const int id = hid[row];
+      if (id >= 0) doff[p] = (uint32_t)(id - id0) * (uint32_t)(HC * 4) + (uint32_t)(c * 16);
+    }
+  }
+  const char *xbase = reinterpret_cast<const char *>(a.xw + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * HC);
+  auto issue_slab = [&](int s) {
+    const char *sb = xbase + s * 128;                  // wave-uniform
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      if (doff[p] != 0xffffffffu)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(sb + doff[p]),
+                                         (__attribute__((address_space(3))) void *)(slab + (p * 256 + wave * 64) * 4), 16, 0, 0);
     }
   };
-  issue_slab(0, slab);
+  issue_slab(0);
   stage_w_chunk<NT>(a.Wt, wbuf, 0, wave, lane);
 
-  // ---- phase A: attention coefficients of this thread's cell, all heads, kept in registers ----------
-  float alf[(K + 1) * H];
+  // ---- phase A: attention coefficients of this lane's cell -> LDS; the two lane halves split the heads ----
   {
     const int my = hid[self_idx];
+    if constexpr (H >= 2) {
+      constexpr int NH = H / 2;
+      float part[(K + 1) * NH];
 #pragma unroll
-    for (int i = 0; i < (K + 1) * H; ++i) alf[i] = 0.0f;
-    if (my >= 0) attention_coefficients<H, K, 0, H>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, alf);
+      for (int i = 0; i < (K + 1) * NH; ++i) part[i] = 0.0f;
+      if (my >= 0) {
+        if (hl == 0) attention_coefficients<H, K, 0, NH>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, part);
+        else attention_coefficients<H, K, H / 2, NH>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, part);
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k)
+#pragma unroll
+        for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + (hl * NH + k) * (K + 1) + b] = part[b * NH + k];
+    } else {
+      float part[K + 1];
+#pragma unroll
+      for (int i = 0; i <= K; ++i) part[i] = 0.0f;
+      if (hl == 0) {
+        if (my >= 0) attention_coefficients<H, K, 0, 1>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, part);
+#pragma unroll
+        for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + b] = part[b];
+      }
+    }
+    // (both halves of a cell sit in the same wave: no barrier needed beyond the one at the top of the slab loop)
   }
 
-  f32x16 acc[2][NT];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[g][t][i] = 0.0f;
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-  const int r = lane & 31, hl = lane >> 5;              // MFMA lane roles: node r of a row group, k-half hl
-  // neighbour rows of this cell in the swizzled slab image: byte offset of chunk 0's slot
   const uint32_t slab0 = lds_addr(slab);
   const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r);
-  const uint32_t scsh0 = lds_addr(scsh);
+  const uint32_t scsh0 = lds_addr(scsh) + hl * 16;
+  const uint32_t alx0 = lds_addr(alx + cell * TILED_PITCH);
 
-  // ---- slabs: ONE barrier each.  Slab s+1 and W chunk s+1 stream into the other buffers while slab s is
-  // gathered and multiplied, so their latency is hidden; the gather output never touches LDS: the wave that
-  // gathers cells 64w..64w+63 is the wave that multiplies them, and v_permlane32_swap puts each value in the
-  // lane half the MFMA B operand wants.
-#pragma unroll
-  for (int hh = 0; hh < H; ++hh) {
+  // ---- slabs.  Lane (r, hl) gathers exactly the 16 values it feeds to the MFMA as B operand: channel chunks
+  // 2j + hl (j = 0..3) of node r, i.e. k = 8j + 4hl + i of k-step j -- no LDS round trip, no lane exchange.
+  {
 #pragma unroll 1
-    for (int ss = 0; ss < SPH; ++ss) {
-      const int s = hh * SPH + ss;
-      const int buf = s & 1;
+    for (int s = 0; s < NSLAB; ++s) {
       wait_vm_lgkm<0>();
-      __builtin_amdgcn_s_barrier();                     // slab s / W s visible; everyone is past iteration s-1
-      if (s + 1 < NSLAB) {
-        issue_slab(s + 1, slab + (buf ^ 1) * HR * 32);
-        stage_w_chunk<NT>(a.Wt, wbuf + (buf ^ 1) * 32 * NC, (s + 1) * 32, wave, lane);
-      }
-      // gather: g[q] = sum_b alpha[b] * row_b[chunk q]
-      f32x4 g[8];
+      __builtin_amdgcn_s_barrier();                     // slab s and W chunk s have landed for every wave
+      const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
+      f32x4 g[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const uint32_t sb = slab0 + buf * (HR * 128);
+      for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int b = 0; b <= K; ++b) {
         const int nidx = b == K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
-        const uint32_t rb = sb + nidx * 128 + (((nidx >> 1) & 7) << 4);   // slot of channel chunk 0
-        f32x4 x[8];
-        x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ 16); x[2] = lds_read4<0>(rb ^ 32); x[3] = lds_read4<0>(rb ^ 48);
-        x[4] = lds_read4<0>(rb ^ 64); x[5] = lds_read4<0>(rb ^ 80); x[6] = lds_read4<0>(rb ^ 96); x[7] = lds_read4<0>(rb ^ 112);
+        // slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5))
+        const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ hl) << 4);
+        f32x4 x[4];
+        const float alpha = lds_read1<0>(ap + 4 * b);
+        x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ 32); x[2] = lds_read4<0>(rb ^ 64); x[3] = lds_read4<0>(rb ^ 96);
         lds_reads_done();
-        const float alpha = alf[b * H + hh];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] += alpha * x[q];
+        for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
       }
-      // layer epilogue: (+bias, BatchNorm) folded, ReLU -> h_{l+1}[cell][s*32 ..], in registers
+      // layer epilogue: (+bias, BatchNorm) folded, ReLU -> h_{l+1}, in registers
       {
         const uint32_t cp = scsh0 + s * 128;
-        f32x4 sc[8], sh[8];
-        sc[0] = lds_read4<0>(cp); sc[1] = lds_read4<16>(cp); sc[2] = lds_read4<32>(cp); sc[3] = lds_read4<48>(cp);
-        sc[4] = lds_read4<64>(cp); sc[5] = lds_read4<80>(cp); sc[6] = lds_read4<96>(cp); sc[7] = lds_read4<112>(cp);
-        sh[0] = lds_read4<HC * 4>(cp); sh[1] = lds_read4<HC * 4 + 16>(cp); sh[2] = lds_read4<HC * 4 + 32>(cp);
-        sh[3] = lds_read4<HC * 4 + 48>(cp); sh[4] = lds_read4<HC * 4 + 64>(cp); sh[5] = lds_read4<HC * 4 + 80>(cp);
-        sh[6] = lds_read4<HC * 4 + 96>(cp); sh[7] = lds_read4<HC * 4 + 112>(cp);
-        lds_reads_done();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          g[q] = g[q] * sc[q] + sh[q];
-          if (a.relu) {
-            g[q].x = g[q].x > 0.f ? g[q].x : 0.f; g[q].y = g[q].y > 0.f ? g[q].y : 0.f;
-            g[q].z = g[q].z > 0.f ? g[q].z : 0.f; g[q].w = g[q].w > 0.f ? g[q].w : 0.f;
+        for (int jp = 0; jp < 2; ++jp) {                // two chunks at a time (register budget)
+          f32x4 sc0, sc1, sh0, sh1;
+          if (jp == 0) { sc0 = lds_read4<0>(cp); sc1 = lds_read4<32>(cp); sh0 = lds_read4<HC * 4>(cp); sh1 = lds_read4<HC * 4 + 32>(cp); }
+          else { sc0 = lds_read4<64>(cp); sc1 = lds_read4<96>(cp); sh0 = lds_read4<HC * 4 + 64>(cp); sh1 = lds_read4<HC * 4 + 96>(cp); }
+          lds_reads_done();
+          g[2 * jp] = g[2 * jp] * sc0 + sh0;
+          g[2 * jp + 1] = g[2 * jp + 1] * sc1 + sh1;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            g[j].x = g[j].x > 0.f ? g[j].x : 0.f; g[j].y = g[j].y > 0.f ? g[j].y : 0.f;
+            g[j].z = g[j].z > 0.f ? g[j].z : 0.f; g[j].w = g[j].w > 0.f ? g[j].w : 0.f;
           }
         }
       }
-      // B operands: MFMA k-step (s8, i) takes channel 8*s8 + 4*hl + i of node r (row group 0) and node r+32
-      // (row group 1).  Lane L holds every channel of node L: chunks 2*s8 (hl = 0) and 2*s8+1 (hl = 1).
-      // permlane32_swap(A, B) -> A' = [low lanes: A.low | high lanes: B.low], B' = [A.high | B.high]
-      f32x4 x0[4], x1[4];
+      __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
+      if (s + 1 < NSLAB) issue_slab(s + 1);
+      // rank-32 update of the wave's [32 nodes x NC] accumulator
 #pragma unroll
       for (int s8 = 0; s8 < 4; ++s8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float lo = g[2 * s8][i], hi = g[2 * s8 + 1][i];
-          // lanes 32-63 of `lo` <-> lanes 0-31 of `hi`
-          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
-          x0[s8][i] = lo;
-          x1[s8][i] = hi;
-        }
-      }
-      // rank-32 update of the block's accumulator
-      const uint32_t wa = wbuf0 + buf * (32 * NC * 4);
-#pragma unroll
-      for (int s8 = 0; s8 < 4; ++s8) {
-        float wv[4][NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          wv[0][t] = lds_read1<(0) * 4>(wa + (s8 * 8 * NC + t * 32) * 4);
-          wv[1][t] = lds_read1<(NC) * 4>(wa + (s8 * 8 * NC + t * 32) * 4);
-          wv[2][t] = lds_read1<(2 * NC) * 4>(wa + (s8 * 8 * NC + t * 32) * 4);
-          wv[3][t] = lds_read1<(3 * NC) * 4>(wa + (s8 * 8 * NC + t * 32) * 4);
-        }
-        lds_reads_done();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int ip = 0; ip < 2; ++ip) {                // two k rows at a time (register budget)
+          float wa_[NT], wb_[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i][t], x0[s8][i], acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i][t], x1[s8][i], acc[1][t], 0, 0, 0);
+            if (ip == 0) {
+              wa_[t] = lds_read1<(0) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
+              wb_[t] = lds_read1<(NC) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
+            } else {
+              wa_[t] = lds_read1<(2 * NC) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
+              wb_[t] = lds_read1<(3 * NC) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
+            }
           }
+          lds_reads_done();
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa_[t], g[s8][2 * ip], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb_[t], g[s8][2 * ip + 1], acc[t], 0, 0, 0);
         }
+      }
+      if (s + 1 < NSLAB) {
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();                   // every wave is done with W chunk s
+        stage_w_chunk<NT>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
       }
     }
   }
-  const int mrow0 = wave * 64 + r;                      // block-local node (cell) of row group 0; group 1 = +32
 
   // ---- epilogue: lane (r, hl) holds node mrow; reg i of tile t -> channel t*32 + 8*(i>>2) + 4*hl + (i&3) ----
-#pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
-    const int mrow = mrow0 + 32 * rg;
-    const int mr = mrow / TILE_W, mc = mrow % TILE_W;
-    const int id = hid[(mr + 1) * HW_ + mc + 1];
+  {
+    const int mr = tr, mc = tc;
+    const int id = hid[self_idx];
     if (EPI == EPI_NEXT) {
       // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32)
       constexpr int TPH = C / 32, H2 = NT / TPH;
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void gat_layer_fused_kernel(FusedArgs a) {
         for (int g = 0; g < 4; ++g) {
           const float4 s4 = *reinterpret_cast<const float4 *>(a.att_src + t * 32 + 8 * g + 4 * hl);
           const float4 d4 = *reinterpret_cast<const float4 *>(a.att_dst + t * 32 + 8 * g + 4 * hl);
-          const float4 v = make_float4(acc[rg][t][4 * g], acc[rg][t][4 * g + 1], acc[rg][t][4 * g + 2], acc[rg][t][4 * g + 3]);
+          const float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
           ps[t / TPH] += v.x * s4.x + v.y * s4.y + v.z * s4.z + v.w * s4.w;
           pd[t / TPH] += v.x * d4.x + v.y * d4.y + v.z * d4.z + v.w * d4.w;
           if (id >= 0) *reinterpret_cast<float4 *>(yp + t * 32 + 8 * g) = v;
@@ -315,8 +339,8 @@ __global__ __launch_bounds__(256, 1) void gat_layer_fused_kernel(FusedArgs a) {
         for (int g = 0; g < 4; ++g) {
           const int c0 = 8 * g + 4 * hl;                 // unit index within the head
           const float4 b4 = *reinterpret_cast<const float4 *>(a.hd_b0 + t * 32 + c0);
-          float v[4] = {acc[rg][t][4 * g] + b4.x, acc[rg][t][4 * g + 1] + b4.y, acc[rg][t][4 * g + 2] + b4.z,
-                        acc[rg][t][4 * g + 3] + b4.w};
+          float v[4] = {acc[t][4 * g] + b4.x, acc[t][4 * g + 1] + b4.y, acc[t][4 * g + 2] + b4.z,
+                        acc[t][4 * g + 3] + b4.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
           if (t == 0) {
@@ -396,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void gat_layer_fused_kernel(FusedArgs a) {
 template <int HC, int C, int K, int NT, int EPI>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr int H = HC / C;
-  constexpr size_t lds_bytes = (size_t)(2 * HALO_ROWS * 32 + 2 * 32 * NT * 32 + 2 * HC + HALO_ROWS + HALO_ROWS * H) * 4;
+  constexpr size_t lds_bytes = (size_t)(FHR * 32 + 32 * NT * 32 + 2 * HC + FHR + FHR * H + 4 + 128 * TILED_PITCH) * 4;
   static bool configured = false;     // per instantiation
   auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI>;
   if (!configured) {
@@ -410,13 +434,13 @@ static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
 }
 
 static bool fused_supported(const bgnn_graph *g, int C) {
-  return g->kind == 0 && (g->K == 4 || g->K == 8) && g->n_blocks2 > 0 && C == 64;
+  return g->kind == 0 && (g->K == 4 || g->K == 8) && g->n_blocks3 > 0 && C == 64 && g->max_w <= 8192;
 }
 
 static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, int ED, const float *xw, const float *asd,
                         int relu) {
-  a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items2;
-  a.tb.bh = g->bh2; a.tb.bw = g->bw2; a.tb.n_blocks = g->n_blocks2;
+  a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items3;
+  a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
   a.node_id = g->d_node_id; a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
   a.ED = ED; a.relu = relu; a.zero_page = g->ctx->zero_page;
   { const char *e = getenv("BGNN_FUSED_DBG"); a.dbg = e ? atoi(e) : 0; }

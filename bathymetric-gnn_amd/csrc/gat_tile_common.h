@@ -15,9 +15,10 @@ template <> struct StencilOffsets<8> {   // graph_construction.py:83-87
   static constexpr int dc[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 };
 
-constexpr int TILE_H = 16, TILE_W = 16;
-constexpr int HALO_W = TILE_W + 2, HALO_ROWS = (TILE_H + 2) * (TILE_W + 2);   // 18, 324
-constexpr int TILED_PITCH = 36;   // dwords per staged 32-channel row slab (32 + 4 pad)
+constexpr int TILE_W = 16;                    // cell blocks are TH x 16 (TH = 16: tiled aggregate, TH = 8: fused layer)
+constexpr int HALO_W = TILE_W + 2;            // 18
+constexpr int TILED_PITCH = 36;               // dwords per staged 32-channel row slab (32 + 4 pad)
+constexpr int TILE_H = 16, HALO_ROWS = (TILE_H + 2) * HALO_W;   // geometry of the 16x16 tiled aggregate
 
 // halo-index offset (dr*HALO_W + dc) of stencil slot b, computed arithmetically for runtime b;
 // b == K is the self loop (offset 0)
@@ -46,6 +47,7 @@ struct BlockPos {
 
 // XCD-aware block order: consecutive work items (adjacent cell blocks, which share halo rows) run on
 // the same XCD and hit its L2.  Bijective for any n_blocks.
+template <int TH = TILE_H>
 __device__ __forceinline__ BlockPos decode_block(const TileBlocks &tb) {
   const int nb = tb.n_blocks;
   const int bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
@@ -58,7 +60,7 @@ __device__ __forceinline__ BlockPos decode_block(const TileBlocks &tb) {
     const int bpt = tb.bh * tb.bw;
     p.tile = wid / bpt;
     const int rem = wid - p.tile * bpt;
-    p.r0 = (rem / tb.bw) * TILE_H; p.c0 = (rem % tb.bw) * TILE_W;
+    p.r0 = (rem / tb.bw) * TH; p.c0 = (rem % tb.bw) * TILE_W;
   }
   const BgnnTileMeta t = tb.tiles[p.tile];
   p.h = t.h; p.w = t.w; p.cell_off = t.cell_off;
@@ -66,10 +68,10 @@ __device__ __forceinline__ BlockPos decode_block(const TileBlocks &tb) {
 }
 
 // phase 0: node ids of the 18x18 halo (-1 = outside the tile or invalid) and their alpha_src
-template <int H, int NTHREADS>
+template <int H, int NTHREADS, int HROWS = HALO_ROWS>
 __device__ __forceinline__ void load_halo_ids(const BlockPos &p, const int32_t *node_id, const float *asd, int *hid,
                                               float *has) {
-  for (int idx = threadIdx.x; idx < HALO_ROWS; idx += NTHREADS) {
+  for (int idx = threadIdx.x; idx < HROWS; idx += NTHREADS) {
     const int gr = p.r0 + idx / HALO_W - 1, gc = p.c0 + idx % HALO_W - 1;
     int id = -1;
     if (gr >= 0 && gr < p.h && gc >= 0 && gc < p.w) {
