@@ -159,12 +159,22 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     }
     c->owns_stream = true;
   }
-  if (hipMalloc((void **)&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+  if (hipMalloc((void **)&c->zero_page, 8192) != hipSuccess || hipMemset(c->zero_page, 0, 8192) != hipSuccess) {
     set_error("zero page allocation failed");
     delete c;
     return BGNN_ERR_NOMEM;
   }
+  c->stamps = reinterpret_cast<unsigned long long *>(c->zero_page + 1024);
   *out = c;
+  return BGNN_OK;
+}
+
+// diagnostic (not part of the documented ABI): read and clear the fused kernel's phase counters
+int bgnn_debug_stamps(bgnn_ctx *ctx, unsigned long long *out16) {
+  if (!ctx || !out16) return BGNN_ERR_INVALID;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (hipMemcpy(out16, ctx->stamps, 128, hipMemcpyDeviceToHost) != hipSuccess) return BGNN_ERR_HIP;
+  (void)hipMemset(ctx->stamps, 0, 128);
   return BGNN_OK;
 }
 

@@ -84,6 +84,7 @@ struct bgnn_ctx {
   size_t pinned_bytes = 0;
   int num_cus = 256;
   float *zero_page = nullptr;   // 4 KiB of zeros
+  unsigned long long *stamps = nullptr;   // 16 diagnostic counters (inside the zero page allocation)
 };
 
 struct BgnnLayer {

@@ -28,6 +28,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_NEXT = 0, EPI_HEADS = 1 };
 
+#define BGNN_STAMP(slot)                                                                   \
+  if (a.stamps && threadIdx.x == 0) {                                                      \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();                            \
+    atomicAdd(a.stamps + (slot), _t - t_prev);                                             \
+    t_prev = _t;                                                                           \
+  }
+
 struct FusedArgs {
   TileBlocks tb;
   const int32_t *node_id;
@@ -40,6 +47,7 @@ struct FusedArgs {
   const float *Wt;        // [HC][NC] next stage weight (transposed)
   const float *zero_page; // >= 16 B of zeros (source of halo rows that have no node)
   int ED, relu, dbg;
+  unsigned long long *stamps;   // diagnostic build only (BGNN_FUSED_STAMPS): per-phase cycle sums
   // EPI_NEXT
   const float *att_src;   // [NC]
   const float *att_dst;
@@ -84,6 +92,38 @@ __device__ __forceinline__ void lds_reads_done() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
+// (+ 4*hl, folded into the base address).  The W fragments of group M+1 are requested before the MFMAs of
+// group M are issued, so their LDS latency hides under the matrix pipe.
+template <int NT, int M>
+struct MfmaGroups {
+  static constexpr int NC = NT * 32;
+  static constexpr int ROW = 8 * (M / 2) + 2 * (M & 1);
+  __device__ static __forceinline__ void load(float (&wa)[NT], float (&wb)[NT], uint32_t wbuf0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wa[t] = lds_read1<ROW * NC * 4>(wbuf0 + t * 128);
+      wb[t] = lds_read1<(ROW + 1) * NC * 4>(wbuf0 + t * 128);
+    }
+  }
+  __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const f32x4 (&g)[4], uint32_t wbuf0) {
+    float wa[NT], wb[NT];
+    load(wa, wb, wbuf0);
+    step(acc, g, wbuf0, wa, wb);
+  }
+  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const f32x4 (&g)[4], uint32_t wbuf0, float (&wa)[NT],
+                                             float (&wb)[NT]) {
+    lds_reads_done();
+    float na[NT], nb[NT];
+    if constexpr (M + 1 < 8) MfmaGroups<NT, M + 1>::load(na, nb, wbuf0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t], g[M / 2][2 * (M & 1) + 1], acc[t], 0, 0, 0);
+    if constexpr (M + 1 < 8) MfmaGroups<NT, M + 1>::step(acc, g, wbuf0, na, nb);
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
@@ -127,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   int *minid = reinterpret_cast<int *>(has + HR * H);  // [4]
   float *alx = reinterpret_cast<float *>(minid + 4);   // [128][36]  alpha[cell][head][K+1]
 
+  unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
   const BlockPos pos = decode_block<FT_H>(a.tb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hl = lane >> 5;
@@ -146,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
     if (m != 0x7fffffff) atomicMin(minid, m);
   }
   __syncthreads();
+  BGNN_STAMP(0)   // halo ids, zero fill, min id
   const int id0 = *minid;                              // smallest node id of the halo (0x7fffffff: block has no node)
 
   // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B;
@@ -176,10 +218,11 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   };
   issue_slab(0);
   stage_w_chunk<NT>(a.Wt, wbuf, 0, wave, lane);
+  BGNN_STAMP(1)   // DMA offsets + first issue
 
   // ---- phase A: attention coefficients of this lane's cell -> LDS; the two lane halves split the heads ----
   {
-    const int my = hid[self_idx];
+    const int my = (a.dbg & 32) ? -1 : hid[self_idx];
     if constexpr (H >= 2) {
       constexpr int NH = H / 2;
       float part[(K + 1) * NH];
@@ -206,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
     // (both halves of a cell sit in the same wave: no barrier needed beyond the one at the top of the slab loop)
   }
 
+  BGNN_STAMP(2)   // phase A
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -222,12 +266,15 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   {
 #pragma unroll 1
     for (int s = 0; s < NSLAB; ++s) {
-      wait_vm_lgkm<0>();
-      __builtin_amdgcn_s_barrier();                     // slab s and W chunk s have landed for every wave
+      // VM queue order per wave: [slab s pieces] [NT pieces of W chunk s]: vmcnt(NT) = "slab landed, W may fly"
+      wait_vm_lgkm<NT>();
+      __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
+      BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
       f32x4 g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!(a.dbg & 1))
 #pragma unroll
       for (int b = 0; b <= K; ++b) {
         const int nidx = b == K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
@@ -260,62 +307,67 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
           }
         }
       }
-      __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
-      if (s + 1 < NSLAB) issue_slab(s + 1);
+      BGNN_STAMP(4)   // gather + layer epilogue
+      wait_vm_lgkm<0>();
+      __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s; W chunk s landed
+      BGNN_STAMP(5)   // wait for W + barrier
+      if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
       // rank-32 update of the wave's [32 nodes x NC] accumulator
-#pragma unroll
-      for (int s8 = 0; s8 < 4; ++s8) {
-#pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {                // two k rows at a time (register budget)
-          float wa_[NT], wb_[NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (ip == 0) {
-              wa_[t] = lds_read1<(0) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
-              wb_[t] = lds_read1<(NC) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
-            } else {
-              wa_[t] = lds_read1<(2 * NC) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
-              wb_[t] = lds_read1<(3 * NC) * 4>(wbuf0 + (s8 * 8 * NC + t * 32) * 4);
-            }
-          }
-          lds_reads_done();
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa_[t], g[s8][2 * ip], acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb_[t], g[s8][2 * ip + 1], acc[t], 0, 0, 0);
-        }
-      }
+      if (!(a.dbg & 2)) MfmaGroups<NT, 0>::run(acc, g, wbuf0);
+      BGNN_STAMP(6)   // slab DMA issue + MFMA
       if (s + 1 < NSLAB) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                   // every wave is done with W chunk s
-        stage_w_chunk<NT>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
+        if (!(a.dbg & 8)) stage_w_chunk<NT>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
+        BGNN_STAMP(7)   // barrier + W DMA issue
       }
     }
   }
 
-  // ---- epilogue: lane (r, hl) holds node mrow; reg i of tile t -> channel t*32 + 8*(i>>2) + 4*hl + (i&3) ----
-  {
+  // ---- epilogue: lane (r, hl) holds node `cell`; reg i of tile t -> channel t*32 + 8*(i>>2) + 4*hl + (i&3) ----
+  if (EPI == EPI_NEXT) {
+    __syncthreads();                                    // every wave is done with wbuf
+    for (int i = tid; i < NC; i += 256) { wbuf[i] = a.att_src[i]; wbuf[NC + i] = a.att_dst[i]; }
+    __syncthreads();
+  }
+  if (!(a.dbg & 64)) {
     const int mr = tr, mc = tc;
     const int id = hid[self_idx];
     if (EPI == EPI_NEXT) {
-      // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32)
+      // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32).
+      // att_src / att_dst were staged into LDS (wbuf is free now): no global-load latency chain here.
       constexpr int TPH = C / 32, H2 = NT / TPH;
       float ps[H2], pd[H2];
 #pragma unroll
       for (int hd = 0; hd < H2; ++hd) { ps[hd] = 0.0f; pd[hd] = 0.0f; }
-      float *yp = a.out + (int64_t)(id >= 0 ? id : 0) * NC + 4 * hl;
+      const float *asl = wbuf + 4 * hl, *adl = wbuf + NC + 4 * hl;
+      // Row-per-lane stores (32 rows x 32 B per instruction) are store-issue bound; instead each 32x32 tile
+      // is transposed through a wave-private LDS patch (the slab region is free now) and written out as whole
+      // 128-byte row segments, 8 rows per instruction.
+      float *patch = slab + wave * (32 * TILED_PITCH);
+      int64_t rid[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = wave * 32 + (lane >> 3) + 8 * k;
+        rid[k] = hid[(c / TILE_W + 1) * HW_ + c % TILE_W + 1];
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 s4 = *reinterpret_cast<const float4 *>(a.att_src + t * 32 + 8 * g + 4 * hl);
-          const float4 d4 = *reinterpret_cast<const float4 *>(a.att_dst + t * 32 + 8 * g + 4 * hl);
+          const float4 s4 = *reinterpret_cast<const float4 *>(asl + t * 32 + 8 * g);
+          const float4 d4 = *reinterpret_cast<const float4 *>(adl + t * 32 + 8 * g);
           const float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
           ps[t / TPH] += v.x * s4.x + v.y * s4.y + v.z * s4.z + v.w * s4.w;
           pd[t / TPH] += v.x * d4.x + v.y * d4.y + v.z * d4.z + v.w * d4.w;
-          if (id >= 0) *reinterpret_cast<float4 *>(yp + t * 32 + 8 * g) = v;
+          *reinterpret_cast<float4 *>(patch + r * TILED_PITCH + 8 * g + 4 * hl) = v;
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
+          if (rid[k] >= 0 && !(a.dbg & 16))
+            *reinterpret_cast<float4 *>(a.out + rid[k] * NC + t * 32 + (lane & 7) * 4) = v;
+        }
       }
 #pragma unroll
       for (int hd = 0; hd < H2; ++hd) {
@@ -415,6 +467,8 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
       }
     }
   }
+  BGNN_STAMP(8)   // final epilogue
+  if (a.stamps && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
 }
 
 template <int HC, int C, int K, int NT, int EPI>
@@ -444,6 +498,7 @@ static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, i
   a.node_id = g->d_node_id; a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
   a.ED = ED; a.relu = relu; a.zero_page = g->ctx->zero_page;
   { const char *e = getenv("BGNN_FUSED_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.stamps = getenv("BGNN_FUSED_STAMPS") ? g->ctx->stamps : nullptr;
 }
 
 // aggregate of layer L (width HC = L.heads*C) fused with the GEMM of the next layer `Ln`

@@ -96,13 +96,24 @@ __device__ __forceinline__ void attention_coefficients(int my, int self_idx, con
   float ea_sum[4] = {0.f, 0.f, 0.f, 0.f};
   int deg = 0;
   bool present[K];
+  float eraw[K * 4];
+  if (ED == 3 && (K * 3) % 4 == 0) {                 // the usual [K][3] block: K*12 bytes, 16-byte aligned rows
+    const float4 *ep = reinterpret_cast<const float4 *>(eattr + (int64_t)my * K * 3);
+#pragma unroll
+    for (int i = 0; i < K * 3 / 4; ++i) {
+      const float4 v = ep[i];
+      eraw[4 * i] = v.x; eraw[4 * i + 1] = v.y; eraw[4 * i + 2] = v.z; eraw[4 * i + 3] = v.w;
+    }
+  }
 #pragma unroll
   for (int b = 0; b < K; ++b) {
     const int nidx = self_idx - Off::dr[b] * HALO_W - Off::dc[b];   // slot b <- source at -offset[b]
     present[b] = hid[nidx] >= 0;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      ea[b][f] = (f < ED && present[b]) ? eattr[((int64_t)my * K + b) * ED + f] : 0.0f;
+      float e = 0.0f;
+      if (f < ED) e = (ED == 3 && (K * 3) % 4 == 0) ? eraw[(b * 3 + f) & (K * 4 - 1)] : eattr[((int64_t)my * K + b) * ED + f];
+      ea[b][f] = (f < ED && present[b]) ? e : 0.0f;
       if (present[b]) ea_sum[f] += ea[b][f];
     }
     deg += present[b] ? 1 : 0;

@@ -57,7 +57,9 @@ __device__ __forceinline__ void stage_w(const float *Wt, float *dst, int kc, int
 template <int NT, bool ATT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
   constexpr int NC = NT * 32;
-  __shared__ float wl[2][GEMM_KC * NC];
+  constexpr int WL = 2 * GEMM_KC * NC > 4 * 32 * 36 ? 2 * GEMM_KC * NC : 4 * 32 * 36;   // also holds the store patches
+  __shared__ float wl_[WL];
+  float (*wl)[GEMM_KC * NC] = reinterpret_cast<float (*)[GEMM_KC * NC]>(wl_);
   const int64_t M = *a.d_m;
   const int64_t row_block = (int64_t)blockIdx.x * 128;
   if (row_block >= M) return;                       // uniform per block
@@ -142,8 +144,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
       }
     }
   }
-  if (ok) {
-    float *yp = a.Y + row * a.ldy + 4 * h;
+  // Row-per-lane stores are store-issue bound (32 rows x 32 B per instruction).  Each 32x32 tile goes through
+  // a wave-private LDS patch (wl is free now) and leaves as whole 128-byte row segments, 8 rows per instruction.
+  __syncthreads();                                   // every wave is past its last read of wl
+  {
+    float *patch = wl_ + wave * (32 * 36);
+    const int64_t wrow0 = row_block + wave * 32;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -157,7 +163,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
           v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
           v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
         }
-        *reinterpret_cast<float4 *>(yp + t * 32 + 8 * g) = v;
+        *reinterpret_cast<float4 *>(patch + r * 36 + 8 * g + 4 * h) = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = (lane >> 3) + 8 * k;
+        const float4 v = *reinterpret_cast<const float4 *>(patch + rr * 36 + (lane & 7) * 4);
+        if (wrow0 + rr < M) *reinterpret_cast<float4 *>(a.Y + (wrow0 + rr) * a.ldy + t * 32 + (lane & 7) * 4) = v;
       }
     }
   }

@@ -1,0 +1,25 @@
+import os, sys, ctypes as C
+os.environ["BGNN_FUSED_STAMPS"]="1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bathymetric_gnn_amd import runtime as rt, synthetic
+from bathymetric_gnn_amd.data import GraphBuilder
+from bathymetric_gnn_amd.models import BathymetricGNN
+from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+dev=torch.device("cuda:0")
+sd = synthetic.synthetic_state_dict(seed=1234)
+model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); model.load_state_dict({k: torch.as_tensor(v) for k,v in sd.items()}); model.to(dev).eval()
+gb=GraphBuilder(device=dev); eng=TileBatchEngine(model, gb, dev)
+B,S=128,256
+depth,mask,_=synthetic.synthetic_tile_batch(8,S,S,100,"V0"); depth=np.concatenate([depth]*16); mask=np.concatenate([mask]*16)
+d_t=torch.from_numpy(depth).to(dev).reshape(-1); m_t=torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
+hw=np.tile(np.array([[S,S]],np.int32),(B,1)); res=np.full((B,2),0.5)
+eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
+lib=rt.load_library(); lib.bgnn_debug_stamps.argtypes=[C.c_void_p, C.POINTER(C.c_uint64)]
+buf=(C.c_uint64*16)(); lib.bgnn_debug_stamps(eng.ctx.handle, buf)
+eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
+lib.bgnn_debug_stamps(eng.ctx.handle, buf)
+n=buf[15]; names=["prologue ids","dma offs+issue","phase A","wait slab+bar","gather","wait W+bar","MFMA(+slab issue)","bar+W issue","final epilogue"]
+tot=sum(buf[i] for i in range(9))
+print("blocks",n, "total cycles/block", tot/n)
+for i,nm in enumerate(names): print("%-20s %10.0f cycles/block  %5.1f%%"%(nm, buf[i]/n, 100*buf[i]/tot))
