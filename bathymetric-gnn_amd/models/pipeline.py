@@ -26,6 +26,28 @@ from .gnn import BathymetricGNN
 logger = logging.getLogger(__name__)
 
 
+def shard_info():
+    """(rank, world_size) of the tile-parallel job: torch.distributed if initialised, else (0, 1)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def exchange_tile_results(mine: dict) -> dict:
+    """Union of every rank's {tile index: result dict}.  One object all-gather per survey; the data path
+    itself (graph build, forward, scatter) has no collective."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return mine
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, mine)
+    out = {}
+    for p in parts:
+        out.update(p)
+    return out
+
+
 class TileBatchEngine:
     """Fused per-batch inference on one GPU (one engine per worker / device)."""
 
@@ -157,28 +179,33 @@ class BathymetricPipeline:
 
     # ---- whole grid ----------------------------------------------------------------------------
     def process_grid(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
-        """The body of ``process`` between load and save (reference :163-211), tiles batched."""
+        """The body of ``process`` between load and save (reference :163-211), tiles batched.
+
+        Multi-GPU: when ``torch.distributed`` is initialised (one process per GPU), the tiles that
+        pass the ``min_valid_ratio`` filter are dealt round-robin by index to the ranks, each rank
+        classifies its share on its own GPU, the per-tile grids are exchanged once
+        (``all_gather_object``; tiles are independent, so there is no collective inside the data
+        path) and EVERY rank stitches them in ascending spec order -- the float32 blend sums and the
+        ``>`` tie rule of the discrete channel therefore do not depend on the number of GPUs."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
-        merger = TileMerger(self.tile_manager)
-        merger.initialize(grid_shape=grid.shape, channels=["cleaned_depth", "classification", "confidence", "correction"])
         _, _, specs = self.tile_manager.compute_tile_grid(grid.shape)
         by_pos = {(s.tile_row, s.tile_col): s for s in specs}
-        num_tiles, pending = 0, []
-
-        def flush():
-            nonlocal num_tiles
-            for t, r in zip(pending, self._process_tiles(pending, grid)):
-                merger.add_tile(by_pos[(t.tile_row, t.tile_col)], r)   # ascending spec order
-                num_tiles += 1
-            pending.clear()
-
-        for tile in self.tile_manager.iterate_tiles(grid, skip_empty=True):
-            pending.append(tile)
-            if len(pending) >= self.tile_batch:
-                flush()
-        if pending:
-            flush()
+        tiles = list(self.tile_manager.iterate_tiles(grid, skip_empty=True))
+        rank, world = shard_info()
+        mine = list(range(rank, len(tiles), world))
+        done = {}
+        for i0 in range(0, len(mine), self.tile_batch):
+            idx = mine[i0:i0 + self.tile_batch]
+            for i, r in zip(idx, self._process_tiles([tiles[i] for i in idx], grid)):
+                done[i] = r
+        done = exchange_tile_results(done)
+        merger = TileMerger(self.tile_manager)
+        merger.initialize(grid_shape=grid.shape, channels=["cleaned_depth", "classification", "confidence", "correction"])
+        for i in range(len(tiles)):                  # ascending spec order
+            t = tiles[i]
+            merger.add_tile(by_pos[(t.tile_row, t.tile_col)], done[i])
+        num_tiles = len(tiles)
         logger.info(f"Processed {num_tiles} tiles ({len(specs) - num_tiles} skipped below min_valid_ratio)")
         results = merger.finalize()
         valid_mask = grid.valid_mask

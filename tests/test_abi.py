@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/bgnn.h declares; the ctypes
+binding covers exactly that set; structure layouts agree with the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "bgnn.h")).read()
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgnn_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bathymetric_gnn_amd import runtime
+    if not os.path.exists(runtime.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return runtime.load_library()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from bathymetric_gnn_amd import runtime
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in bgnn.h but not exported"
+    assert sorted(runtime._SIGNATURES) == syms
+    assert lib.bgnn_abi_version() == int(re.search(r"#define BGNN_ABI_VERSION (\d+)", HEADER).group(1))
+
+
+def test_struct_layouts():
+    from bathymetric_gnn_amd import runtime as rt
+    assert C.sizeof(rt.ModelDesc) == 32
+    assert C.sizeof(rt.GraphOpts) == 4 * (2 + 1 + 8 + 1 + 4)
+    assert C.sizeof(rt.Outputs) == 9 * C.sizeof(C.c_void_p)
+    assert C.sizeof(rt.Tiles) == 8 + 5 * C.sizeof(C.c_void_p)
+    n_k = int(re.search(r"BGNN_K_COUNT = (\d+)", HEADER).group(1))
+    assert len(rt.K_NAMES) == n_k
+
+
+def test_weight_count_matches_reference_parameter_count(lib):
+    """182 469 parameters for in=8 (docs/QUICK_REFERENCE.md:185 says '182K'); the library's blob adds
+    the BatchNorm running statistics (2 x 832 floats), which are buffers, not parameters."""
+    from bathymetric_gnn_amd import runtime as rt
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    m = BathymetricGNN(in_channels=8, edge_dim=3)
+    assert sum(p.numel() for p in m.parameters()) == 182469
+    d = m._desc()
+    assert lib.bgnn_model_weight_count(C.byref(d)) == 182469 + 2 * (256 * 3 + 64) == m.pack_weights().size
+
+
+def test_errors_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.bgnn_ctx_create(0, None, C.byref(h))
+    assert rc != 0 and lib.bgnn_last_error()
+    from bathymetric_gnn_amd import runtime as rt
+    from bathymetric_gnn_amd.data import GraphBuilder
+    import numpy as np
+    with pytest.raises(rt.BgnnError):                 # no CPU fallback: fail loudly
+        GraphBuilder().build_graph(np.zeros((4, 4), np.float32))
+    with pytest.raises(ValueError):
+        GraphBuilder(connectivity="6-connected")

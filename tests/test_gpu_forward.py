@@ -194,3 +194,48 @@ def test_full_batch_properties(gpu_device):
     assert (o["class_probs"].sum(-1) - 1).abs().max().item() < 1e-5
     cls_grid = out[0].reshape(-1)[torch.from_numpy(mask).cuda().reshape(-1)]
     assert torch.equal(cls_grid, o["predicted_class"].float())
+
+
+def test_pipeline_process_grid_matches_oracle(gpu_device):
+    """BathymetricPipeline.process (models/pipeline.py:134-241) minus file I/O: overlapping tiles, batched
+    fused inference, Hann-ramp stitch, unprocessed-cell preservation, _apply_corrections."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.config import Config
+    from bathymetric_gnn_amd.data import BathymetricGrid, TileManager, TileMerger
+    from bathymetric_gnn_amd.models import BathymetricPipeline
+    cfg = Config()
+    cfg.tile.tile_size, cfg.tile.overlap, cfg.tile.min_valid_ratio = 64, 16, 0.3
+    d, m, _ = synthetic.synthetic_tile(150, 130, 9, "V1")
+    d[:50, :60] = 1.0e6
+    grid = BathymetricGrid(depth=d, nodata_value=1.0e6, resolution=(0.5, 0.5))
+    sd = synthetic.synthetic_state_dict(seed=1234)
+    pipe = BathymetricPipeline(cfg, tile_batch=5)
+    with pytest.raises(RuntimeError):
+        pipe.process_grid(grid)
+    pipe.set_model(_model(sd))
+    res = pipe.process_grid(grid)
+    # oracle: same tile walk, CPU forward per tile, same merger
+    tm = TileManager(64, 16, 0.3)
+    _, _, specs = tm.compute_tile_grid(grid.shape)
+    by_pos = {(s.tile_row, s.tile_col): s for s in specs}
+    merger = TileMerger(tm)
+    merger.initialize(grid.shape, ["cleaned_depth", "classification", "confidence", "correction"])
+    for t in tm.iterate_tiles(grid):
+        og = graph_cpu.build_graph(t.data, t.valid_mask, None, grid.resolution)
+        r = gat_cpu.process_tile(sd, og, 0.85, 0.6)
+        r["cleaned_depth"] = t.data
+        merger.add_tile(by_pos[(t.tile_row, t.tile_col)], r)
+    ref = merger.finalize()
+    vm = grid.valid_mask
+    proc = ~np.isnan(ref["classification"])
+    assert np.array_equal(np.isnan(res["confidence"]), np.isnan(ref["confidence"]) & ~vm)
+    assert np.nanmax(np.abs(res["confidence"][proc] - ref["confidence"][proc])) < TOL
+    assert np.nanmax(np.abs(res["correction"][proc] - ref["correction"][proc])) < 2e-4
+    agree = (res["classification"][proc] == ref["classification"][proc]).mean()
+    assert agree > 0.995                      # (ties between near-equal probabilities / confidences aside)
+    unproc = vm & ~proc
+    assert unproc.any() and np.all(res["classification"][unproc] == 0) and np.all(res["confidence"][unproc] == 0)
+    assert np.array_equal(res["cleaned_depth"][unproc], d[unproc])
+    assert res["valid_mask"].dtype == np.float32 and np.array_equal(res["valid_mask"] > 0, vm)
+    with pytest.raises(ImportError):
+        pipe.process("in.bag", "out.bag")

@@ -1,0 +1,94 @@
+"""Host-side mirror of the reference API: config tree, module/parameter naming, checkpoint key
+compatibility, NativeVRProcessor bookkeeping -- everything that needs no GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bathymetric_gnn_amd import synthetic
+from bathymetric_gnn_amd.config import Config, CORRECTION_NORM_FLOOR, CORRECTION_NORM_CAP
+from bathymetric_gnn_amd.models import BathymetricGNN
+
+
+def test_config_defaults_roundtrip_and_asserts(tmp_path):
+    c = Config()
+    assert (c.tile.tile_size, c.tile.overlap, c.tile.min_valid_ratio) == (1024, 128, 0.1)
+    assert c.graph.connectivity == "8-connected" and c.graph.edge_features == ["distance", "depth_difference", "slope"]
+    assert (c.model.gnn_type, c.model.gnn_hidden_channels, c.model.gnn_num_layers, c.model.gnn_heads) == ("GAT", 64, 4, 4)
+    assert (c.inference.auto_correct_threshold, c.inference.review_threshold) == (0.85, 0.6)
+    assert (CORRECTION_NORM_FLOOR, CORRECTION_NORM_CAP) == (0.01, 50.0)
+    c.tile.tile_size = 512; c.model.gnn_num_layers = 3; c.training = {"epochs": 7}
+    p = tmp_path / "config.yaml"
+    c.save(p)
+    d = Config.load(p)
+    assert d.tile.tile_size == 512 and d.model.gnn_num_layers == 3 and d.training == {"epochs": 7}
+    with pytest.raises(AssertionError):
+        Config(tile=type(c.tile)(tile_size=100, overlap=80))
+    with pytest.raises(AssertionError):
+        Config(graph=type(c.graph)(connectivity="6-connected"))
+
+
+def test_state_dict_keys_match_reference_names():
+    m = BathymetricGNN(in_channels=7, edge_dim=3)
+    keys = set(m.state_dict().keys())
+    ref = set(synthetic.synthetic_state_dict().keys())
+    assert keys == ref
+    assert m.feature_extractor.mlp[0].in_features == 7          # scripts/inference_native.py:147
+    assert (m.CLASS_SEAFLOOR, m.CLASS_FEATURE, m.CLASS_NOISE) == (0, 1, 2)
+    assert m.gnn.convs[0].lin.weight.shape == (256, 64) and m.gnn.convs[3].lin.weight.shape == (64, 256)
+    assert m.gnn.convs[3].bias.shape == (64,) and m.gnn.norms[0].module.weight.shape == (256,)
+    # older torch_geometric checkpoints (lin_src / lin_dst) load too
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in synthetic.synthetic_state_dict(legacy_lin_src=True).items()})
+    with pytest.raises(NotImplementedError):
+        BathymetricGNN(in_channels=7, gnn_type="GCN", edge_dim=3)
+    with pytest.raises(ValueError):
+        BathymetricGNN(in_channels=7, gnn_type="Transformer", edge_dim=3)
+
+
+def test_pack_weights_order_and_invalidate():
+    sd = synthetic.synthetic_state_dict(seed=3)
+    m = BathymetricGNN(in_channels=7, edge_dim=3)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    blob = m.pack_weights()
+    n0 = sd["feature_extractor.mlp.0.weight"].size
+    assert np.array_equal(blob[:n0], sd["feature_extractor.mlp.0.weight"].ravel())
+    tail = sd["correction_head.mlp.3.bias"]
+    assert np.array_equal(blob[-tail.size:], tail.ravel())
+    v0 = m._weights_version()
+    with torch.no_grad():
+        m.gnn.convs[0].bias.add_(1.0)
+    assert m._weights_version() != v0                           # native handle would be rebuilt
+
+
+def test_checkpoint_loading_paths(tmp_path, monkeypatch):
+    """load_model accepts the trainer's dict layout (training/trainer.py:809-829) and finds the model
+    hyper-parameters under 'model_config' (models/pipeline.py:108) -- exercised up to set_model."""
+    from bathymetric_gnn_amd.models import pipeline as pl
+    sd = {k: torch.as_tensor(v) for k, v in synthetic.synthetic_state_dict(in_channels=8, num_layers=3, seed=1).items()}
+    path = tmp_path / "best_model.pt"
+    torch.save({"epoch": 3, "model_state_dict": sd, "in_channels": 8, "edge_dim": 3,
+                "model_config": {"gnn_hidden_channels": 64, "gnn_num_layers": 3, "gnn_type": "GAT", "gnn_heads": 4,
+                                 "num_classes": 3, "predict_correction": True}}, path)
+    captured = {}
+    p = pl.BathymetricPipeline.__new__(pl.BathymetricPipeline)
+    p.config = Config()
+    monkeypatch.setattr(pl.BathymetricPipeline, "set_model", lambda self, m: captured.setdefault("m", m))
+    p.load_model(path)
+    assert captured["m"].in_channels == 8 and captured["m"].num_gnn_layers == 3
+    with pytest.raises(FileNotFoundError):
+        p.load_model(tmp_path / "missing.pt")
+
+
+def test_apply_results_arithmetic():
+    from bathymetric_gnn_amd.scripts.inference_native import apply_results
+    depth = np.array([[10.0, 11.0], [12.0, 1.0e6]], np.float32)
+    unc = np.full((2, 2), 0.5, np.float32)
+    cls = np.array([[2, 2], [1, 2]], np.float32)
+    conf = np.array([[0.85, 0.5], [0.9, 0.99]], np.float32)
+    corr = np.full((2, 2), 0.25, np.float32)
+    valid = depth != 1.0e6
+    applied = apply_results(depth, unc, cls, conf, corr, valid, 0.85)
+    assert applied.tolist() == [[True, False], [False, False]]      # >= threshold, noise, valid (:480-503)
+    assert depth[0, 0] == np.float32(9.75) and unc[0, 0] == np.float32(0.5 * (2 - 0.85))
+    assert depth[1, 1] == np.float32(1.0e6)
