@@ -623,4 +623,123 @@ int launch_results_to_grids(bgnn_graph *g, const int64_t *cls, const float *conf
   return BGNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// generic graphs: a PyG `Data` built elsewhere (x, edge_index, edge_attr).  CSR by target with every
+// row in ascending edge-id order -- the order torch_geometric's scatter sums in -- and self loops
+// dropped, as GATConv does (remove_self_loops before add_self_loops(fill_value='mean')).
+// ------------------------------------------------------------------------------------------
+struct DegValue {
+  const int32_t *deg;
+  __device__ int operator()(int64_t i) const { return deg[i]; }
+};
+
+__global__ void generic_pad_x_kernel(const float *x, int F, int64_t n, float *x8) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 8) return;
+  const int64_t r = i >> 3;
+  const int c = (int)(i & 7);
+  x8[i] = c < F ? x[r * F + c] : 0.0f;
+}
+
+__global__ void generic_degree_kernel(const int64_t *ei, int64_t E, int64_t N, int32_t *deg) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = ei[e], t = ei[E + e];
+  if (s != t && s >= 0 && s < N && t >= 0 && t < N) atomicAdd(deg + t, 1);
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_rowptr_kernel(DegValue val, int64_t n, const int32_t *block_off,
+                                                                         int32_t *rowptr) {
+  int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+  int v[SCAN_PER_THREAD];
+  int p = block_off[blockIdx.x] + block_exclusive(val, n, base, v);
+#pragma unroll
+  for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+    if (base + j < n) {
+      rowptr[base + j] = p;
+      p += v[j];
+      if (base + j == n - 1) rowptr[n] = p;
+    }
+  }
+}
+
+__global__ void generic_fill_kernel(const int64_t *ei, int64_t E, int64_t N, const int32_t *rowptr, int32_t *cursor,
+                                    int32_t *col, int32_t *eid) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = ei[e], t = ei[E + e];
+  if (s != t && s >= 0 && s < N && t >= 0 && t < N) {
+    const int pos = rowptr[t] + atomicAdd(cursor + t, 1);
+    col[pos] = (int32_t)s;
+    eid[pos] = (int32_t)e;
+  }
+}
+
+// one thread per row: order the row by edge id (insertion sort; rows are short), then gather the attributes
+__global__ void generic_sort_rows_kernel(int64_t N, const int32_t *rowptr, int32_t *col, int32_t *eid) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int b = rowptr[i], e = rowptr[i + 1];
+  for (int p = b + 1; p < e; ++p) {
+    const int ke = eid[p], kc = col[p];
+    int q = p - 1;
+    while (q >= b && eid[q] > ke) { eid[q + 1] = eid[q]; col[q + 1] = col[q]; --q; }
+    eid[q + 1] = ke; col[q + 1] = kc;
+  }
+}
+
+__global__ void generic_gather_attr_kernel(const int32_t *eid, int64_t nnz_cap, const int32_t *rowptr, int64_t N,
+                                           const float *edge_attr, int ED, float *out) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz_cap || p >= rowptr[N]) return;
+  const int64_t e = eid[p];
+  for (int f = 0; f < ED; ++f) out[p * ED + f] = edge_attr[e * ED + f];
+}
+
+int launch_generic_build(bgnn_ctx *ctx, bgnn_graph *g, int64_t n_nodes, int32_t n_feat, const float *x, int64_t n_edges,
+                         const int64_t *edge_index, int32_t edge_dim, const float *edge_attr) {
+  DevPool &P = ctx->pool;
+  const int64_t N = n_nodes, E = n_edges;
+  int rc = BGNN_OK;
+#define GALLOC(ptr, type, count) if (rc == BGNN_OK) { void *_p = nullptr; rc = P.alloc((size_t)((count) > 0 ? (count) : 1) * sizeof(type), &_p); ptr = (type *)_p; }
+  GALLOC(g->d_counts, int64_t, 4)
+  GALLOC(g->d_x8, float, N * 8)
+  GALLOC(g->d_rowptr, int32_t, N + 1)
+  GALLOC(g->d_nbr, int32_t, E)
+  GALLOC(g->d_edge_perm, int32_t, E)
+  GALLOC(g->d_eattr, float, E * edge_dim)
+#undef GALLOC
+  BGNN_TRY(rc);
+  const int64_t counts[4] = {N, E, 0, 0};
+  BGNN_TRY(ctx_upload(ctx, counts, sizeof(counts), g->d_counts));
+  if (N == 0) return BGNN_OK;
+  void *wsp;
+  BGNN_TRY(ctx_workspace(ctx, 4, (size_t)N * 2 * sizeof(int32_t), &wsp));
+  int32_t *deg = (int32_t *)wsp, *cursor = deg + N;
+  BGNN_HIP_CHECK(hipMemsetAsync(deg, 0, (size_t)N * 2 * sizeof(int32_t), ctx->stream));
+  BGNN_HIP_CHECK(hipMemsetAsync(g->d_rowptr, 0, (size_t)(N + 1) * sizeof(int32_t), ctx->stream));
+  ProfScope ps(ctx, BGNN_K_FEATURES);
+  hipLaunchKernelGGL(generic_pad_x_kernel, dim3((unsigned)((N * 8 + 255) / 256)), dim3(256), 0, ctx->stream, x, n_feat, N,
+                     g->d_x8);
+  if (E > 0) {
+    const unsigned eb = (unsigned)((E + 255) / 256);
+    hipLaunchKernelGGL(generic_degree_kernel, dim3(eb), dim3(256), 0, ctx->stream, edge_index, E, N, deg);
+    DegValue dv{deg};
+    int32_t *block_off;
+    BGNN_TRY(run_scan_counts(ctx, dv, N, &block_off, g->d_counts + 2));
+    const int n_blocks = (int)((N + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(scan_apply_rowptr_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, dv, N, block_off,
+                       g->d_rowptr);
+    hipLaunchKernelGGL(generic_fill_kernel, dim3(eb), dim3(256), 0, ctx->stream, edge_index, E, N, g->d_rowptr, cursor,
+                       g->d_nbr, g->d_edge_perm);
+    hipLaunchKernelGGL(generic_sort_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, N,
+                       g->d_rowptr, g->d_nbr, g->d_edge_perm);
+    hipLaunchKernelGGL(generic_gather_attr_kernel, dim3(eb), dim3(256), 0, ctx->stream, g->d_edge_perm, E, g->d_rowptr, N,
+                       edge_attr, edge_dim, g->d_eattr);
+  }
+  BGNN_HIP_CHECK(hipGetLastError());
+  BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the caller may free x / edge_index / edge_attr afterwards
+  return BGNN_OK;
+}
+
 }  // namespace bgnn
