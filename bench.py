@@ -48,7 +48,24 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
     gemm_flops += 2 * hidden * nh * (hidden // 2)
     gemm_bytes += 4 * (hidden + nh * (hidden // 2))
     build_bytes = 5 + 28 + 4 + 4 * deg * edge_dim                   # native-internal graph form (133 B)
-    return {"aggregate_bytes": agg_bytes, "gemm_flops": gemm_flops, "gemm_bytes": gemm_bytes, "build_bytes": build_bytes}
+    # fused path: launch l = aggregate of layer l + GEMM of layer l+1 (last: + heads + grid scatter);
+    # the front GEMMs (feature extractor + lin of layer 0) stay separate
+    fused_flops, fused_bytes = 0, 0
+    front_flops = 2 * (in_ch * hidden + hidden * hidden + hidden * (hidden * (heads if num_layers > 1 else 1)))
+    for l in range(num_layers):
+        last = l == num_layers - 1
+        H = 1 if last else heads
+        hc = H * hidden
+        if not last:
+            Hn = 1 if l + 1 == num_layers - 1 else heads
+            nc = Hn * hidden
+            fused_flops += 2 * hc * nc
+            fused_bytes += 4 * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * nc + 4 * 2 * Hn
+        else:
+            fused_flops += 2 * hidden * nh * (hidden // 2)
+            fused_bytes += 4 * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * 3
+    return {"aggregate_bytes": agg_bytes, "gemm_flops": gemm_flops, "gemm_bytes": gemm_bytes, "build_bytes": build_bytes,
+            "fused_flops": fused_flops, "fused_bytes": fused_bytes, "front_flops": front_flops}
 
 
 def cpu_baseline(n_tiles, tile, sd, seed0):
@@ -85,9 +102,13 @@ def main():
     ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="run K3 / K4 / K5 / K6 as separate kernels (standalone gather-aggregate roofline)")
     ap.add_argument("--cpu-tiles", type=int, default=4)
     args = ap.parse_args()
 
+    if args.unfused:
+        os.environ["BGNN_NO_FUSED"] = "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,29 +180,42 @@ def main():
         for k, v in prof.items():
             if v["launches"]:
                 kernels[k] = {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps}
-        agg_s = prof["aggregate"]["ms"] / 1e3
-        gemm_s = prof["gemm"]["ms"] / 1e3
         n_local = nodes_per_step * args.steps
-        agg = {"kernel": "gat_aggregate_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-               "achieved": am["aggregate_bytes"] * n_local / agg_s / 1e9 if agg_s > 0 else None,
-               "avg_launch_ms": prof["aggregate"]["ms"] / max(prof["aggregate"]["launches"], 1),
-               "algorithmic_bytes_per_node_per_forward": am["aggregate_bytes"], "traffic": None}
-        gem = {"kernel": "gemm_f32_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
-               "achieved": am["gemm_flops"] * n_local / gemm_s / 1e12 if gemm_s > 0 else None,
-               "avg_launch_ms": prof["gemm"]["ms"] / max(prof["gemm"]["launches"], 1),
-               "algorithmic_flops_per_node_per_forward": am["gemm_flops"], "traffic": None}
-        for r in (agg, gem):
-            r["frac"] = r["achieved"] / r["peak"] if r["achieved"] else None
+        def roof(kernel, key, bound, work_per_node, note):
+            t = prof[key]["ms"] / 1e3
+            if t <= 0:
+                return None
+            unit, peak, scale = ("GB/s", HBM_PEAK_GBS, 1e9) if bound == "hbm" else ("TFLOP/s", MFMA_F32_PEAK_TFLOPS, 1e12)
+            ach = work_per_node * n_local / t / scale
+            return {"kernel": kernel, "bound": bound, "unit": unit, "peak": peak, "achieved": ach, "frac": ach / peak,
+                    "avg_launch_ms": prof[key]["ms"] / max(prof[key]["launches"], 1),
+                    "launches_per_step": prof[key]["launches"] / args.steps,
+                    "algorithmic_work_per_node_per_forward": work_per_node, "traffic": None, "note": note}
+        roofs = {}
+        if prof["fused"]["launches"]:
+            roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma", am["fused_flops"],
+                                       "K4 gather-softmax-aggregate fused with the next layer's exact-f32 MFMA GEMM (last: heads + scatter)")
+            roofs["fused_hbm"] = roof("gat_layer_fused_kernel", "fused", "hbm", am["fused_bytes"],
+                                      "same launches priced by compulsory HBM bytes (read xW + attrs, write next xW)")
+            roofs["front_gemm"] = roof("gemm_f32_kernel", "gemm", "mfma", am["front_flops"], "feature extractor + lin of layer 0")
+        else:
+            roofs["aggregate_hbm"] = roof("gat_aggregate_tiled_kernel", "aggregate", "hbm", am["aggregate_bytes"],
+                                          "standalone K4 (LDS-tiled gather-softmax-aggregate + BN + ReLU)")
+            roofs["gemm_mfma"] = roof("gemm_f32_kernel", "gemm", "mfma", am["gemm_flops"], "all K3 GEMMs, exact f32 MFMA")
+        roofs = {k: v for k, v in roofs.items() if v}
         # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach if present
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 t = json.load(open(pmc))
-                agg["traffic"] = t.get("gat_aggregate_kernel", {}).get("bytes_per_launch")
-                gem["traffic"] = t.get("gemm_f32_kernel", {}).get("bytes_per_launch")
+                for v in roofs.values():
+                    v["traffic"] = t.get(v["kernel"], {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        dominant = agg if agg_s >= gemm_s else gem
+        if "fused_mfma" in roofs:
+            dominant = roofs["fused_mfma"]
+        else:
+            dominant = max(roofs.values(), key=lambda v: v["avg_launch_ms"] * v["launches_per_step"])
         line = {
             "metric": "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,7 +226,7 @@ def main():
                        "tiles_per_gpu": B, "tile": S, "nodes_per_step_per_gpu": nodes_per_step,
                        "parallelism": f"tile-sharded x{world}, no collective"},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")},
-            "roofline_aggregate": agg, "roofline_gemm": gem, "kernels": kernels,
+            "rooflines": roofs, "kernels": kernels, "path": "unfused" if args.unfused else "fused",
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
