@@ -27,6 +27,9 @@ OFFSETS = {  # graph_construction.py:78-87
     "4-connected": [(-1, 0), (1, 0), (0, -1), (0, 1)],
     "8-connected": [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)],
 }
+# NOT in the reference (BASELINE config 3 "k=16" has no counterpart there): the build-side
+# dilated extension = the 8 base offsets followed by the same offsets x2.  No golden vectors can exist.
+OFFSETS["16-dilated"] = OFFSETS["8-connected"] + [(2 * r, 2 * c) for r, c in OFFSETS["8-connected"]]
 
 
 @dataclass

@@ -270,3 +270,16 @@ def test_foreign_data_generic_graph(gpu_device):
                              edge_attr=torch.from_numpy(ea).cuda()))
     ref = gat_cpu.predict(sd, x, ei, ea)
     _compare(out, ref)
+
+
+def test_k16_dilated_extension(gpu_device):
+    """connectivity='16-dilated' (BASELINE config 3's "k=16"; not in the reference, no golden vectors): same
+    formulas on a dilated stencil.  Checked against the oracle's identical extension only."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(40, 36, 8, "V1")
+    g = GraphBuilder(connectivity="16-dilated").build_graph(d, m, None, (0.5, 0.5))
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5), connectivity="16-dilated")
+    assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
+    sd = synthetic.synthetic_state_dict(seed=1234)
+    _compare(_model(sd).predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
