@@ -159,7 +159,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     }
     c->owns_stream = true;
   }
-  if (hipMalloc((void **)&c->zero_page, 8192) != hipSuccess || hipMemset(c->zero_page, 0, 8192) != hipSuccess) {
+  if (hipMalloc((void **)&c->zero_page, 16384) != hipSuccess || hipMemset(c->zero_page, 0, 16384) != hipSuccess) {
     set_error("zero page allocation failed");
     delete c;
     return BGNN_ERR_NOMEM;

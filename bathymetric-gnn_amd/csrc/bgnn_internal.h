@@ -83,7 +83,7 @@ struct bgnn_ctx {
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
   int num_cus = 256;
-  float *zero_page = nullptr;   // 4 KiB of zeros
+  float *zero_page = nullptr;   // 16 KiB: [0,4K) zeros, [4K,4K+128) diagnostic counters, [8K,16K) dump rows
   unsigned long long *stamps = nullptr;   // 16 diagnostic counters (inside the zero page allocation)
 };
 

@@ -46,6 +46,7 @@ struct FusedArgs {
   const float *shift;
   const float *Wt;        // [HC][NC] next stage weight (transposed)
   const float *zero_page; // >= 16 B of zeros (source of halo rows that have no node)
+  float *dump;            // >= 1 KiB scratch row: stores of rows that have no node land here (keeps the epilogue branch-free)
   int ED, relu, dbg;
   unsigned long long *stamps;   // diagnostic build only (BGNN_FUSED_STAMPS): per-phase cycle sums
   // EPI_NEXT
@@ -345,11 +346,12 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
       // is transposed through a wave-private LDS patch (the slab region is free now) and written out as whole
       // 128-byte row segments, 8 rows per instruction.
       float *patch = slab + wave * (32 * TILED_PITCH);
-      int64_t rid[4];
+      float *prow[4];                                   // output row of patch row (lane>>3) + 8k, column chunk lane&7
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = wave * 32 + (lane >> 3) + 8 * k;
-        rid[k] = hid[(c / TILE_W + 1) * HW_ + c % TILE_W + 1];
+        const int rid = hid[(c / TILE_W + 1) * HW_ + c % TILE_W + 1];
+        prow[k] = (rid >= 0 ? a.out + (int64_t)rid * NC : a.dump) + (lane & 7) * 4;
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -363,11 +365,9 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
           *reinterpret_cast<float4 *>(patch + r * TILED_PITCH + 8 * g + 4 * hl) = v;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 v = *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
-          if (rid[k] >= 0 && !(a.dbg & 16))
-            *reinterpret_cast<float4 *>(a.out + rid[k] * NC + t * 32 + (lane & 7) * 4) = v;
-        }
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<float4 *>(prow[k] + t * 32) =
+              *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
       }
 #pragma unroll
       for (int hd = 0; hd < H2; ++hd) {
@@ -496,7 +496,7 @@ static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, i
   a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items3;
   a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
   a.node_id = g->d_node_id; a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
-  a.ED = ED; a.relu = relu; a.zero_page = g->ctx->zero_page;
+  a.ED = ED; a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
   { const char *e = getenv("BGNN_FUSED_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.stamps = getenv("BGNN_FUSED_STAMPS") ? g->ctx->stamps : nullptr;
 }

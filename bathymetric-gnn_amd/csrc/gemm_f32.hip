@@ -35,6 +35,7 @@ struct GemmArgs {
   const float *att_src;   // [NC] or nullptr
   const float *att_dst;   // [NC]
   float *asd;             // [M][2H]
+  float *dump;            // >= 1 KiB scratch row for rows >= M (branch-free stores)
   int ldx, ldy, K, relu, H, C;
 };
 
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int rr = (lane >> 3) + 8 * k;
-        const float4 v = *reinterpret_cast<const float4 *>(patch + rr * 36 + (lane & 7) * 4);
-        if (wrow0 + rr < M) *reinterpret_cast<float4 *>(a.Y + (wrow0 + rr) * a.ldy + t * 32 + (lane & 7) * 4) = v;
+        float *dst = (wrow0 + rr < M ? a.Y + (wrow0 + rr) * a.ldy : a.dump) + t * 32 + (lane & 7) * 4;
+        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(patch + rr * 36 + (lane & 7) * 4);
       }
     }
   }
@@ -183,7 +184,7 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
-  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ldx, ldy, K, relu, H, C};
+  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C};
   dim3 grid((unsigned)((max_rows + 127) / 128)), block(256);
 #define BGNN_GEMM_CASE(NT)                                                                         \
   case NT:                                                                                         \
