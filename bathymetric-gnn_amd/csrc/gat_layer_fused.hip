@@ -314,7 +314,12 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
       BGNN_STAMP(5)   // wait for W + barrier
       if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
       // rank-32 update of the wave's [32 nodes x NC] accumulator
+      // Two workgroups share each SIMD's matrix pipe.  Giving every other workgroup a higher priority while it
+      // multiplies breaks the symmetry: when both reach their MFMA phase together the favoured one takes the pipe,
+      // finishes first and gathers while the other multiplies -- the two settle into opposite phases.
+      if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(2);
       if (!(a.dbg & 2)) MfmaGroups<NT, 0>::run(acc, g, wbuf0);
+      __builtin_amdgcn_s_setprio(0);
       BGNN_STAMP(6)   // slab DMA issue + MFMA
       if (s + 1 < NSLAB) {
         wait_lgkm0();
