@@ -20,6 +20,7 @@
 // Reference semantics: models/gnn.py:173-188 (conv -> norm -> relu), :392-406 (heads),
 // :427-449 (predict), models/pipeline.py:278-307 (grids); GATConv per SURVEY Appendix B.
 #include <stdlib.h>
+#include <algorithm>
 #include "gat_tile_common.h"
 
 namespace bgnn {
@@ -96,9 +97,8 @@ __device__ __forceinline__ void lds_reads_done() {
 // MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
 // (+ 4*hl, folded into the base address).  The W fragments of group M+1 are requested before the MFMAs of
 // group M are issued, so their LDS latency hides under the matrix pipe.
-template <int NT, int M>
+template <int NT, int NC, int M>
 struct MfmaGroups {
-  static constexpr int NC = NT * 32;
   static constexpr int ROW = 8 * (M / 2) + 2 * (M & 1);
   __device__ static __forceinline__ void load(float (&wa)[NT], float (&wb)[NT], uint32_t wbuf0) {
 #pragma unroll
@@ -116,12 +116,12 @@ struct MfmaGroups {
                                              float (&wb)[NT]) {
     lds_reads_done();
     float na[NT], nb[NT];
-    if constexpr (M + 1 < 8) MfmaGroups<NT, M + 1>::load(na, nb, wbuf0);
+    if constexpr (M + 1 < 8) MfmaGroups<NT, NC, M + 1>::load(na, nb, wbuf0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], acc[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t], g[M / 2][2 * (M & 1) + 1], acc[t], 0, 0, 0);
-    if constexpr (M + 1 < 8) MfmaGroups<NT, M + 1>::step(acc, g, wbuf0, na, nb);
+    if constexpr (M + 1 < 8) MfmaGroups<NT, NC, M + 1>::step(acc, g, wbuf0, na, nb);
   }
 };
 
@@ -131,15 +131,16 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NT>
+template <int NT, int NW = 4>
 __device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k0, int wave, int lane) {
-  // rows k0..k0+31 of Wt[.][NC]: 32*NC contiguous floats = NT*4 pieces of 1 KiB, 4 waves
+  // rows k0..k0+31 of Wt[.][NC]: 32*NC contiguous floats = NT*4 pieces of 1 KiB over NW waves
   constexpr int NC = NT * 32;
   const char *src = reinterpret_cast<const char *>(Wt + (int64_t)k0 * NC);
   constexpr int NQ = NT * 4;
+  static_assert(NQ % NW == 0, "every wave issues the same number of pieces (counted vmcnt waits rely on it)");
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int q = j * 4 + wave;
+  for (int j = 0; j < NQ / NW; ++j) {
+    const int q = j * NW + wave;
     if (q < NQ)
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void *)(dst + q * 256), 16, 0, 0);
@@ -149,15 +150,19 @@ __device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k
 constexpr int FT_H = 8;                                  // fused kernel: 8 x 16 cell blocks
 constexpr int FHR = (FT_H + 2) * HALO_W;                 // 180 halo rows
 
-template <int HC, int C, int K, int NT, int EPI>
-__global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
-  // 4 waves; wave w owns cells 32w..32w+31 (two tile rows).  Lane (r, hl): node r of the wave, k-half hl.
-  // TWO workgroups per CU (2 waves per SIMD, 256 registers each): while one runs its MFMA phase the other
-  // gathers / waits for its DMA, so the matrix pipe stays fed without hand interleaving.
+template <int HC, int C, int K, int NT, int EPI, int NS>
+__global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(FusedArgs a) {
+  // 4*NS waves, two workgroups per CU.  Wave w: node group ng = w & 3 (cells 32ng..32ng+31, two tile rows) and,
+  // for NS = 2, column half nh = w >> 2 of the NC output channels.  Lane (r, hl): node r of the group, k-half hl.
+  // NS = 2 halves the accumulator (64 registers) so that 16 waves fit a CU: the two waves of a node group each
+  // gather the same B operands (cheap) and multiply them into their own half of the columns.  More resident
+  // waves = more of the per-workgroup latency chains (halo ids, alpha, DMA waits, epilogue) hidden under MFMAs.
+  constexpr int NTH = 256 * NS, NTL = NT / NS;
   constexpr int H = HC / C;
   constexpr int NC = NT * 32;
   constexpr int NSLAB = HC / 32, SPH = C / 32;
   constexpr int HR = FHR, HW_ = HALO_W;
+  static_assert(NS == 1 || EPI == EPI_NEXT, "column split is built for the layer -> layer form only");
   using Off = StencilOffsets<K>;
   extern __shared__ __attribute__((aligned(128))) float lds[];
   float *slab = lds;                                   // [HR][32]  halo rows of the current slab, 16-B chunks XOR-swizzled
@@ -171,20 +176,21 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
   const BlockPos pos = decode_block<FT_H>(a.tb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ng = wave & 3, nh = wave >> 2;
   const int r = lane & 31, hl = lane >> 5;
-  const int cell = wave * 32 + r;                      // block-local cell of this lane (both halves)
+  const int cell = ng * 32 + r;                        // block-local cell of this lane
   const int tr = cell / TILE_W, tc = cell % TILE_W;
   const int self_idx = (tr + 1) * HW_ + tc + 1;
 
   if (tid == 0) *minid = 0x7fffffff;
   // rows without a node are never written by the DMA: zero them once
-  for (int i = tid; i < HR * 8; i += 256) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  load_halo_ids<H, 256, HR>(pos, a.node_id, a.asd, hid, has);
-  for (int i = tid; i < HC; i += 256) { scsh[i] = a.scale[i]; scsh[HC + i] = a.shift[i]; }
+  for (int i = tid; i < HR * 8; i += NTH) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  load_halo_ids<H, NTH, HR>(pos, a.node_id, a.asd, hid, has);
+  for (int i = tid; i < HC; i += NTH) { scsh[i] = a.scale[i]; scsh[HC + i] = a.shift[i]; }
   __syncthreads();
   {
     int m = 0x7fffffff;
-    for (int i = tid; i < HR; i += 256) { const int v = hid[i]; if (v >= 0 && v < m) m = v; }
+    for (int i = tid; i < HR; i += NTH) { const int v = hid[i]; if (v >= 0 && v < m) m = v; }
     if (m != 0x7fffffff) atomicMin(minid, m);
   }
   __syncthreads();
@@ -195,11 +201,11 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk
   // p ^ ((row >> 1) & 7).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
   // offsets (relative to node id0, 32 bits) are computed once.
-  constexpr int NPIECE = (HR * 8 + 255) / 256;
+  constexpr int NPIECE = (HR * 8 + NTH - 1) / NTH;
   uint32_t doff[NPIECE];
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) {
-    const int idx = p * 256 + tid;
+    const int idx = p * NTH + tid;
     doff[p] = 0xffffffffu;
     if (idx < HR * 8) {
       const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
@@ -214,51 +220,37 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
     for (int p = 0; p < NPIECE; ++p) {
       if (doff[p] != 0xffffffffu)
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(sb + doff[p]),
-                                         (__attribute__((address_space(3))) void *)(slab + (p * 256 + wave * 64) * 4), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
     }
   };
   issue_slab(0);
-  stage_w_chunk<NT>(a.Wt, wbuf, 0, wave, lane);
+  stage_w_chunk<NT, 4 * NS>(a.Wt, wbuf, 0, wave, lane);
   BGNN_STAMP(1)   // DMA offsets + first issue
 
-  // ---- phase A: attention coefficients of this lane's cell -> LDS; the two lane halves split the heads ----
+  // ---- phase A: attention coefficients -> LDS.  The 2*NS lanes that share a cell (lane halves x column halves)
+  // take the heads round-robin.
   {
     const int my = (a.dbg & 32) ? -1 : hid[self_idx];
-    if constexpr (H >= 2) {
-      constexpr int NH = H / 2;
-      float part[(K + 1) * NH];
-#pragma unroll
-      for (int i = 0; i < (K + 1) * NH; ++i) part[i] = 0.0f;
-      if (my >= 0) {
-        if (hl == 0) attention_coefficients<H, K, 0, NH>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, part);
-        else attention_coefficients<H, K, H / 2, NH>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, part);
-      }
-#pragma unroll
-      for (int k = 0; k < NH; ++k)
-#pragma unroll
-        for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + (hl * NH + k) * (K + 1) + b] = part[b * NH + k];
-    } else {
+    for (int hh = nh * 2 + hl; hh < H; hh += 2 * NS) {
       float part[K + 1];
 #pragma unroll
       for (int i = 0; i <= K; ++i) part[i] = 0.0f;
-      if (hl == 0) {
-        if (my >= 0) attention_coefficients<H, K, 0, 1>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, part);
+      if (my >= 0) attention_coefficients_head<H, K>(my, self_idx, hh, hid, has, a.asd, a.eattr, a.V, a.ED, part);
 #pragma unroll
-        for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + b] = part[b];
-      }
+      for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + hh * (K + 1) + b] = part[b];
     }
-    // (both halves of a cell sit in the same wave: no barrier needed beyond the one at the top of the slab loop)
+    // (consumers wait at the barrier at the top of the slab loop)
   }
 
   BGNN_STAMP(2)   // phase A
-  f32x16 acc[NT];
+  f32x16 acc[NTL];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NTL; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
   const uint32_t slab0 = lds_addr(slab);
-  const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r);
+  const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + nh * NTL * 32 + r);
   const uint32_t scsh0 = lds_addr(scsh) + hl * 16;
   const uint32_t alx0 = lds_addr(alx + cell * TILED_PITCH);
 
@@ -267,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   {
 #pragma unroll 1
     for (int s = 0; s < NSLAB; ++s) {
-      // VM queue order per wave: [slab s pieces] [NT pieces of W chunk s]: vmcnt(NT) = "slab landed, W may fly"
-      wait_vm_lgkm<NT>();
+      // VM queue order per wave: [slab s pieces] [NTL pieces of W chunk s]: vmcnt(NTL) = "slab landed, W may fly"
+      wait_vm_lgkm<NTL>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
@@ -313,27 +305,23 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
       __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s; W chunk s landed
       BGNN_STAMP(5)   // wait for W + barrier
       if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
-      // rank-32 update of the wave's [32 nodes x NC] accumulator
-      // Two workgroups share each SIMD's matrix pipe.  Giving every other workgroup a higher priority while it
-      // multiplies breaks the symmetry: when both reach their MFMA phase together the favoured one takes the pipe,
-      // finishes first and gathers while the other multiplies -- the two settle into opposite phases.
-      if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(2);
-      if (!(a.dbg & 2)) MfmaGroups<NT, 0>::run(acc, g, wbuf0);
-      __builtin_amdgcn_s_setprio(0);
+      // rank-32 update of the wave's [32 nodes x NTL*32] accumulator
+      if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 0>::run(acc, g, wbuf0);
       BGNN_STAMP(6)   // slab DMA issue + MFMA
       if (s + 1 < NSLAB) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                   // every wave is done with W chunk s
-        if (!(a.dbg & 8)) stage_w_chunk<NT>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
+        if (!(a.dbg & 8)) stage_w_chunk<NT, 4 * NS>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
         BGNN_STAMP(7)   // barrier + W DMA issue
       }
     }
   }
 
   // ---- epilogue: lane (r, hl) holds node `cell`; reg i of tile t -> channel t*32 + 8*(i>>2) + 4*hl + (i&3) ----
-  if (EPI == EPI_NEXT) {
+  float *attl = wbuf + 32 * NC - 2 * NC;                // att_src | att_dst, parked at the END of wbuf: the store
+  if (EPI == EPI_NEXT) {                                 // patches below grow from the slab into the start of wbuf
     __syncthreads();                                    // every wave is done with wbuf
-    for (int i = tid; i < NC; i += 256) { wbuf[i] = a.att_src[i]; wbuf[NC + i] = a.att_dst[i]; }
+    for (int i = tid; i < NC; i += NTH) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
     __syncthreads();
   }
   if (!(a.dbg & 64)) {
@@ -342,11 +330,12 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
     if (EPI == EPI_NEXT) {
       // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32).
       // att_src / att_dst were staged into LDS (wbuf is free now): no global-load latency chain here.
-      constexpr int TPH = C / 32, H2 = NT / TPH;
-      float ps[H2], pd[H2];
+      constexpr int TPH = C / 32, H2 = NT / TPH, H2L = NTL / TPH > 0 ? NTL / TPH : 1;
+      static_assert(EPI != EPI_NEXT || NTL % TPH == 0, "a wave column share must hold whole heads");
+      float ps[H2L], pd[H2L];
 #pragma unroll
-      for (int hd = 0; hd < H2; ++hd) { ps[hd] = 0.0f; pd[hd] = 0.0f; }
-      const float *asl = wbuf + 4 * hl, *adl = wbuf + NC + 4 * hl;
+      for (int hd = 0; hd < H2L; ++hd) { ps[hd] = 0.0f; pd[hd] = 0.0f; }
+      const float *asl = attl + nh * NTL * 32 + 4 * hl, *adl = attl + NC + nh * NTL * 32 + 4 * hl;
       // Row-per-lane stores (32 rows x 32 B per instruction) are store-issue bound; instead each 32x32 tile
       // is transposed through a wave-private LDS patch (the slab region is free now) and written out as whole
       // 128-byte row segments, 8 rows per instruction.
@@ -354,12 +343,12 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
       float *prow[4];                                   // output row of patch row (lane>>3) + 8k, column chunk lane&7
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int c = wave * 32 + (lane >> 3) + 8 * k;
+        const int c = ng * 32 + (lane >> 3) + 8 * k;
         const int rid = hid[(c / TILE_W + 1) * HW_ + c % TILE_W + 1];
-        prow[k] = (rid >= 0 ? a.out + (int64_t)rid * NC : a.dump) + (lane & 7) * 4;
+        prow[k] = (rid >= 0 ? a.out + (int64_t)rid * NC : a.dump) + nh * NTL * 32 + (lane & 7) * 4;
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NTL; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 s4 = *reinterpret_cast<const float4 *>(asl + t * 32 + 8 * g);
@@ -375,12 +364,12 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
               *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
       }
 #pragma unroll
-      for (int hd = 0; hd < H2; ++hd) {
+      for (int hd = 0; hd < H2L; ++hd) {
         const float s_ = ps[hd] + __shfl_xor(ps[hd], 32);
         const float d_ = pd[hd] + __shfl_xor(pd[hd], 32);
         if (id >= 0 && hl == 0) {
-          a.asd_out[(int64_t)id * 2 * H2 + hd] = s_;
-          a.asd_out[(int64_t)id * 2 * H2 + H2 + hd] = d_;
+          a.asd_out[(int64_t)id * 2 * H2 + nh * H2L + hd] = s_;
+          a.asd_out[(int64_t)id * 2 * H2 + H2 + nh * H2L + hd] = d_;
         }
       }
     } else {
@@ -476,18 +465,20 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fused_kernel(FusedArgs a) {
   if (a.stamps && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
 }
 
-template <int HC, int C, int K, int NT, int EPI>
+template <int HC, int C, int K, int NT, int EPI, int NS = 1>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr int H = HC / C;
   constexpr size_t lds_bytes = (size_t)(FHR * 32 + 32 * NT * 32 + 2 * HC + FHR + FHR * H + 4 + 128 * TILED_PITCH) * 4;
   static bool configured = false;     // per instantiation
-  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI>;
+  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS>;
+  size_t lds_launch = lds_bytes;
+  if (const char *e = getenv("BGNN_FUSED_LDS_PAD")) lds_launch = std::max(lds_bytes, (size_t)atoi(e) * 1024);   // occupancy experiment
   if (!configured) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes));
+                                       (int)std::max(lds_launch, lds_bytes)));
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tb.n_blocks), dim3(256), lds_bytes, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.tb.n_blocks), dim3(256 * NS), lds_launch, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;
 }
@@ -517,10 +508,14 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   a.Wt = Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
   ProfScope ps(ctx, BGNN_K_FUSED);
-#define BGNN_FUSED_CASE(hc, nt)                                                                         \
+#define BGNN_FUSED_CASE(hc, nt, ns)                                                                     \
   if (HC == hc && NC == nt * 32)                                                                        \
-    return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT>(ctx, a);
-  BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2) BGNN_FUSED_CASE(128, 4) BGNN_FUSED_CASE(128, 2) BGNN_FUSED_CASE(64, 2)
+    return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, ns>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, ns>(ctx, a);
+  // Column split (16 waves per CU at 128 registers): correct, but hipcc spills inside the gather loop at that
+  // budget and every spill reload waits on the in-flight DMAs -- 1.5x slower than NS = 1 today.  Opt-in only.
+  static const int ns_big = getenv("BGNN_FUSED_SPLIT") ? 2 : 1;
+  if (ns_big == 2) { BGNN_FUSED_CASE(256, 8, 2) }
+  BGNN_FUSED_CASE(256, 8, 1) BGNN_FUSED_CASE(256, 2, 1) BGNN_FUSED_CASE(128, 4, 1) BGNN_FUSED_CASE(128, 2, 1) BGNN_FUSED_CASE(64, 2, 1)
 #undef BGNN_FUSED_CASE
   return BGNN_ERR_UNSUPPORTED;
 }

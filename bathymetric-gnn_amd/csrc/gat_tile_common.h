@@ -162,4 +162,69 @@ __device__ __forceinline__ void attention_coefficients(int my, int self_idx, con
   }
 }
 
+// same as attention_coefficients for ONE head given at run time; out[b], b = 0..K
+template <int H, int K>
+__device__ __forceinline__ void attention_coefficients_head(int my, int self_idx, int hh, const int *hid, const float *has,
+                                                            const float *asd, const float *eattr, const float *V, int ED,
+                                                            float *out) {
+  using Off = StencilOffsets<K>;
+  float v[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) v[f] = f < ED ? V[hh * ED + f] : 0.0f;
+  const float ad = asd[(int64_t)my * 2 * H + H + hh];
+  float ea_sum[4] = {0.f, 0.f, 0.f, 0.f};
+  int deg = 0;
+  float mx = -__builtin_inff();
+  float lg[K + 1];
+  bool present[K];
+  const bool vec = (ED == 3 && (K * 3) % 4 == 0);
+  float eraw[K * 4];
+  if (vec) {
+    const float4 *ep = reinterpret_cast<const float4 *>(eattr + (int64_t)my * K * 3);
+#pragma unroll
+    for (int i = 0; i < K * 3 / 4; ++i) {
+      const float4 q = ep[i];
+      eraw[4 * i] = q.x; eraw[4 * i + 1] = q.y; eraw[4 * i + 2] = q.z; eraw[4 * i + 3] = q.w;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    const int nidx = self_idx - Off::dr[b] * HALO_W - Off::dc[b];
+    present[b] = hid[nidx] >= 0;
+    float dot = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float e = 0.0f;
+      if (f < ED && present[b]) e = vec ? eraw[(b * 3 + f) & (K * 4 - 1)] : eattr[((int64_t)my * K + b) * ED + f];
+      ea_sum[f] += e;
+      dot += e * v[f];
+    }
+    float x = has[nidx * H + hh] + ad + dot;
+    x = x > 0.0f ? x : 0.2f * x;
+    lg[b] = x;
+    if (present[b]) { mx = fmaxf(mx, x); ++deg; }
+  }
+  {
+    const float cnt = (float)(deg > 0 ? deg : 1);
+    float dot = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dot += (ea_sum[f] / cnt) * v[f];
+    float x = has[self_idx * H + hh] + ad + dot;
+    x = x > 0.0f ? x : 0.2f * x;
+    lg[K] = x;
+    mx = fmaxf(mx, x);
+  }
+  float den = 0.0f;
+#pragma unroll
+  for (int b = 0; b <= K; ++b) {
+    const bool on = b == K ? true : present[b];
+    const float pe = on ? expf(lg[b] - mx) : 0.0f;
+    lg[b] = pe;
+    den += pe;
+  }
+  den += 1e-16f;
+#pragma unroll
+  for (int b = 0; b <= K; ++b) out[b] = lg[b] / den;
+}
+
 }  // namespace bgnn
