@@ -97,7 +97,7 @@ __device__ __forceinline__ void lds_reads_done() {
 // MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
 // (+ 4*hl, folded into the base address).  The W fragments of group M+1 are requested before the MFMAs of
 // group M are issued, so their LDS latency hides under the matrix pipe.
-template <int NT, int NC, int M>
+template <int NT, int NC, int M, int END = 8>
 struct MfmaGroups {
   static constexpr int ROW = 8 * (M / 2) + 2 * (M & 1);
   __device__ static __forceinline__ void load(float (&wa)[NT], float (&wb)[NT], uint32_t wbuf0) {
@@ -116,12 +116,12 @@ struct MfmaGroups {
                                              float (&wb)[NT]) {
     lds_reads_done();
     float na[NT], nb[NT];
-    if constexpr (M + 1 < 8) MfmaGroups<NT, NC, M + 1>::load(na, nb, wbuf0);
+    if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::load(na, nb, wbuf0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], acc[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t], g[M / 2][2 * (M & 1) + 1], acc[t], 0, 0, 0);
-    if constexpr (M + 1 < 8) MfmaGroups<NT, NC, M + 1>::step(acc, g, wbuf0, na, nb);
+    if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::step(acc, g, wbuf0, na, nb);
   }
 };
 
@@ -131,15 +131,14 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NT, int NW = 4>
+template <int NT, int NW = 4, int ROWS = 32>
 __device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k0, int wave, int lane) {
-  // rows k0..k0+31 of Wt[.][NC]: 32*NC contiguous floats = NT*4 pieces of 1 KiB over NW waves
+  // rows k0..k0+ROWS-1 of Wt[.][NC]: ROWS*NC contiguous floats = ROWS*NT/8 pieces of 1 KiB over NW waves
   constexpr int NC = NT * 32;
   const char *src = reinterpret_cast<const char *>(Wt + (int64_t)k0 * NC);
-  constexpr int NQ = NT * 4;
-  static_assert(NQ % NW == 0, "every wave issues the same number of pieces (counted vmcnt waits rely on it)");
+  constexpr int NQ = ROWS * NT / 8;
 #pragma unroll
-  for (int j = 0; j < NQ / NW; ++j) {
+  for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
     const int q = j * NW + wave;
     if (q < NQ)
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
@@ -224,7 +223,8 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
     }
   };
   issue_slab(0);
-  stage_w_chunk<NT, 4 * NS>(a.Wt, wbuf, 0, wave, lane);
+  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, 0, wave, lane);
+  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, 16, wave, lane);
   BGNN_STAMP(1)   // DMA offsets + first issue
 
   // ---- phase A: attention coefficients -> LDS.  The 2*NS lanes that share a cell (lane halves x column halves)
@@ -259,8 +259,12 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
   {
 #pragma unroll 1
     for (int s = 0; s < NSLAB; ++s) {
-      // VM queue order per wave: [slab s pieces] [NTL pieces of W chunk s]: vmcnt(NTL) = "slab landed, W may fly"
-      wait_vm_lgkm<NTL>();
+      // VM queue order per wave: [slab s] [W rows 0-15 of slab s: WA] [W rows 16-31: WB] [slab s+1] [WA s+1] ...
+      // WA / WB are NTL/2 pieces per wave each (unconditional); slab pieces are exec-masked, so they are never
+      // counted on: a wait that must cover a W half uses only the W pieces issued after it.
+      constexpr int WH = (16 * NT / 8) / (4 * NS);       // pieces per wave in one W half
+      // (when the pieces do not divide evenly some waves issue one more: the floor only makes their wait conservative)
+      wait_vm_lgkm<2 * WH>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
@@ -301,23 +305,26 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
         }
       }
       BGNN_STAMP(4)   // gather + layer epilogue
-      wait_vm_lgkm<0>();
-      __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s; W chunk s landed
-      BGNN_STAMP(5)   // wait for W + barrier
+      wait_vm_lgkm<WH>();                               // WA(s) landed (WB(s) may still fly)
+      __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
+      BGNN_STAMP(5)   // wait for WA + barrier
       if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
-      // rank-32 update of the wave's [32 nodes x NTL*32] accumulator
-      if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 0>::run(acc, g, wbuf0);
-      BGNN_STAMP(6)   // slab DMA issue + MFMA
+      // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
+      if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
+      wait_vm_lgkm<0>();                                // WB(s) landed (and, conservatively, slab s+1)
+      __builtin_amdgcn_s_barrier();                     // every wave is done with W rows 0-15
+      if (s + 1 < NSLAB && !(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
+      if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
+      BGNN_STAMP(6)   // MFMA
       if (s + 1 < NSLAB) {
         wait_lgkm0();
-        __builtin_amdgcn_s_barrier();                   // every wave is done with W chunk s
-        if (!(a.dbg & 8)) stage_w_chunk<NT, 4 * NS>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
-        BGNN_STAMP(7)   // barrier + W DMA issue
+        __builtin_amdgcn_s_barrier();                   // every wave is done with W rows 16-31
+        if (!(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, (s + 1) * 32 + 16, wave, lane);
+        BGNN_STAMP(7)   // barrier + WB DMA issue
       }
     }
   }
 
-  // ---- epilogue: lane (r, hl) holds node `cell`; reg i of tile t -> channel t*32 + 8*(i>>2) + 4*hl + (i&3) ----
   float *attl = wbuf + 32 * NC - 2 * NC;                // att_src | att_dst, parked at the END of wbuf: the store
   if (EPI == EPI_NEXT) {                                 // patches below grow from the slab into the start of wbuf
     __syncthreads();                                    // every wave is done with wbuf

@@ -105,6 +105,11 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="run K3 / K4 / K5 / K6 as separate kernels (standalone gather-aggregate roofline)")
     ap.add_argument("--cpu-tiles", type=int, default=4)
+    ap.add_argument("--workload", default="tiles", choices=["tiles", "vr"],
+                    help="tiles: B uniform tiles per step (headline). vr: BASELINE config 4 -- a stream of 4096 ragged "
+                         "refinement grids (3x3..50x50, in=8) packed by the reference's 50 000-node batch budget")
+    ap.add_argument("--vr-grids", type=int, default=4096)
+    ap.add_argument("--vr-budget", type=int, default=50000)
     args = ap.parse_args()
 
     if args.unfused:
@@ -127,28 +132,53 @@ def main():
     from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
 
     B, S = args.tiles, args.tile_size
-    sd = synthetic.synthetic_state_dict(in_channels=7, num_layers=args.layers, seed=1234)
-    model = BathymetricGNN(in_channels=7, num_gnn_layers=args.layers, edge_dim=3, dropout=0.0)
+    in_ch = 8 if args.workload == "vr" else 7
+    sd = synthetic.synthetic_state_dict(in_channels=in_ch, num_layers=args.layers, seed=1234)
+    model = BathymetricGNN(in_channels=in_ch, num_gnn_layers=args.layers, edge_dim=3, dropout=0.0)
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     model.to(dev).eval()
     gb = GraphBuilder(device=dev)
     eng = TileBatchEngine(model, gb, dev)
     ctx = eng.ctx
-
-    # synthetic batch, resident in HBM before the timed region (a few distinct tiles, tiled to B)
-    n_distinct = min(B, 8)
-    depth, mask, _ = synthetic.synthetic_tile_batch(n_distinct, S, S, 100 + 1000 * rank, args.variant)
-    reps = (B + n_distinct - 1) // n_distinct
-    depth = np.concatenate([depth] * reps)[:B]; mask = np.concatenate([mask] * reps)[:B]
-    d_t = torch.from_numpy(depth).to(dev).reshape(-1)
-    m_t = torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
-    hw = np.tile(np.array([[S, S]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
-    out = torch.empty((3, d_t.numel()), dtype=torch.float32, device=dev)
     nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    nodes_per_step = int(mask.sum())
 
-    def step():
-        eng.infer_device(hw, res, d_t, m_t, None, out=out, n_nodes_out=nn_dev)
+    if args.workload == "tiles":
+        # synthetic batch, resident in HBM before the timed region (a few distinct tiles, tiled to B)
+        n_distinct = min(B, 8)
+        depth, mask, _ = synthetic.synthetic_tile_batch(n_distinct, S, S, 100 + 1000 * rank, args.variant)
+        reps = (B + n_distinct - 1) // n_distinct
+        depth = np.concatenate([depth] * reps)[:B]; mask = np.concatenate([mask] * reps)[:B]
+        d_t = torch.from_numpy(depth).to(dev).reshape(-1)
+        m_t = torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
+        hw = np.tile(np.array([[S, S]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
+        out = torch.empty((3, d_t.numel()), dtype=torch.float32, device=dev)
+        nodes_per_step = int(mask.sum())
+        workload_name = (f"{B} tiles of {S}x{S} per GPU per step, 8-connected (k=8), {args.layers}-layer GAT "
+                         f"(hidden 64, heads 4), mask {args.variant}, inputs resident in HBM")
+
+        def step():
+            eng.infer_device(hw, res, d_t, m_t, None, out=out, n_nodes_out=nn_dev)
+    else:
+        # config 4: ragged refinement grids, packed greedily in stream order until the node budget is reached
+        grids = synthetic.vr_grid_stream(args.vr_grids, seed0=1000 + 100000 * rank)
+        batches, cur, cur_nodes, nodes_per_step = [], [], 0, 0
+        for d, u, r in grids:
+            m = (d != synthetic.NODATA) & np.isfinite(d)
+            cur.append((d, m, u, r)); cur_nodes += int(m.sum())
+            if cur_nodes >= args.vr_budget:
+                batches.append(cur); nodes_per_step += cur_nodes; cur, cur_nodes = [], 0
+        if cur:
+            batches.append(cur); nodes_per_step += cur_nodes
+        dev_batches = []
+        for b in batches:
+            hw_b, res_b, d_b, m_b, u_b = gb.upload_tiles([x[0] for x in b], [x[1] for x in b], [x[2] for x in b], [x[3] for x in b])
+            dev_batches.append((hw_b, res_b, d_b, m_b, u_b, torch.empty((3, d_b.numel()), dtype=torch.float32, device=dev)))
+        workload_name = (f"{args.vr_grids} ragged refinement grids (3x3..50x50, in=8) per GPU per step in {len(batches)} batches "
+                         f"of >= {args.vr_budget} nodes, 8-connected, {args.layers}-layer GAT, inputs resident in HBM")
+
+        def step():
+            for hw_b, res_b, d_b, m_b, u_b, o_b in dev_batches:
+                eng.infer_device(hw_b, res_b, d_b, m_b, u_b, out=o_b)
 
     def barrier():
         if dist is not None:
@@ -166,7 +196,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile([])
-    assert int(nn_dev.item()) == nodes_per_step
+    if args.workload == "tiles":
+        assert int(nn_dev.item()) == nodes_per_step
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,14 +252,14 @@ def main():
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B} tiles of {S}x{S} per GPU per step, 8-connected (k=8), {args.layers}-layer GAT "
-                                   f"(hidden 64, heads 4), mask {args.variant}, inputs resident in HBM",
-                       "tiles_per_gpu": B, "tile": S, "nodes_per_step_per_gpu": nodes_per_step,
+            "config": {"workload": workload_name,
+                       "tiles_per_gpu": B if args.workload == "tiles" else args.vr_grids, "tile": S if args.workload == "tiles" else "3..50",
+                       "nodes_per_step_per_gpu": nodes_per_step,
                        "parallelism": f"tile-sharded x{world}, no collective"},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")},
             "rooflines": roofs, "kernels": kernels, "path": "unfused" if args.unfused else "fused",
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
             line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
