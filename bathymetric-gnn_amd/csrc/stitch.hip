@@ -1,0 +1,105 @@
+// Device-side stitching of overlapping tile results into survey grids.
+//
+// Restates TileMerger.add_tile / finalize (reference data/tiling.py:384-454), TileManager.merge_tile /
+// finalize_output (:218-294), the unprocessed-cell preservation of BathymetricPipeline.process
+// (models/pipeline.py:196-207) and _apply_corrections (:316-349) as ONE gather kernel: each survey cell
+// walks the (<= 3 x 3) tiles that cover it in ascending spec order -- the order the reference's serial
+// loop adds them in -- so the float32 blend sums and the strict '>' confidence arbitration come out
+// identical to the host merge.  Compiled with -ffp-contract=off (product rounded, then added, as numpy).
+#include "bgnn_internal.h"
+
+namespace bgnn {
+
+struct StitchArgs {
+  int H, W;
+  int ntr, ntc;                 // tile rows / cols
+  const int32_t *row_start;     // [ntr]
+  const int32_t *row_end;       // [ntr]
+  const int32_t *col_start;     // [ntc]
+  const int32_t *col_end;       // [ntc]
+  const float *roww;            // [ntr][tile]  1-D blend weights of each tile row's extent
+  const float *colw;            // [ntc][tile]
+  int tile;                     // pitch of the two weight tables
+  const int64_t *tile_off;      // [ntr*ntc] offset of the tile's cells in the result arrays; < 0: tile skipped
+  const float *cls, *conf, *corr;   // concatenated per-tile grids (row-major [h][w] each)
+  const float *depth;           // [H][W] survey depth
+  const uint8_t *valid;         // [H][W] survey valid mask
+  float auto_thr;
+  float *o_cls, *o_conf, *o_corr, *o_clean;   // [H][W]
+};
+
+__global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= a.W) return;
+  const float NANF = __builtin_nanf("");
+  float acc_conf = NANF, w_conf = 0.0f, acc_corr = NANF, w_corr = 0.0f;
+  float lab = NANF, tracked = -1.0f;
+  // candidate tile rows / cols: starts are ascending, so scan the few whose extent contains the cell
+  for (int tr = 0; tr < a.ntr; ++tr) {
+    const int rs = a.row_start[tr];
+    if (rs > r) break;
+    if (r >= a.row_end[tr]) continue;
+    for (int tc = 0; tc < a.ntc; ++tc) {
+      const int cs = a.col_start[tc];
+      if (cs > c) break;
+      if (c >= a.col_end[tc]) continue;
+      const int64_t off = a.tile_off[tr * a.ntc + tc];
+      if (off < 0) continue;                                    // tile skipped (min_valid_ratio)
+      const int tw = a.col_end[tc] - cs;
+      const int64_t i = off + (int64_t)(r - rs) * tw + (c - cs);
+      const float w = a.roww[tr * a.tile + (r - rs)] * a.colw[tc * a.tile + (c - cs)];   // np.outer, float32
+      const float vconf = a.conf[i], vcorr = a.corr[i], vcls = a.cls[i];
+      // continuous channels: weighted accumulation (tiling.py:242-258)
+      if (vconf == vconf && fabsf(vconf) != __builtin_inff()) {
+        if (acc_conf != acc_conf) acc_conf = 0.0f;
+        w_conf = w_conf + w;
+        acc_conf = acc_conf + vconf * w;
+      }
+      if (vcorr == vcorr && fabsf(vcorr) != __builtin_inff()) {
+        if (acc_corr != acc_corr) acc_corr = 0.0f;
+        w_corr = w_corr + w;
+        acc_corr = acc_corr + vcorr * w;
+      }
+      // discrete channel: the tile with the higher confidence wins; first writer always (tiling.py:408-420)
+      if (vcls == vcls && fabsf(vcls) != __builtin_inff()) {
+        if (vconf > tracked || lab != lab) { lab = vcls; tracked = vconf; }
+      }
+    }
+  }
+  if (w_conf > 0.0f) acc_conf = acc_conf / w_conf;              // finalize_output (tiling.py:289-292)
+  if (w_corr > 0.0f) acc_corr = acc_corr / w_corr;
+  const int64_t o = (int64_t)r * a.W + c;
+  const bool valid = a.valid[o] != 0;
+  if (valid && lab != lab) { lab = 0.0f; acc_conf = 0.0f; acc_corr = 0.0f; }   // pipeline.py:198-207
+  const float d = a.depth[o];
+  float clean = d;
+  if (lab == 2.0f && acc_conf > a.auto_thr && valid) clean = d - acc_corr;      // pipeline.py:337-342
+  a.o_cls[o] = lab; a.o_conf[o] = acc_conf; a.o_corr[o] = acc_corr; a.o_clean[o] = clean;
+}
+
+}  // namespace bgnn
+
+using namespace bgnn;
+
+extern "C" int bgnn_stitch_tiles(bgnn_ctx *ctx, int32_t height, int32_t width, int32_t n_tile_rows, int32_t n_tile_cols,
+                                 const int32_t *row_start, const int32_t *row_end, const int32_t *col_start,
+                                 const int32_t *col_end, const float *row_weights, const float *col_weights,
+                                 int32_t weight_pitch, const int64_t *tile_offsets, const float *classification,
+                                 const float *confidence, const float *correction, const float *depth,
+                                 const uint8_t *valid_mask, float auto_correct_threshold, float *out_classification,
+                                 float *out_confidence, float *out_correction, float *out_cleaned_depth) {
+  BGNN_REQUIRE(ctx && row_start && row_end && col_start && col_end && row_weights && col_weights && tile_offsets &&
+                   classification && confidence && correction && depth && valid_mask && out_classification &&
+                   out_confidence && out_correction && out_cleaned_depth,
+               "bgnn_stitch_tiles: NULL argument");
+  BGNN_REQUIRE(height > 0 && width > 0 && n_tile_rows > 0 && n_tile_cols > 0 && weight_pitch > 0, "bgnn_stitch_tiles: bad sizes");
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  StitchArgs a{height, width, n_tile_rows, n_tile_cols, row_start, row_end, col_start, col_end, row_weights, col_weights,
+               weight_pitch, tile_offsets, classification, confidence, correction, depth, valid_mask,
+               auto_correct_threshold, out_classification, out_confidence, out_correction, out_cleaned_depth};
+  ProfScope ps(ctx, BGNN_K_SCATTER);
+  hipLaunchKernelGGL(stitch_kernel, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, a);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}

@@ -62,8 +62,8 @@ class TileBatchEngine:
         self.norm_floor = norm_floor
 
     def infer_device(self, hw: np.ndarray, res: np.ndarray, depth_t: torch.Tensor, mask_t: torch.Tensor,
-                     unc_t: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
-                     n_nodes_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     unc_t: Optional[torch.Tensor], out=None,
+                     n_nodes_out: Optional[torch.Tensor] = None):
         """Device-resident tiles in, device-resident grids out: returns float32 [3, cells]
         (classification, confidence, correction), same cell layout as ``depth_t``.  Asynchronous
         with respect to the host."""
@@ -71,6 +71,8 @@ class TileBatchEngine:
         cells = depth_t.numel()
         if out is None:
             out = torch.empty((3, cells), dtype=torch.float32, device=ctx.device)
+        # `out`: a [3, cells] tensor, or three 1-D [cells] tensors (classification, confidence, correction)
+        assert all(o.is_contiguous() and o.numel() == cells for o in (out[0], out[1], out[2]))
         tiles, keep = rt.make_tiles(hw, res, depth_t, mask_t, unc_t)
         model_h = self.model.native(ctx)
         ctx.begin()
@@ -115,6 +117,7 @@ class BathymetricPipeline:
                                           edge_features=config.graph.edge_features)
         self.model: Optional[BathymetricGNN] = None
         self._engine: Optional[TileBatchEngine] = None
+        self.host_stitch = False      # True: numpy TileMerger on the host even on one GPU (the multi-rank path)
         if config.device != "cuda" or not torch.cuda.is_available():
             raise rt.BgnnError(f"config.device={config.device!r}: this pipeline runs on an MI355X only "
                                "(there is no CPU fallback)")
@@ -178,6 +181,75 @@ class BathymetricPipeline:
         return self._process_tiles([tile], grid)[0]
 
     # ---- whole grid ----------------------------------------------------------------------------
+    def process_grid_device(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
+        """Single-GPU survey path with everything between the two PCIe crossings on the device: the survey is
+        uploaded once, tiles are cut and batched on the GPU, classified by the fused engine into three long
+        result arrays, and stitched / post-processed by ``bgnn_stitch_tiles``.  Same results as the host merge
+        (``process_grid`` under torch.distributed uses that one), bit for bit."""
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        import ctypes as C
+        eng, ctx, dev = self._engine, self._engine.ctx, self._engine.ctx.device
+        tm = self.tile_manager
+        H, W = grid.shape
+        ntr, ntc, specs = tm.compute_tile_grid(grid.shape)
+        depth_np = np.ascontiguousarray(grid.depth, dtype=np.float32)
+        valid_np = grid.valid_mask
+        depth_t = torch.from_numpy(depth_np).to(dev)
+        valid_t = torch.from_numpy(valid_np.view(np.uint8)).to(dev)
+        use_unc = self.model.in_channels == 8 and grid.uncertainty is not None
+        unc_t = torch.from_numpy(np.ascontiguousarray(grid.uncertainty, dtype=np.float32)).to(dev) if use_unc else None
+        # per-tile valid ratio from an integral image (exact integer counts), same float64 test as iterate_tiles
+        ii = torch.zeros((H + 1, W + 1), dtype=torch.int64, device=dev)
+        ii[1:, 1:] = torch.cumsum(torch.cumsum(valid_t.to(torch.int64), 0), 1)
+        sa = np.array([[s.row_start, s.col_start, s.row_end, s.col_end] for s in specs], np.int64)
+        st = torch.from_numpy(sa).to(dev)
+        cnt = (ii[st[:, 2], st[:, 3]] - ii[st[:, 0], st[:, 3]] - ii[st[:, 2], st[:, 1]] + ii[st[:, 0], st[:, 1]]).cpu().numpy()
+        size = (sa[:, 2] - sa[:, 0]) * (sa[:, 3] - sa[:, 1])
+        keep = ~((cnt / size) < tm.min_valid_ratio)
+        proc = np.nonzero(keep)[0]
+        th, tw = int(sa[0, 2] - sa[0, 0]), int(sa[0, 3] - sa[0, 1])     # every tile has this extent (shift-back rule)
+        assert np.all(size == th * tw)
+        n_proc = len(proc)
+        tile_off = np.full(len(specs), -1, np.int64)
+        tile_off[proc] = np.arange(n_proc, dtype=np.int64) * (th * tw)
+        total = max(n_proc, 1) * th * tw
+        r_cls = torch.empty(total, dtype=torch.float32, device=dev)
+        r_conf = torch.empty(total, dtype=torch.float32, device=dev)
+        r_corr = torch.empty(total, dtype=torch.float32, device=dev)
+        resol = np.array([[float(grid.resolution[0]), float(grid.resolution[1])]], np.float64)
+        for b0 in range(0, n_proc, self.tile_batch):
+            idx = proc[b0:b0 + self.tile_batch]
+            nb = len(idx)
+            d_b = torch.stack([depth_t[sa[i, 0]:sa[i, 2], sa[i, 1]:sa[i, 3]] for i in idx]).reshape(-1)
+            m_b = torch.stack([valid_t[sa[i, 0]:sa[i, 2], sa[i, 1]:sa[i, 3]] for i in idx]).reshape(-1)
+            u_b = torch.stack([unc_t[sa[i, 0]:sa[i, 2], sa[i, 1]:sa[i, 3]] for i in idx]).reshape(-1) if use_unc else None
+            lo, hi = b0 * th * tw, (b0 + nb) * th * tw
+            eng.infer_device(np.tile(np.array([[th, tw]], np.int32), (nb, 1)), np.tile(resol, (nb, 1)), d_b, m_b, u_b,
+                             out=(r_cls[lo:hi], r_conf[lo:hi], r_corr[lo:hi]))
+        # extents and blend windows per tile row / column (numpy, exactly TileManager._create_1d_blend)
+        rs = np.array([specs[i * ntc].row_start for i in range(ntr)], np.int32); re = np.array([specs[i * ntc].row_end for i in range(ntr)], np.int32)
+        cs = np.array([specs[j].col_start for j in range(ntc)], np.int32); ce = np.array([specs[j].col_end for j in range(ntc)], np.int32)
+        pitch = max(th, tw)
+        roww = np.zeros((ntr, pitch), np.float32); colw = np.zeros((ntc, pitch), np.float32)
+        for i in range(ntr):
+            roww[i, :re[i] - rs[i]] = tm._create_1d_blend(int(re[i] - rs[i]))
+        for j in range(ntc):
+            colw[j, :ce[j] - cs[j]] = tm._create_1d_blend(int(ce[j] - cs[j]))
+        dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        rs_t, re_t, cs_t, ce_t, rw_t, cw_t, off_t = dv(rs), dv(re), dv(cs), dv(ce), dv(roww), dv(colw), dv(tile_off)
+        o = torch.empty((4, H, W), dtype=torch.float32, device=dev)
+        ctx.begin()
+        rt.check(ctx.lib.bgnn_stitch_tiles(
+            ctx.handle, H, W, ntr, ntc, rt.ptr(rs_t), rt.ptr(re_t), rt.ptr(cs_t), rt.ptr(ce_t), rt.ptr(rw_t), rt.ptr(cw_t),
+            pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr), rt.ptr(depth_t), rt.ptr(valid_t),
+            C.c_float(self.config.inference.auto_correct_threshold), rt.ptr(o[0]), rt.ptr(o[1]), rt.ptr(o[2]), rt.ptr(o[3])))
+        ctx.end()
+        host = o.cpu().numpy()
+        logger.info(f"Processed {n_proc} tiles ({len(specs) - n_proc} skipped below min_valid_ratio)")
+        return {"cleaned_depth": host[3], "classification": host[0], "confidence": host[1], "correction": host[2],
+                "valid_mask": valid_np.astype(np.float32)}
+
     def process_grid(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
         """The body of ``process`` between load and save (reference :163-211), tiles batched.
 
@@ -189,6 +261,8 @@ class BathymetricPipeline:
         ``>`` tie rule of the discrete channel therefore do not depend on the number of GPUs."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
+        if shard_info()[1] == 1 and getattr(self, "_engine", None) is not None and not getattr(self, "host_stitch", False):
+            return self.process_grid_device(grid)
         _, _, specs = self.tile_manager.compute_tile_grid(grid.shape)
         by_pos = {(s.tile_row, s.tile_col): s for s in specs}
         tiles = list(self.tile_manager.iterate_tiles(grid, skip_empty=True))

@@ -74,6 +74,8 @@ _SIGNATURES = {
     "bgnn_graph_export": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "bgnn_graph_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bgnn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(Outputs)]),
+    "bgnn_stitch_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
+                          [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4),
     "bgnn_infer_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Tiles), C.POINTER(GraphOpts), C.c_float,
                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

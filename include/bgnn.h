@@ -193,6 +193,26 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *model, const bgnn_tiles *tiles,
                      float norm_floor, float *classification, float *confidence, float *correction,
                      int64_t *n_nodes_out);
 
+/* ---- stitching: TileMerger + BathymetricPipeline.process post-steps on the device ------------------
+ * Replaces, for one survey grid [height][width]: TileMerger.add_tile / finalize (data/tiling.py:384-454:
+ * Hann-ramp weighted blend of confidence and correction, confidence-arbitrated classification), the
+ * preservation of valid cells no processed tile covered (models/pipeline.py:196-207: class 0, confidence 0,
+ * correction 0) and _apply_corrections (models/pipeline.py:316-349).  Tiles are visited per cell in
+ * ascending spec order, so results equal the reference's serial host merge bit for bit.
+ *   row_start/row_end [n_tile_rows], col_start/col_end [n_tile_cols]   DEVICE int32 (TileSpec extents)
+ *   row_weights [n_tile_rows][weight_pitch], col_weights [n_tile_cols][weight_pitch]  DEVICE f32: the 1-D
+ *       blend windows of each extent as TileManager._create_1d_blend computes them (host numpy)
+ *   tile_offsets [n_tile_rows*n_tile_cols] DEVICE int64: offset of the tile's cells inside classification /
+ *       confidence / correction (the concatenated outputs of bgnn_infer_tiles); negative = tile was skipped
+ *   outputs [height][width] DEVICE f32; cells no tile covered and that are not valid stay NaN.   Asynchronous. */
+int bgnn_stitch_tiles(bgnn_ctx *ctx, int32_t height, int32_t width, int32_t n_tile_rows, int32_t n_tile_cols,
+                      const int32_t *row_start, const int32_t *row_end, const int32_t *col_start,
+                      const int32_t *col_end, const float *row_weights, const float *col_weights,
+                      int32_t weight_pitch, const int64_t *tile_offsets, const float *classification,
+                      const float *confidence, const float *correction, const float *depth,
+                      const uint8_t *valid_mask, float auto_correct_threshold, float *out_classification,
+                      float *out_confidence, float *out_correction, float *out_cleaned_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,7 +214,12 @@ def test_pipeline_process_grid_matches_oracle(gpu_device):
     with pytest.raises(RuntimeError):
         pipe.process_grid(grid)
     pipe.set_model(_model(sd))
-    res = pipe.process_grid(grid)
+    res = pipe.process_grid(grid)                  # device-side stitch (bgnn_stitch_tiles)
+    pipe.host_stitch = True
+    res_host = pipe.process_grid(grid)             # numpy TileMerger on the same per-tile grids
+    for k in res_host:                             # the two stitchers agree bit for bit
+        assert np.array_equal(np.isnan(res[k]), np.isnan(res_host[k])), k
+        assert np.array_equal(np.nan_to_num(res[k]).view(np.uint32), np.nan_to_num(res_host[k]).view(np.uint32)), k
     # oracle: same tile walk, CPU forward per tile, same merger
     tm = TileManager(64, 16, 0.3)
     _, _, specs = tm.compute_tile_grid(grid.shape)

@@ -25,13 +25,13 @@ pipe = BathymetricPipeline(cfg, tile_batch=args.tile_batch)
 sd = synthetic.synthetic_state_dict(seed=1234)
 m = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
 pipe.set_model(m)
-t_gpu = [0.0]; orig = pipe._process_tiles
-def timed(tiles, g):
-    t0 = time.perf_counter(); out = orig(tiles, g); torch.cuda.synchronize(); t_gpu[0] += time.perf_counter() - t0; return out
-pipe._process_tiles = timed
-t0 = time.perf_counter(); res = pipe.process_grid(grid); dt = time.perf_counter() - t0
 _, _, specs = pipe.tile_manager.compute_tile_grid(grid.shape)
 evals = sum((s.row_end - s.row_start) * (s.col_end - s.col_start) for s in specs)
-print(json.dumps({"survey": f"{S}x{S}", "tiles": len(specs), "node_evals": evals, "valid_cells": int(grid.valid_mask.sum()),
-                  "wall_s": dt, "infer_incl_copies_s": t_gpu[0], "host_tiling_merge_s": dt - t_gpu[0],
-                  "node_evals_per_s_end_to_end": evals / dt, "node_evals_per_s_infer_incl_copies": evals / t_gpu[0]}))
+out = {"survey": f"{S}x{S}", "tiles": len(specs), "node_evals": evals, "valid_cells": int(grid.valid_mask.sum())}
+pipe.process_grid_device(BathymetricGrid(depth=depth[:1024, :1024].copy(), nodata_value=1.0e6, resolution=(0.5, 0.5)))  # warm-up
+for name, host in (("device_stitch", False), ("host_stitch", True)):
+    pipe.host_stitch = host
+    torch.cuda.synchronize(); t0 = time.perf_counter(); res = pipe.process_grid(grid); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out[name] = {"wall_s": dt, "node_evals_per_s": evals / dt}
+print(json.dumps(out))
