@@ -1,21 +1,21 @@
 // Fused GAT layer for stencil graphs (gfx950):  aggregate_l  ->  BN/ReLU  ->  GEMM_{l+1}
 //
 // One workgroup (256 threads = 4 waves; two workgroups per CU) owns an 8x16 block of cells of one tile and
-// produces, for those 256 nodes, what the NEXT stage needs:
+// produces, for those 128 nodes, what the NEXT stage needs:
 //   EPI_NEXT : xw_{l+1} = h_{l+1} @ W_{l+1}^T  and its attention dots (alpha_src, alpha_dst)
 //   EPI_HEADS: the three output heads, softmax / argmax / sigmoid, the predict() flags and
 //              (optionally) the classification / confidence / correction GRIDS of
 //              BathymetricPipeline._process_tile -- i.e. K4(last) + K5 + K6 in one launch.
-// h_{l+1} (the aggregate output, 1 KiB/node) never goes to HBM: per 32-channel slab it is
-// produced by the LDS-tiled gather (as gat_aggregate_tiled.hip), staged in LDS and immediately
-// consumed as the B operand of a rank-32 MFMA update of the block's [256 nodes x NC] accumulator.
-// HBM traffic per layer drops from read xw + write h + read h + write xw' (4.3 KiB/node at
-// HC = 256) to read xw (x1.27 halo) + write xw' (2.3 KiB/node); the kernel is then bound by the
-// exact-f32 matrix pipe.
+// h_{l+1} (the aggregate output, 1 KiB/node) never goes to HBM and never even to LDS: per 32-channel slab
+// each lane gathers -- from the LDS image of the halo rows -- exactly the 16 values it must supply as the
+// MFMA B operand, applies bias + BatchNorm + ReLU in registers and issues a rank-32 update of its wave's
+// [32 nodes x NC] accumulator.  HBM traffic per layer drops from read xw + write h + read h + write xw'
+// (4.3 KiB/node at HC = 256) to read xw (x1.4 halo, mostly L2) + write xw' (2.3 KiB/node); the kernel is
+// then bound by the exact-f32 matrix pipe.
 //
-// Per slab s:   [halo slab regs -> LDS] | barrier | gather+epilogue -> stage | barrier |
-//               issue next halo loads | 2 x 32 x NT MFMAs per wave | barrier | next W chunk (LDS-DMA)
-// so the halo loads of slab s+1 hide under the MFMAs of slab s and the W chunk under its gather.
+// Per slab s:   wait slab | barrier | gather + BN/ReLU in registers | wait W rows 0-15 | barrier | DMA slab s+1 |
+//               16 x NT MFMAs | barrier | DMA W rows 0-15 of slab s+1 | 16 x NT MFMAs | barrier | DMA W rows 16-31
+// so every DMA has at least half a slab of matrix work (plus the next gather) to land.
 //
 // Reference semantics: models/gnn.py:173-188 (conv -> norm -> relu), :392-406 (heads),
 // :427-449 (predict), models/pipeline.py:278-307 (grids); GATConv per SURVEY Appendix B.
