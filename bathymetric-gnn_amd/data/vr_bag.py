@@ -1,0 +1,386 @@
+"""Variable-resolution BAG refinement grids behind an array interface (reference ``data/vr_bag.py``).
+
+The reference reads ``BAG_root/varres_metadata`` and ``BAG_root/varres_refinements`` with h5py and walks the
+base grid in Python (``VRBagHandler.iterate_refinements``, :243-298), writing corrected values back one grid
+at a time (``VRBagWriter.update_refinement_batch``, :550-588).  h5py and GDAL are not part of this path:
+the handlers here work on the two structured arrays themselves (``from_arrays``), which is also what the
+device path (``NativeVRProcessor.process_refinements``) uploads as they are.  Opening a file needs h5py and
+raises ``ImportError`` without it, as the reference does (:118-119); the georeferenced ``SidecarBuilder``
+(GDAL) stays with the reference.
+
+Array formats (BAG 1.6, the fields the reference reads at :262-290):
+  varres_metadata     [rows, cols] records: index u32, dimensions_x u32, dimensions_y u32, resolution_x f32,
+                      resolution_y f32, sw_corner_x f32, sw_corner_y f32
+  varres_refinements  [1, N] records: depth f32, depth_uncrt f32
+"""
+from __future__ import annotations
+
+import logging
+import shutil
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Generator, Optional, Tuple
+
+import numpy as np
+
+try:                                  # pragma: no cover - not installed in this image
+    import h5py
+    H5PY_AVAILABLE = True
+except ImportError:
+    H5PY_AVAILABLE = False
+
+logger = logging.getLogger(__name__)
+
+VARRES_METADATA_DTYPE = np.dtype([("index", "<u4"), ("dimensions_x", "<u4"), ("dimensions_y", "<u4"),
+                                  ("resolution_x", "<f4"), ("resolution_y", "<f4"),
+                                  ("sw_corner_x", "<f4"), ("sw_corner_y", "<f4")])
+VARRES_REFINEMENT_DTYPE = np.dtype([("depth", "<f4"), ("depth_uncrt", "<f4")])
+
+
+@dataclass
+class RefinementGrid:
+    """One refinement grid of a VR BAG (reference :67-97)."""
+    base_row: int
+    base_col: int
+    depth: np.ndarray
+    uncertainty: np.ndarray
+    resolution: Tuple[float, float]      # (x_res, y_res)
+    dimensions: Tuple[int, int]          # (rows, cols)
+    sw_corner: Tuple[float, float]
+    start_index: int                     # into varres_refinements
+
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return self.depth.shape
+
+    @property
+    def valid_mask(self) -> np.ndarray:
+        return (self.depth != 1.0e6) & np.isfinite(self.depth)
+
+    @property
+    def num_valid(self) -> int:
+        return int(np.sum(self.valid_mask))
+
+
+def refinement_table(varres_metadata: np.ndarray):
+    """Flat table of the refined base cells in iteration order (row-major over the base grid, cells with
+    a zero dimension skipped, reference :265-273): dict of 1-D arrays ``base_row, base_col, index, dims_y,
+    dims_x, res_x, res_y, sw_x, sw_y`` plus ``contiguous`` -- True when the grids' record ranges tile
+    ``[index[0], index[0] + total)`` back to back in that order, i.e. the records are already the
+    concatenated tile layout."""
+    md = np.asarray(varres_metadata)
+    dx = md["dimensions_x"].astype(np.int64); dy = md["dimensions_y"].astype(np.int64)
+    rows, cols = np.nonzero((dx != 0) & (dy != 0))
+    sel = md[rows, cols]
+    t = {"base_row": rows, "base_col": cols, "index": sel["index"].astype(np.int64),
+         "dims_y": sel["dimensions_y"].astype(np.int64), "dims_x": sel["dimensions_x"].astype(np.int64),
+         "res_x": sel["resolution_x"], "res_y": sel["resolution_y"],
+         "sw_x": sel["sw_corner_x"], "sw_y": sel["sw_corner_y"]}
+    cells = t["dims_y"] * t["dims_x"]
+    t["cells"] = cells
+    if len(cells):
+        t["contiguous"] = bool(np.all(t["index"][1:] == t["index"][:-1] + cells[:-1]))
+    else:
+        t["contiguous"] = True
+    return t
+
+
+class VRBagHandler:
+    """Iterate refinement grids and hand out writers (reference :100-316)."""
+
+    NODATA = 1.0e6
+    INVALID_INDEX = 4294967295
+
+    def __init__(self, path):
+        if not H5PY_AVAILABLE:
+            raise ImportError("h5py is required for VR BAG handling")
+        self.path = Path(path)                                       # pragma: no cover - needs h5py
+        with h5py.File(str(self.path), "r") as f:                    # pragma: no cover
+            if "BAG_root" not in f:
+                raise ValueError(f"Not a valid BAG file: {self.path}")
+            root = f["BAG_root"]
+            if "varres_refinements" not in root:
+                raise ValueError(f"Not a VR BAG (no varres_refinements): {self.path}")
+            if "varres_metadata" not in root:
+                raise ValueError(f"Not a VR BAG (no varres_metadata): {self.path}")
+            self._init_arrays(root["varres_metadata"][:], root["varres_refinements"][:], root["elevation"].shape)
+        self.geotransform = None; self.crs = None                    # pragma: no cover (GDAL is outside the path)
+
+    @classmethod
+    def from_arrays(cls, varres_metadata: np.ndarray, varres_refinements: np.ndarray, base_shape=None,
+                    geotransform=None, crs=None) -> "VRBagHandler":
+        self = object.__new__(cls)
+        self.path = None
+        self._init_arrays(varres_metadata, varres_refinements, base_shape)
+        self.geotransform = geotransform; self.crs = crs
+        return self
+
+    def _init_arrays(self, varres_metadata, varres_refinements, base_shape):
+        md = np.asarray(varres_metadata)
+        if md.ndim != 2 or md.dtype.names is None or not {"index", "dimensions_x", "dimensions_y", "resolution_x",
+                                                            "resolution_y", "sw_corner_x", "sw_corner_y"} <= set(md.dtype.names):
+            raise ValueError("varres_metadata must be a 2-D structured array with the BAG varres_metadata fields")
+        ref = np.asarray(varres_refinements)
+        if ref.dtype.names is None or not {"depth", "depth_uncrt"} <= set(ref.dtype.names):
+            raise ValueError("varres_refinements must be a structured array with depth / depth_uncrt")
+        if ref.ndim == 1:
+            ref = ref[None, :]
+        if ref.ndim != 2 or ref.shape[0] != 1:
+            raise ValueError("varres_refinements must have shape (1, N)")
+        self.varres_metadata = md
+        self.varres_refinements = ref
+        self.base_shape = tuple(base_shape) if base_shape is not None else md.shape
+        self.min_depth = None; self.max_depth = None
+
+    # ---- summary properties (reference :152-240) ---------------------------------------------------------
+    @property
+    def base_cell_size(self) -> Tuple[float, float]:
+        if self.geotransform:
+            return (abs(self.geotransform[1]), abs(self.geotransform[5]))
+        res_x = self.varres_metadata["resolution_x"]; dims_x = self.varres_metadata["dimensions_x"]
+        valid = dims_x > 0
+        if np.any(valid):
+            m = np.max(res_x[valid] * dims_x[valid])
+            return (float(m), float(m))
+        return (50.0, 50.0)
+
+    @property
+    def finest_resolution(self) -> float:
+        res_x = self.varres_metadata["resolution_x"]
+        valid = res_x > 0
+        return float(np.min(res_x[valid])) if np.any(valid) else 1.0
+
+    @property
+    def bounds(self) -> Tuple[float, float, float, float]:
+        if self.geotransform:
+            gt = self.geotransform
+            min_x, max_y = gt[0], gt[3]
+            return (min_x, max_y + self.base_shape[0] * gt[5], min_x + self.base_shape[1] * gt[1], max_y)
+        return (0, 0, self.base_shape[1] * 50, self.base_shape[0] * 50)
+
+    @property
+    def resampled_shape(self) -> Tuple[int, int]:
+        b, res = self.bounds, self.finest_resolution
+        return (int(np.ceil((b[3] - b[1]) / res)), int(np.ceil((b[2] - b[0]) / res)))
+
+    @property
+    def num_refinement_cells(self) -> int:
+        return int(np.sum(self.varres_metadata["dimensions_x"] > 0))
+
+    @property
+    def total_refinement_nodes(self) -> int:
+        md = self.varres_metadata
+        return int(np.sum(md["dimensions_x"].astype(np.int64) * md["dimensions_y"].astype(np.int64)))
+
+    def get_refinement_info(self) -> Dict:
+        md = self.varres_metadata
+        dx, dy, rx = md["dimensions_x"], md["dimensions_y"], md["resolution_x"]
+        has = dx > 0
+        return {"base_shape": self.base_shape, "num_refined_cells": int(np.sum(has)),
+                "total_refinement_nodes": self.total_refinement_nodes,
+                "unique_dimensions": sorted(set(zip(dx[has].flatten(), dy[has].flatten()))),
+                "unique_resolutions": sorted(set(rx[has].flatten()))}
+
+    def refinement_table(self):
+        return refinement_table(self.varres_metadata)
+
+    # ---- iteration (reference :243-298) -------------------------------------------------------------------
+    def iterate_refinements(self, min_valid_ratio: float = 0.0) -> Generator[RefinementGrid, None, None]:
+        ref = self.varres_refinements[0, :]
+        md = self.varres_metadata
+        for row in range(self.base_shape[0]):
+            for col in range(self.base_shape[1]):
+                meta = md[row, col]
+                dims_x, dims_y = int(meta["dimensions_x"]), int(meta["dimensions_y"])
+                if dims_x == 0 or dims_y == 0:
+                    continue
+                start = int(meta["index"])
+                sl = ref[start:start + dims_x * dims_y]
+                grid = RefinementGrid(
+                    base_row=row, base_col=col,
+                    depth=sl["depth"].reshape(dims_y, dims_x).copy(),
+                    uncertainty=sl["depth_uncrt"].reshape(dims_y, dims_x).copy(),
+                    resolution=(float(meta["resolution_x"]), float(meta["resolution_y"])),
+                    dimensions=(dims_y, dims_x),
+                    sw_corner=(float(meta["sw_corner_x"]), float(meta["sw_corner_y"])),
+                    start_index=start)
+                if grid.num_valid / grid.depth.size >= min_valid_ratio:
+                    yield grid
+
+    def copy_and_open_for_writing(self, output_path=None) -> "VRBagWriter":
+        """File-backed: copy the BAG and open the copy (reference :300-316).  Array-backed (``from_arrays``):
+        a writer over a copy of the refinement records; ``output_path`` is ignored."""
+        if self.path is None:
+            return VRBagWriter.from_arrays(self.varres_refinements.copy(), self.varres_metadata)
+        logger.info(f"Copying VR BAG: {self.path} -> {output_path}")      # pragma: no cover - needs h5py
+        shutil.copy(str(self.path), str(output_path))                     # pragma: no cover
+        return VRBagWriter(output_path)                                   # pragma: no cover
+
+
+class VRBagWriter:
+    """Write corrected refinement values back (reference :478-609)."""
+
+    NODATA = 1.0e6
+
+    def __init__(self, path):
+        if not H5PY_AVAILABLE:
+            raise ImportError("h5py is required for VR BAG handling")
+        self.path = Path(path)                                       # pragma: no cover - needs h5py
+        self._file = h5py.File(str(self.path), "r+")                 # pragma: no cover
+        root = self._file["BAG_root"]                                # pragma: no cover
+        self._refinements = root["varres_refinements"]               # pragma: no cover
+        self._metadata = root["varres_metadata"][:]                  # pragma: no cover
+        self._corrections_applied = 0; self._uncertainty_updates = 0   # pragma: no cover
+
+    @classmethod
+    def from_arrays(cls, varres_refinements: np.ndarray, varres_metadata: Optional[np.ndarray] = None) -> "VRBagWriter":
+        self = object.__new__(cls)
+        self.path = None; self._file = None
+        ref = np.asarray(varres_refinements)
+        self._refinements = ref[None, :] if ref.ndim == 1 else ref
+        self._metadata = varres_metadata
+        self._corrections_applied = 0; self._uncertainty_updates = 0
+        return self
+
+    @property
+    def refinements(self) -> np.ndarray:
+        """The (1, N) record array being modified (array-backed writers)."""
+        return self._refinements
+
+    def _check(self, grid, corrected_depth):
+        if corrected_depth.shape != grid.shape:
+            raise ValueError(f"Shape mismatch: corrected {corrected_depth.shape} vs grid {grid.shape}")
+
+    def update_refinement(self, grid: RefinementGrid, corrected_depth: np.ndarray,
+                          corrected_uncertainty: Optional[np.ndarray] = None):
+        """Reference :502-548 (element-wise writes there; same end state and counters)."""
+        self._check(grid, corrected_depth)
+        s, n = grid.start_index, grid.dimensions[0] * grid.dimensions[1]
+        cur = self._refinements[0, s:s + n]
+        cur["depth"] = corrected_depth.flatten()
+        self._corrections_applied += int(np.sum((corrected_depth != grid.depth) & grid.valid_mask))
+        if corrected_uncertainty is not None:
+            cur["depth_uncrt"] = corrected_uncertainty.flatten()
+            self._uncertainty_updates += int(np.sum((corrected_uncertainty != grid.uncertainty) & grid.valid_mask))
+        self._refinements[0, s:s + n] = cur
+
+    def update_refinement_batch(self, grid: RefinementGrid, corrected_depth: np.ndarray,
+                                corrected_uncertainty: Optional[np.ndarray] = None):
+        """Reference :550-588: read the grid's records, replace depth (and uncertainty), write back."""
+        self._check(grid, corrected_depth)
+        s, n = grid.start_index, grid.dimensions[0] * grid.dimensions[1]
+        cur = self._refinements[0, s:s + n]
+        cur["depth"] = corrected_depth.flatten()
+        if corrected_uncertainty is not None:
+            cur["depth_uncrt"] = corrected_uncertainty.flatten()
+        self._refinements[0, s:s + n] = cur
+        self._corrections_applied += int(np.sum((corrected_depth != grid.depth) & grid.valid_mask))
+
+    def write_records(self, start: int, records: np.ndarray, corrections_applied: int = 0):
+        """Bulk write-back used by the device path: ``records`` (structured or float32 [n, 2]) replace
+        ``varres_refinements[0, start:start+n]`` in one slice assignment."""
+        rec = np.asarray(records)
+        if rec.dtype.names is None:
+            rec = np.ascontiguousarray(rec, dtype=np.float32).reshape(-1, 2).view(VARRES_REFINEMENT_DTYPE).reshape(-1)
+        cur = self._refinements[0, start:start + rec.shape[0]]
+        cur["depth"] = rec["depth"]; cur["depth_uncrt"] = rec["depth_uncrt"]
+        self._refinements[0, start:start + rec.shape[0]] = cur
+        self._corrections_applied += int(corrections_applied)
+
+    def close(self):
+        if self._file is not None:                                   # pragma: no cover - needs h5py
+            self._file.close(); self._file = None
+        logger.info("VR BAG modifications complete:")
+        logger.info(f"  - Depth corrections applied: {self._corrections_applied:,}")
+        if self._uncertainty_updates > 0:
+            logger.info(f"  - Uncertainty updates: {self._uncertainty_updates:,}")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.close()
+        return False
+
+
+class SRBagHandler:
+    """Single-resolution BAG as one "refinement grid" (reference :319-428), array-backed."""
+
+    NODATA = 1.0e6
+
+    def __init__(self, path):
+        if not H5PY_AVAILABLE:
+            raise ImportError("h5py is required for native BAG processing")
+        raise NotImplementedError("file-backed SR BAGs: read elevation / uncertainty with h5py and use from_arrays")  # pragma: no cover
+
+    @classmethod
+    def from_arrays(cls, elevation: np.ndarray, uncertainty: Optional[np.ndarray] = None, resolution: float = 1.0) -> "SRBagHandler":
+        self = object.__new__(cls)
+        self.path = None
+        self._depth = np.asarray(elevation).astype(np.float32)
+        self._uncertainty = (np.asarray(uncertainty).astype(np.float32) if uncertainty is not None
+                             else np.zeros_like(self._depth))
+        self._shape = self._depth.shape
+        self._resolution = float(resolution)
+        return self
+
+    @property
+    def base_shape(self) -> Tuple[int, int]:
+        return self._shape
+
+    def get_refinement_info(self) -> Dict:
+        valid = (self._depth != 1.0e6) & np.isfinite(self._depth)
+        return {"base_shape": self._shape, "num_refined_cells": 1, "total_refinement_nodes": int(np.sum(valid)),
+                "unique_resolutions": [self._resolution]}
+
+    def iterate_refinements(self, min_valid_ratio: float = 0.0) -> Generator[RefinementGrid, None, None]:
+        valid = (self._depth != 1.0e6) & np.isfinite(self._depth)
+        if np.sum(valid) / self._depth.size >= min_valid_ratio:
+            yield RefinementGrid(base_row=0, base_col=0, depth=self._depth.copy(), uncertainty=self._uncertainty.copy(),
+                                 resolution=(self._resolution, self._resolution), dimensions=self._shape,
+                                 sw_corner=(0.0, 0.0), start_index=0)
+
+    def copy_and_open_for_writing(self, output_path=None) -> "SRBagWriter":
+        return SRBagWriter.from_arrays(self._depth.copy(), self._uncertainty.copy())
+
+
+class SRBagWriter:
+    """Reference :431-475: the whole elevation / uncertainty grid is replaced."""
+
+    def __init__(self, path):
+        if not H5PY_AVAILABLE:
+            raise ImportError("h5py is required for native BAG processing")
+        raise NotImplementedError("file-backed SR BAGs: use from_arrays")   # pragma: no cover
+
+    @classmethod
+    def from_arrays(cls, elevation: np.ndarray, uncertainty: Optional[np.ndarray]) -> "SRBagWriter":
+        self = object.__new__(cls)
+        self.elevation = elevation; self.uncertainty = uncertainty
+        return self
+
+    def update_refinement_batch(self, grid, corrected_depth, corrected_uncertainty):
+        self.elevation[:] = corrected_depth
+        if self.uncertainty is not None:
+            self.uncertainty[:] = corrected_uncertainty
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.close()
+        return False
+
+
+def detect_bag_type(path) -> str:
+    """Reference :29-64; needs h5py."""
+    if not H5PY_AVAILABLE:
+        raise ImportError("h5py is required for BAG type detection")
+    with h5py.File(Path(path), "r") as f:                            # pragma: no cover - needs h5py
+        root = f["BAG_root"]
+        if "varres_metadata" in root and "varres_refinements" in root:
+            if np.any(root["varres_metadata"][:]["dimensions_x"] > 0):
+                return "VR"
+        return "SR"

@@ -99,6 +99,95 @@ class NativeVRProcessor:
         items, self._batch, self._batch_node_count = self._batch, [], 0
         return self._run(items)
 
+    # ---- whole-BAG device path (MI355X-first replacement of the main loop, :445-538) ---------------------
+    def process_refinements(self, handler, writer=None, min_valid_ratio: float = 0.0,
+                            cell_budget: int = 8 << 20, return_results: bool = False):
+        """Classify and correct every refinement grid of a VR BAG with the records resident in HBM.
+
+        ``varres_refinements`` is already the concatenated-grid layout ``bgnn_infer_tiles`` consumes
+        (grids row-major, one after another in ``varres_metadata.index`` order), so the records are uploaded
+        as they are, in chunks of about ``cell_budget`` cells cut at grid boundaries (the reference batches
+        50 000 nodes because PyG materialises per-edge tensors; here the bound is HBM).  Per chunk:
+        ``bgnn_vr_unpack`` (planes, valid mask, ``min_valid_ratio`` filter) -> ``bgnn_infer_tiles`` ->
+        ``bgnn_vr_apply`` (the write-back arithmetic of ``apply_results``) -> one D2H of the corrected
+        records into ``writer``.  Returns the statistics the reference's ``main`` logs (:540-559); with
+        ``return_results`` also per-record classification / confidence / correction arrays (what the
+        sidecar builder consumes).  Results equal ``run_refinements`` (the grid-by-grid loop) bit for bit."""
+        import ctypes as C
+        from .. import runtime as rt
+        eng = self._engine
+        ctx, dev = eng.ctx, eng.ctx.device
+        tab = handler.refinement_table()
+        n_grids = len(tab["cells"])
+        stats = {"grids_processed": 0, "cells_processed": 0, "cells_classified_noise": 0, "cells_corrected": 0,
+                 "total_confidence": 0.0, "mean_confidence": 0.0, "grids_skipped": 0}
+        total = int(tab["cells"].sum()) if n_grids else 0
+        res_all = np.zeros((3, total), np.float32) if return_results else None
+        if n_grids == 0:
+            return (stats, res_all) if return_results else stats
+        ref = handler.varres_refinements[0, :]
+        plain = (ref.dtype.itemsize == 8 and ref.dtype.fields["depth"][1] == 0 and ref.dtype.fields["depth_uncrt"][1] == 4
+                 and ref.dtype.fields["depth"][0] == np.dtype("<f4"))
+        start0 = int(tab["index"][0])
+        if tab["contiguous"] and plain:
+            rec_all = np.ascontiguousarray(ref[start0:start0 + total]).view(np.float32).reshape(total, 2)
+            perm = None
+        else:       # records not laid out in iteration order (or foreign record layout): pack on the host once
+            perm = np.concatenate([np.arange(i, i + c, dtype=np.int64) for i, c in zip(tab["index"], tab["cells"])])
+            rec_all = np.empty((total, 2), np.float32)
+            rec_all[:, 0] = ref["depth"][perm]; rec_all[:, 1] = ref["depth_uncrt"][perm]
+        use_unc = self.expected_in_channels != 7
+        off = np.zeros(n_grids + 1, np.int64); np.cumsum(tab["cells"], out=off[1:])
+        hw = np.stack([tab["dims_y"], tab["dims_x"]], 1).astype(np.int32)
+        res = np.stack([tab["res_x"], tab["res_y"]], 1).astype(np.float64)
+        counts_t = torch.zeros(3, dtype=torch.int64, device=dev)
+        csum_t = torch.zeros(1, dtype=torch.float64, device=dev)
+        g0 = 0
+        while g0 < n_grids:
+            g1 = int(np.searchsorted(off, off[g0] + cell_budget, side="right")) - 1
+            g1 = min(max(g1, g0 + 1), n_grids)
+            lo, hi = int(off[g0]), int(off[g1])
+            n = hi - lo
+            rec_t = torch.from_numpy(rec_all[lo:hi]).to(dev)
+            off_t = torch.from_numpy(off[g0:g1 + 1] - lo).to(dev)
+            depth_t = torch.empty(n, dtype=torch.float32, device=dev)
+            unc_t = torch.empty(n, dtype=torch.float32, device=dev) if use_unc else None
+            mask_t = torch.empty(n, dtype=torch.uint8, device=dev)
+            cnt_t = torch.empty(g1 - g0, dtype=torch.int64, device=dev)
+            keep_t = torch.empty(g1 - g0, dtype=torch.uint8, device=dev)
+            ctx.begin()
+            rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(rec_t), n, C.c_float(handler.NODATA), g1 - g0, rt.ptr(off_t),
+                                            C.c_double(min_valid_ratio), rt.ptr(depth_t), rt.ptr(unc_t), rt.ptr(mask_t),
+                                            rt.ptr(cnt_t), rt.ptr(keep_t)))
+            ctx.end()
+            out = eng.infer_device(hw[g0:g1], res[g0:g1], depth_t, mask_t, unc_t)
+            before = counts_t[2].item() if writer is not None else 0
+            ctx.begin()
+            rt.check(ctx.lib.bgnn_vr_apply(ctx.handle, rt.ptr(rec_t), n, rt.ptr(mask_t), rt.ptr(out[0]), rt.ptr(out[1]),
+                                           rt.ptr(out[2]), C.c_float(self.auto_correct_threshold), rt.ptr(counts_t),
+                                           rt.ptr(csum_t)))
+            ctx.end()
+            keep = keep_t.cpu().numpy().astype(bool); cnt = cnt_t.cpu().numpy()
+            stats["grids_processed"] += int(keep.sum()); stats["grids_skipped"] += int((~keep).sum())
+            stats["cells_processed"] += int(cnt[keep].sum())
+            if return_results:
+                res_all[:, lo:hi] = out.cpu().numpy()
+            if writer is not None:
+                rec_np = rec_t.cpu().numpy()
+                changed = counts_t[2].item() - before
+                if perm is None:
+                    writer.write_records(start0 + lo, rec_np, corrections_applied=changed)
+                else:
+                    for g in range(g0, g1):
+                        writer.write_records(int(tab["index"][g]), rec_np[off[g] - lo:off[g + 1] - lo],
+                                             corrections_applied=changed if g == g0 else 0)
+            g0 = g1
+        c = counts_t.cpu().numpy()
+        stats["cells_classified_noise"] = int(c[0]); stats["cells_corrected"] = int(c[1])
+        stats["total_confidence"] = float(csum_t.item())
+        stats["mean_confidence"] = stats["total_confidence"] / stats["cells_processed"] if stats["cells_processed"] else 0
+        return (stats, res_all) if return_results else stats
+
 
 def apply_results(depth: np.ndarray, uncertainty: Optional[np.ndarray], classification: np.ndarray,
                   confidence: np.ndarray, correction: np.ndarray, valid_mask: np.ndarray,
@@ -111,3 +200,53 @@ def apply_results(depth: np.ndarray, uncertainty: Optional[np.ndarray], classifi
     if uncertainty is not None:
         uncertainty[apply] *= (2.0 - confidence[apply])
     return apply
+
+
+def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_ratio: float = 0.0,
+                    auto_correct_threshold: Optional[float] = None, results_sink=None):
+    """The grid-by-grid loop of the reference's ``main`` (:445-538): iterate the refinement grids, queue them
+    with ``add_to_batch``, flush when ``batch_ready``, apply each grid's results (``apply_results`` closure,
+    :480-503) and write it back with ``update_refinement_batch``.  Kept as the API-level mirror and as the
+    statement ``NativeVRProcessor.process_refinements`` (records resident in HBM) is tested against.
+    ``results_sink(grid, classification, confidence, correction)`` stands where the sidecar builder is fed."""
+    thr = processor.auto_correct_threshold if auto_correct_threshold is None else auto_correct_threshold
+    stats = {"grids_processed": 0, "cells_processed": 0, "cells_classified_noise": 0, "cells_corrected": 0,
+             "total_confidence": 0.0}
+    nodata = getattr(handler, "NODATA", 1.0e6)
+    pending = []
+
+    def apply_one(grid, classification, confidence, correction):
+        if results_sink is not None:
+            results_sink(grid, classification, confidence, correction)
+        depth = grid.depth.copy(); unc = grid.uncertainty.copy()
+        noise = (classification == processor.CLASS_NOISE) & grid.valid_mask
+        applied = noise & (confidence >= thr)
+        if np.any(applied):
+            depth[applied] -= correction[applied]
+            stats["cells_corrected"] += int(np.sum(applied))
+            unc[applied] *= 2.0 - confidence[applied]
+        writer.update_refinement_batch(grid, depth, unc)
+        stats["grids_processed"] += 1
+        stats["cells_processed"] += grid.num_valid
+        stats["cells_classified_noise"] += int(np.sum(noise))
+        stats["total_confidence"] += float(np.sum(confidence[grid.valid_mask]))
+
+    def flush():
+        if not pending:
+            return
+        batch = processor.flush_batch()
+        k = 0
+        for grid, immediate in pending:
+            if immediate is not None:
+                apply_one(grid, *immediate)
+            else:
+                apply_one(grid, *batch[k]); k += 1
+        pending.clear()
+
+    for grid in handler.iterate_refinements(min_valid_ratio):
+        pending.append((grid, processor.add_to_batch(grid.depth, grid.uncertainty, grid.resolution, nodata=nodata)))
+        if processor.batch_ready:
+            flush()
+    flush()
+    stats["mean_confidence"] = stats["total_confidence"] / stats["cells_processed"] if stats["cells_processed"] > 0 else 0
+    return stats

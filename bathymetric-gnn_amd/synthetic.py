@@ -74,6 +74,42 @@ def vr_grid_stream(n: int, seed0: int = 1000, lo: int = 3, hi: int = 50):
     return out
 
 
+def synthetic_vr_bag(base_rows: int, base_cols: int, seed: int = 1000, lo: int = 3, hi: int = 50,
+                     refined_fraction: float = 0.85, empty_fraction: float = 0.02, sparse_fraction: float = 0.03):
+    """A synthetic VR BAG as its two HDF5 arrays (``data/vr_bag.py`` formats): ``varres_metadata``
+    [base_rows, base_cols] and ``varres_refinements`` (1, N).  A base cell is refined with probability
+    ``refined_fraction``; its grid is a ``vr_grid_stream`` grid (dims iid on {lo..hi}^2, 3 % nodata), entirely
+    nodata with probability ``empty_fraction`` and 99.5 % nodata with ``sparse_fraction`` (what
+    ``min_valid_ratio`` filters).  Records are laid out in base-grid row-major order, as BAG writers do."""
+    from .data.vr_bag import VARRES_METADATA_DTYPE, VARRES_REFINEMENT_DTYPE
+    rng = np.random.default_rng(seed)
+    md = np.zeros((base_rows, base_cols), VARRES_METADATA_DTYPE)
+    md["index"] = 4294967295
+    recs = []
+    pos = 0
+    k = 0
+    for r in range(base_rows):
+        for c in range(base_cols):
+            if rng.random() >= refined_fraction:
+                continue
+            (d, u, res), = vr_grid_stream(1, seed0=seed + 7919 * (k + 1), lo=lo, hi=hi)
+            k += 1
+            roll = rng.random()
+            if roll < empty_fraction:
+                d = np.full_like(d, np.float32(NODATA))
+            elif roll < empty_fraction + sparse_fraction:
+                keep = rng.random(d.shape) < 0.005
+                d = np.where(keep, d, np.float32(NODATA)).astype(np.float32)
+            h, w = d.shape
+            md[r, c] = (pos, w, h, res[0], res[1], 0.5 * res[0], 0.5 * res[1])
+            rec = np.empty(h * w, VARRES_REFINEMENT_DTYPE)
+            rec["depth"] = d.ravel(); rec["depth_uncrt"] = u.ravel()
+            recs.append(rec)
+            pos += h * w
+    ref = (np.concatenate(recs) if recs else np.empty(0, VARRES_REFINEMENT_DTYPE))[None, :]
+    return md, ref
+
+
 def _glorot(rng, shape, fan_in, fan_out):
     a = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-a, a, size=shape).astype(np.float32)

@@ -213,6 +213,30 @@ int bgnn_stitch_tiles(bgnn_ctx *ctx, int32_t height, int32_t width, int32_t n_ti
                       const uint8_t *valid_mask, float auto_correct_threshold, float *out_classification,
                       float *out_confidence, float *out_correction, float *out_cleaned_depth);
 
+/* ---- VR BAG refinement records (next row (f)3: data/vr_bag.py, scripts/inference_native.py main loop) ----
+ * `records` is BAG_root/varres_refinements[0, :] as float32 pairs {depth, depth_uncrt} (DEVICE, [n_cells][2]):
+ * every refinement grid row-major, grids in varres_metadata.index order (data/vr_bag.py:262-276), i.e. already
+ * the concatenated tile layout of bgnn_tiles.
+ *
+ * bgnn_vr_unpack: depth / uncertainty (may be NULL) planes and the valid mask RefinementGrid.valid_mask defines
+ * (data/vr_bag.py:88-92: depth != nodata and finite).  With a grid table (cell_offsets DEVICE int64
+ * [n_grids + 1]) it also writes valid_count[g] (DEVICE int64) and keep[g] (DEVICE u8) =
+ * valid_count / cells >= min_valid_ratio in float64 (iterate_refinements :293-295) and clears the mask of
+ * dropped grids, so that they come out of bgnn_infer_tiles as zeros and are left untouched by bgnn_vr_apply.
+ *
+ * bgnn_vr_apply: apply_results (scripts/inference_native.py:480-503) on the records, in place: where
+ * classification == 2 (noise), mask and confidence >= auto_correct_threshold: depth -= correction,
+ * depth_uncrt *= (2 - confidence), float32.  counts (DEVICE u64[3], caller zeroes) += {noise & valid cells,
+ * corrected cells, cells whose depth changed (VRBagWriter._corrections_applied, data/vr_bag.py:583-584)};
+ * confidence_sum (DEVICE f64[1]) += sum of confidence over valid cells (the log's mean confidence; summed in
+ * float64, not in numpy's float32 pairwise order).  Both asynchronous. */
+int bgnn_vr_unpack(bgnn_ctx *ctx, const float *records, int64_t n_cells, float nodata, int32_t n_grids,
+                   const int64_t *cell_offsets, double min_valid_ratio, float *depth, float *uncertainty,
+                   uint8_t *mask, int64_t *valid_count, uint8_t *keep);
+int bgnn_vr_apply(bgnn_ctx *ctx, float *records, int64_t n_cells, const uint8_t *mask, const float *classification,
+                  const float *confidence, const float *correction, float auto_correct_threshold, uint64_t *counts,
+                  double *confidence_sum);
+
 #ifdef __cplusplus
 }
 #endif

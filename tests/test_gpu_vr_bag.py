@@ -1,0 +1,142 @@
+"""Whole-BAG device path through the C ABI: NativeVRProcessor.process_refinements (records resident
+in HBM: bgnn_vr_unpack -> bgnn_infer_tiles -> bgnn_vr_apply) against the grid-by-grid loop of the reference's main
+(run_refinements: iterate -> add_to_batch / flush_batch -> apply_results -> update_refinement_batch), and the two
+record kernels against numpy statements of the same arithmetic.  Bit-exact: byte / float32 elementwise work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _processor(in_channels=8, seed=1234, thr=0.85):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor
+    sd = synthetic.synthetic_state_dict(in_channels=in_channels, seed=seed)
+    m = BathymetricGNN(in_channels=in_channels, hidden_channels=64, num_gnn_layers=4, heads=4, edge_dim=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return NativeVRProcessor(m.to(torch.device("cuda:0")).eval(), GraphBuilder(), torch.device("cuda:0"), thr)
+
+
+def test_unpack_and_apply_kernels(gpu_device):
+    from bathymetric_gnn_amd import runtime as rt
+    ctx = rt.get_context(gpu_device)
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 400, size=37); sizes[5] = 3000
+    off = np.zeros(len(sizes) + 1, np.int64); np.cumsum(sizes, out=off[1:])
+    n = int(off[-1])
+    rec = np.empty((n, 2), np.float32)
+    rec[:, 0] = rng.normal(-20, 3, n); rec[:, 1] = rng.uniform(0.05, 0.3, n)
+    rec[rng.random(n) < 0.3, 0] = 1.0e6
+    rec[rng.random(n) < 0.01, 0] = np.nan; rec[rng.random(n) < 0.01, 0] = np.inf; rec[rng.random(n) < 0.01, 0] = -np.inf
+    lo, hi = off[7], off[8]; rec[lo:hi, 0] = 1.0e6                       # an empty grid
+    lo, hi = off[5], off[6]; rec[lo:hi, 0] = 1.0e6; rec[lo + 2, 0] = -3.0  # 1 valid of 3000: below 0.01
+    ratio = 0.01
+    rec_t = torch.from_numpy(rec).to(gpu_device); off_t = torch.from_numpy(off).to(gpu_device)
+    depth_t = torch.empty(n, device=gpu_device); unc_t = torch.empty(n, device=gpu_device)
+    mask_t = torch.empty(n, dtype=torch.uint8, device=gpu_device)
+    cnt_t = torch.empty(len(sizes), dtype=torch.int64, device=gpu_device)
+    keep_t = torch.empty(len(sizes), dtype=torch.uint8, device=gpu_device)
+    ctx.begin()
+    rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(rec_t), n, C.c_float(1.0e6), len(sizes), rt.ptr(off_t),
+                                    C.c_double(ratio), rt.ptr(depth_t), rt.ptr(unc_t), rt.ptr(mask_t), rt.ptr(cnt_t),
+                                    rt.ptr(keep_t)))
+    ctx.end()
+    torch.cuda.synchronize()
+    valid = (rec[:, 0] != np.float32(1.0e6)) & np.isfinite(rec[:, 0])
+    cnt = np.add.reduceat(valid.astype(np.int64), off[:-1])
+    keep = (cnt / sizes) >= ratio
+    assert not keep[5] and not keep[7] and keep.sum() > 30
+    assert np.array_equal(depth_t.cpu().numpy().view(np.uint32), rec[:, 0].view(np.uint32))
+    assert np.array_equal(unc_t.cpu().numpy(), rec[:, 1])
+    assert np.array_equal(cnt_t.cpu().numpy(), cnt) and np.array_equal(keep_t.cpu().numpy().astype(bool), keep)
+    exp_mask = valid & np.repeat(keep, sizes)
+    assert np.array_equal(mask_t.cpu().numpy().astype(bool), exp_mask)
+
+    # apply: numpy statement of scripts/inference_native.py:480-503
+    cls = rng.integers(0, 3, n).astype(np.float32); conf = rng.random(n).astype(np.float32)
+    conf[rng.random(n) < 0.05] = np.float32(0.85)                          # '>=' boundary
+    corr = rng.normal(0, 1, n).astype(np.float32); corr[rng.random(n) < 0.1] = 0.0
+    counts_t = torch.zeros(3, dtype=torch.int64, device=gpu_device); csum_t = torch.zeros(1, dtype=torch.float64, device=gpu_device)
+    t = lambda a: torch.from_numpy(a).to(gpu_device)
+    cls_t, conf_t, corr_t = t(cls), t(conf), t(corr)
+    ctx.begin()
+    rt.check(ctx.lib.bgnn_vr_apply(ctx.handle, rt.ptr(rec_t), n, rt.ptr(mask_t), rt.ptr(cls_t), rt.ptr(conf_t), rt.ptr(corr_t),
+                                   C.c_float(0.85), rt.ptr(counts_t), rt.ptr(csum_t)))
+    ctx.end()
+    torch.cuda.synchronize()
+    noise = (cls == 2) & exp_mask
+    app = noise & (conf >= np.float32(0.85))
+    d = rec[:, 0].copy(); u = rec[:, 1].copy()
+    d[app] -= corr[app]; u[app] *= (2.0 - conf[app])
+    got = rec_t.cpu().numpy()
+    assert np.array_equal(got[:, 0].view(np.uint32), d.view(np.uint32))
+    assert np.array_equal(got[:, 1].view(np.uint32), u.view(np.uint32))
+    c = counts_t.cpu().numpy()
+    assert c[0] == noise.sum() and c[1] == app.sum() and c[2] == ((d != rec[:, 0]) & exp_mask).sum()
+    assert abs(csum_t.item() - conf[exp_mask].astype(np.float64).sum()) < 1e-6
+
+
+@pytest.mark.parametrize("in_channels,ratio,budget", [(8, 0.01, 8 << 20), (7, 0.0, 3000), (8, 0.01, 1)])
+def test_process_refinements_equals_grid_loop(in_channels, ratio, budget, gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import VRBagHandler
+    from bathymetric_gnn_amd.scripts.inference_native import run_refinements
+    proc = _processor(in_channels, thr=0.5)        # lower threshold so that a good share of cells is corrected
+    md, ref = synthetic.synthetic_vr_bag(6, 7, seed=77 + in_channels, lo=3, hi=30, empty_fraction=0.08, sparse_fraction=0.08)
+    h = VRBagHandler.from_arrays(md, ref)
+    # reference-shaped loop
+    w_loop = h.copy_and_open_for_writing()
+    sink = {}
+    proc.BATCH_NODE_BUDGET = 4000
+    st_loop = run_refinements(proc, h, w_loop, ratio, results_sink=lambda g, a, b, c: sink.__setitem__(g.start_index, (a, b, c)))
+    # device path
+    w_dev = h.copy_and_open_for_writing()
+    st_dev, res = proc.process_refinements(h, w_dev, ratio, cell_budget=budget, return_results=True)
+    assert np.array_equal(w_dev.refinements.view(np.uint32), w_loop.refinements.view(np.uint32))
+    assert st_dev["cells_corrected"] == st_loop["cells_corrected"] > 0
+    for k in ("grids_processed", "cells_processed", "cells_classified_noise"):
+        assert st_dev[k] == st_loop[k], k
+    assert st_dev["grids_skipped"] == h.num_refinement_cells - st_loop["grids_processed"]
+    assert (st_dev["grids_skipped"] > 0) == (ratio > 0)
+    assert abs(st_dev["total_confidence"] - st_loop["total_confidence"]) < 1e-3 * max(1.0, st_loop["total_confidence"])
+    assert w_dev._corrections_applied == w_loop._corrections_applied
+    assert np.any(w_dev.refinements["depth"] != ref["depth"]) and np.array_equal(h.varres_refinements, ref)
+    for start, (cls, conf, corr) in sink.items():
+        n = cls.size
+        assert np.array_equal(res[0, start:start + n], cls.ravel())
+        assert np.array_equal(res[1, start:start + n].view(np.uint32), conf.ravel().view(np.uint32))
+        assert np.array_equal(res[2, start:start + n].view(np.uint32), corr.ravel().view(np.uint32))
+
+
+def test_process_refinements_non_contiguous_layout(gpu_device):
+    """Records stored in reverse grid order with gaps: the path packs on the host and writes back per grid."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import VRBagHandler
+    from bathymetric_gnn_amd.data.vr_bag import refinement_table
+    proc = _processor(8, thr=0.5)
+    md, ref = synthetic.synthetic_vr_bag(4, 5, seed=9, lo=3, hi=20)
+    h = VRBagHandler.from_arrays(md, ref)
+    w = h.copy_and_open_for_writing()
+    proc.process_refinements(h, w, 0.01)
+    t = refinement_table(md)
+    md2 = md.copy(); gap = 5
+    total = int(t["cells"].sum()) + gap * len(t["cells"])
+    ref2 = np.zeros((1, total), ref.dtype); ref2["depth"] = 1.0e6
+    pos = total
+    for r, c, i, n in zip(t["base_row"], t["base_col"], t["index"], t["cells"]):
+        pos -= n + gap
+        ref2[0, pos:pos + n] = ref[0, i:i + n]
+        md2[r, c]["index"] = pos
+    h2 = VRBagHandler.from_arrays(md2, ref2)
+    assert not h2.refinement_table()["contiguous"]
+    w2 = h2.copy_and_open_for_writing()
+    proc.process_refinements(h2, w2, 0.01)
+    for r, c, i, n in zip(t["base_row"], t["base_col"], t["index"], t["cells"]):
+        j = int(md2[r, c]["index"])
+        assert np.array_equal(w2.refinements[0, j:j + n], w.refinements[0, i:i + n])
+    assert w2._corrections_applied == w._corrections_applied
