@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import logging
 from pathlib import Path
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -181,35 +181,34 @@ class BathymetricPipeline:
         return self._process_tiles([tile], grid)[0]
 
     # ---- whole grid ----------------------------------------------------------------------------
-    def process_grid_device(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
-        """Single-GPU survey path with everything between the two PCIe crossings on the device: the survey is
-        uploaded once, tiles are cut and batched on the GPU, classified by the fused engine into three long
-        result arrays, and stitched / post-processed by ``bgnn_stitch_tiles``.  Same results as the host merge
-        (``process_grid`` under torch.distributed uses that one), bit for bit."""
+    def process_survey_device(self, depth_t: torch.Tensor, valid_t: torch.Tensor, unc_t: Optional[torch.Tensor],
+                              resolution) -> torch.Tensor:
+        """Survey resident in HBM in, ``[4, H, W]`` float32 device tensor out (classification, confidence,
+        correction, cleaned depth): tiles are cut (``bgnn_cut_tiles``), filtered by ``min_valid_ratio``
+        (``bgnn_tile_valid_counts``), classified batch by batch into three long per-tile result arrays and
+        stitched / post-processed by ``bgnn_stitch_tiles``.  Nothing crosses PCIe in between; sized for one
+        GPU's 288 GB (a 60000 x 60000 survey @512/128 holds 14 GB of depth, 77 GB of per-tile results and
+        58 GB of outputs)."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
-        import ctypes as C
         eng, ctx, dev = self._engine, self._engine.ctx, self._engine.ctx.device
         tm = self.tile_manager
-        H, W = grid.shape
-        ntr, ntc, specs = tm.compute_tile_grid(grid.shape)
-        depth_np = np.ascontiguousarray(grid.depth, dtype=np.float32)
-        valid_np = grid.valid_mask
-        depth_t = torch.from_numpy(depth_np).to(dev)
-        valid_t = torch.from_numpy(valid_np.view(np.uint8)).to(dev)
-        use_unc = self.model.in_channels == 8 and grid.uncertainty is not None
-        unc_t = torch.from_numpy(np.ascontiguousarray(grid.uncertainty, dtype=np.float32)).to(dev) if use_unc else None
-        # per-tile valid ratio from an integral image (exact integer counts), same float64 test as iterate_tiles
-        ii = torch.zeros((H + 1, W + 1), dtype=torch.int64, device=dev)
-        ii[1:, 1:] = torch.cumsum(torch.cumsum(valid_t.to(torch.int64), 0), 1)
+        H, W = (int(v) for v in depth_t.shape)
+        assert depth_t.dtype == torch.float32 and depth_t.is_contiguous() and valid_t.is_contiguous() and valid_t.shape == depth_t.shape
+        valid_u8 = valid_t.view(torch.uint8) if valid_t.dtype == torch.bool else valid_t
+        ntr, ntc, specs = tm.compute_tile_grid((H, W))
         sa = np.array([[s.row_start, s.col_start, s.row_end, s.col_end] for s in specs], np.int64)
-        st = torch.from_numpy(sa).to(dev)
-        cnt = (ii[st[:, 2], st[:, 3]] - ii[st[:, 0], st[:, 3]] - ii[st[:, 2], st[:, 1]] + ii[st[:, 0], st[:, 1]]).cpu().numpy()
-        size = (sa[:, 2] - sa[:, 0]) * (sa[:, 3] - sa[:, 1])
-        keep = ~((cnt / size) < tm.min_valid_ratio)
-        proc = np.nonzero(keep)[0]
         th, tw = int(sa[0, 2] - sa[0, 0]), int(sa[0, 3] - sa[0, 1])     # every tile has this extent (shift-back rule)
+        size = (sa[:, 2] - sa[:, 0]) * (sa[:, 3] - sa[:, 1])
         assert np.all(size == th * tw)
+        org_t = torch.from_numpy(np.ascontiguousarray(sa[:, :2], dtype=np.int32)).to(dev)
+        cnt_t = torch.empty(len(specs), dtype=torch.int64, device=dev)
+        ctx.begin()
+        rt.check(ctx.lib.bgnn_tile_valid_counts(ctx.handle, H, W, rt.ptr(valid_u8), len(specs), rt.ptr(org_t), th, tw, rt.ptr(cnt_t)))
+        ctx.end()
+        cnt = cnt_t.cpu().numpy()
+        keep = ~((cnt / size) < tm.min_valid_ratio)                      # same float64 test as iterate_tiles
+        proc = np.nonzero(keep)[0]
         n_proc = len(proc)
         tile_off = np.full(len(specs), -1, np.int64)
         tile_off[proc] = np.arange(n_proc, dtype=np.int64) * (th * tw)
@@ -217,16 +216,24 @@ class BathymetricPipeline:
         r_cls = torch.empty(total, dtype=torch.float32, device=dev)
         r_conf = torch.empty(total, dtype=torch.float32, device=dev)
         r_corr = torch.empty(total, dtype=torch.float32, device=dev)
-        resol = np.array([[float(grid.resolution[0]), float(grid.resolution[1])]], np.float64)
+        resol = np.array([[float(resolution[0]), float(resolution[1])]], np.float64)
+        nbmax = min(self.tile_batch, max(n_proc, 1))
+        d_b = torch.empty(nbmax * th * tw, dtype=torch.float32, device=dev)
+        m_b = torch.empty(nbmax * th * tw, dtype=torch.uint8, device=dev)
+        u_b = torch.empty(nbmax * th * tw, dtype=torch.float32, device=dev) if unc_t is not None else None
         for b0 in range(0, n_proc, self.tile_batch):
             idx = proc[b0:b0 + self.tile_batch]
             nb = len(idx)
-            d_b = torch.stack([depth_t[sa[i, 0]:sa[i, 2], sa[i, 1]:sa[i, 3]] for i in idx]).reshape(-1)
-            m_b = torch.stack([valid_t[sa[i, 0]:sa[i, 2], sa[i, 1]:sa[i, 3]] for i in idx]).reshape(-1)
-            u_b = torch.stack([unc_t[sa[i, 0]:sa[i, 2], sa[i, 1]:sa[i, 3]] for i in idx]).reshape(-1) if use_unc else None
+            o_b = org_t[torch.from_numpy(idx).to(dev)].contiguous()
+            ctx.begin()
+            rt.check(ctx.lib.bgnn_cut_tiles(ctx.handle, H, W, rt.ptr(depth_t), rt.ptr(valid_u8), rt.ptr(unc_t), nb, rt.ptr(o_b),
+                                            th, tw, rt.ptr(d_b), rt.ptr(m_b), rt.ptr(u_b)))
+            ctx.end()
             lo, hi = b0 * th * tw, (b0 + nb) * th * tw
-            eng.infer_device(np.tile(np.array([[th, tw]], np.int32), (nb, 1)), np.tile(resol, (nb, 1)), d_b, m_b, u_b,
-                             out=(r_cls[lo:hi], r_conf[lo:hi], r_corr[lo:hi]))
+            n = nb * th * tw
+            eng.infer_device(np.tile(np.array([[th, tw]], np.int32), (nb, 1)), np.tile(resol, (nb, 1)), d_b[:n], m_b[:n],
+                             u_b[:n] if u_b is not None else None, out=(r_cls[lo:hi], r_conf[lo:hi], r_corr[lo:hi]))
+        del d_b, m_b, u_b
         # extents and blend windows per tile row / column (numpy, exactly TileManager._create_1d_blend)
         rs = np.array([specs[i * ntc].row_start for i in range(ntr)], np.int32); re = np.array([specs[i * ntc].row_end for i in range(ntr)], np.int32)
         cs = np.array([specs[j].col_start for j in range(ntc)], np.int32); ce = np.array([specs[j].col_end for j in range(ntc)], np.int32)
@@ -242,11 +249,26 @@ class BathymetricPipeline:
         ctx.begin()
         rt.check(ctx.lib.bgnn_stitch_tiles(
             ctx.handle, H, W, ntr, ntc, rt.ptr(rs_t), rt.ptr(re_t), rt.ptr(cs_t), rt.ptr(ce_t), rt.ptr(rw_t), rt.ptr(cw_t),
-            pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr), rt.ptr(depth_t), rt.ptr(valid_t),
+            pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr), rt.ptr(depth_t), rt.ptr(valid_u8),
             C.c_float(self.config.inference.auto_correct_threshold), rt.ptr(o[0]), rt.ptr(o[1]), rt.ptr(o[2]), rt.ptr(o[3])))
         ctx.end()
-        host = o.cpu().numpy()
+        self.last_tile_counts = (n_proc, len(specs) - n_proc)
         logger.info(f"Processed {n_proc} tiles ({len(specs) - n_proc} skipped below min_valid_ratio)")
+        return o
+
+    def process_grid_device(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
+        """Single-GPU survey path with everything between the two PCIe crossings on the device: the survey is
+        uploaded once, processed by ``process_survey_device`` and the four result grids come back in one copy.
+        Same results as the host merge (``process_grid`` under torch.distributed uses that one), bit for bit."""
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        dev = self._engine.ctx.device
+        valid_np = grid.valid_mask
+        depth_t = torch.from_numpy(np.ascontiguousarray(grid.depth, dtype=np.float32)).to(dev)
+        valid_t = torch.from_numpy(np.ascontiguousarray(valid_np).view(np.uint8)).to(dev)
+        use_unc = self.model.in_channels == 8 and grid.uncertainty is not None
+        unc_t = torch.from_numpy(np.ascontiguousarray(grid.uncertainty, dtype=np.float32)).to(dev) if use_unc else None
+        host = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution).cpu().numpy()
         return {"cleaned_depth": host[3], "classification": host[0], "confidence": host[1], "correction": host[2],
                 "valid_mask": valid_np.astype(np.float32)}
 

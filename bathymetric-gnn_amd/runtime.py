@@ -76,6 +76,10 @@ _SIGNATURES = {
     "bgnn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(Outputs)]),
     "bgnn_stitch_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
                           [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4),
+    "bgnn_cut_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                 C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgnn_tile_valid_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_void_p]),
     "bgnn_vr_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_void_p, C.c_double] +
                        [C.c_void_p] * 5),
     "bgnn_vr_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),

@@ -213,6 +213,18 @@ int bgnn_stitch_tiles(bgnn_ctx *ctx, int32_t height, int32_t width, int32_t n_ti
                       const uint8_t *valid_mask, float auto_correct_threshold, float *out_classification,
                       float *out_confidence, float *out_correction, float *out_cleaned_depth);
 
+/* Tiles out of a survey resident in HBM: TileManager.extract_tile / iterate_tiles (data/tiling.py:136-216) for a
+ * batch of n_tiles equally sized windows (the shift-back rule, :119-122, makes every tile of a survey the same
+ * size).  origins DEVICE int32 [n_tiles][2] = (row_start, col_start); the caller guarantees origin + tile size
+ * stays inside the survey.  bgnn_cut_tiles copies depth / valid mask / uncertainty (NULL pair allowed) windows into
+ * the concatenated tile layout of bgnn_tiles; bgnn_tile_valid_counts gives the per-tile number of valid cells
+ * (DEVICE int64 [n_tiles]) that iterate_tiles' min_valid_ratio test needs.  Asynchronous. */
+int bgnn_cut_tiles(bgnn_ctx *ctx, int32_t height, int32_t width, const float *depth, const uint8_t *valid_mask,
+                   const float *uncertainty, int32_t n_tiles, const int32_t *origins, int32_t tile_h, int32_t tile_w,
+                   float *out_depth, uint8_t *out_mask, float *out_uncertainty);
+int bgnn_tile_valid_counts(bgnn_ctx *ctx, int32_t height, int32_t width, const uint8_t *valid_mask, int32_t n_tiles,
+                           const int32_t *origins, int32_t tile_h, int32_t tile_w, int64_t *counts);
+
 /* ---- VR BAG refinement records (next row (f)3: data/vr_bag.py, scripts/inference_native.py main loop) ----
  * `records` is BAG_root/varres_refinements[0, :] as float32 pairs {depth, depth_uncrt} (DEVICE, [n_cells][2]):
  * every refinement grid row-major, grids in varres_metadata.index order (data/vr_bag.py:262-276), i.e. already

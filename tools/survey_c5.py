@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 on ONE MI355X with the survey resident in HBM: an S x S synthetic survey @0.5 m (default the
+full 60000 x 60000: 14.4 GB of depth), overlapping 512 x 512 tiles (overlap 128 -> 156 x 156 = 24 336 tiles,
+6.38 G node evaluations), classified and stitched without leaving the device
+(BathymetricPipeline.process_survey_device).  The depth field is generated on the device (torch; the SURVEY 8(d)
+formula, noise from torch's generator) because numpy would need minutes for 3.6 G cells."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bathymetric_gnn_amd import synthetic
+from bathymetric_gnn_amd.config import Config
+from bathymetric_gnn_amd.models import BathymetricGNN, BathymetricPipeline
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=60000); ap.add_argument("--tile-batch", type=int, default=32)
+ap.add_argument("--d2h", action="store_true", help="also copy the four result grids to the host")
+args = ap.parse_args()
+S = args.size
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(0)
+depth = torch.empty((S, S), dtype=torch.float32, device=dev)
+c = torch.arange(S, dtype=torch.float32, device=dev)[None, :]
+band = 4096
+for r0 in range(0, S, band):                     # in row bands: no survey-sized temporaries
+    r1 = min(S, r0 + band)
+    r = torch.arange(r0, r1, dtype=torch.float32, device=dev)[:, None]
+    d = -20 - 0.01 * c - 0.005 * r + 0.5 * torch.sin(2 * np.pi * r / 37) * torch.cos(2 * np.pi * c / 53)
+    d += 0.05 * torch.randn((r1 - r0, S), generator=g, device=dev)
+    depth[r0:r1] = d
+del d
+depth[: S // 10, : S // 8] = 1.0e6               # a nodata corner: tiles skipped by min_valid_ratio, ragged edge
+valid = (depth != 1.0e6) & torch.isfinite(depth)
+cfg = Config(); cfg.tile.tile_size, cfg.tile.overlap = 512, 128
+pipe = BathymetricPipeline(cfg, tile_batch=args.tile_batch)
+sd = synthetic.synthetic_state_dict(seed=1234)
+m = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+pipe.set_model(m)
+_, _, specs = pipe.tile_manager.compute_tile_grid((S, S))
+pipe.process_survey_device(depth[:1024, :1024].contiguous(), valid[:1024, :1024].contiguous(), None, (0.5, 0.5))   # warm-up
+torch.cuda.synchronize(); t0 = time.perf_counter()
+o = pipe.process_survey_device(depth, valid, None, (0.5, 0.5))
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+n_proc, n_skip = pipe.last_tile_counts
+evals = n_proc * 512 * 512 if S >= 512 else n_proc * S * S
+out = {"survey": f"{S}x{S}", "tiles": len(specs), "tiles_processed": n_proc, "tiles_skipped": n_skip, "node_evals": evals,
+       "valid_cells": int(valid.sum().item()), "wall_s": dt, "node_evals_per_s": evals / dt,
+       "hbm_peak_GB": torch.cuda.max_memory_allocated() / 1e9,
+       "class_histogram": [int((o[0] == k).sum().item()) for k in range(3)],
+       "nan_cells": int(torch.isnan(o[0]).sum().item()),
+       "checksum_confidence": float(torch.nan_to_num(o[1]).double().sum().item())}
+if args.d2h:
+    t0 = time.perf_counter(); host = o.cpu(); out["d2h_s"] = time.perf_counter() - t0
+print(json.dumps(out))
