@@ -48,6 +48,65 @@ def exchange_tile_results(mine: dict) -> dict:
     return out
 
 
+
+def survey_shard_plan(row_start, row_end, height: int, world: int):
+    """Row-band ownership of a tiled survey over ``world`` GPUs (contiguous row bands localise the
+    stitch).  Tile rows are split into contiguous blocks; rank k owns tile rows ``[a_k, b_k)`` and the survey cell
+    rows ``[R_k, R_{k+1})`` with ``R_k = row_start[a_k]`` (``R_0 = 0``, ``R_world = height``).  The cells of a band
+    are covered by the rank's own tile rows plus the earlier tile rows that reach into it (``row_end > R_k``):
+    those are the only results that cross GPUs.  Returns a list of dicts
+    ``{"tile_rows": (a, b), "cell_rows": (R0, R1), "need": [(src_rank, tile_row), ...]}``."""
+    rs = np.asarray(row_start, np.int64); re = np.asarray(row_end, np.int64)
+    ntr = len(rs)
+    cuts = [int(x) for x in np.linspace(0, ntr, world + 1).round()]
+    owner = np.empty(ntr, np.int64)
+    for k in range(world):
+        owner[cuts[k]:cuts[k + 1]] = k
+    plan = []
+    for k in range(world):
+        a, b = cuts[k], cuts[k + 1]
+        if a == b:                                     # more GPUs than tile rows: nothing to own
+            plan.append({"tile_rows": (a, b), "cell_rows": (height, height), "need": []})
+            continue
+        R0 = 0 if a == 0 else int(rs[a])
+        nxt = next((cuts[j] for j in range(k + 1, world) if cuts[j] < cuts[j + 1]), ntr)
+        R1 = height if nxt >= ntr else int(rs[nxt])
+        need = [(int(owner[t]), int(t)) for t in range(0, a) if re[t] > R0]
+        plan.append({"tile_rows": (a, b), "cell_rows": (R0, R1), "need": need})
+    return plan
+
+
+def exchange_halo_tile_rows(plan, rank: int, local_rows: Dict[int, torch.Tensor]) -> Dict[int, torch.Tensor]:
+    """Point-to-point exchange of the tile-row result blocks ``survey_shard_plan`` lists under ``need``: every rank
+    sends each of its tile rows that a later band needs and receives the ones its own band needs.  ``local_rows``
+    maps tile row -> tensor (all of one shape and dtype); returns {tile row: tensor} for the received rows.  This
+    is the path's only inter-GPU traffic (RCCL send/recv over xGMI under the ``nccl`` backend; staged through the
+    host under ``gloo``)."""
+    import torch.distributed as dist
+    if not plan[rank]["need"] and not any(src == rank for p in plan for src, _ in p["need"]):
+        return {}
+    via_host = dist.get_backend() == "gloo"
+    ops, recv, keep = [], {}, []
+    for dst, p in enumerate(plan):                       # same deterministic order on every rank
+        for src, t in p["need"]:
+            if src == rank and dst != rank:
+                buf = local_rows[t].contiguous()
+                buf = buf.cpu() if via_host else buf
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, dst, tag=t))
+            elif dst == rank and src != rank:
+                shape, dtype, dev = plan[rank]["_halo_shape"], plan[rank]["_halo_dtype"], plan[rank]["_halo_device"]
+                buf = torch.empty(shape, dtype=dtype, device="cpu" if via_host else dev)
+                recv[t] = buf
+                ops.append(dist.P2POp(dist.irecv, buf, src, tag=t))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if via_host:
+        recv = {t: b.to(plan[rank]["_halo_device"]) for t, b in recv.items()}
+    return recv
+
+
 class TileBatchEngine:
     """Fused per-batch inference on one GPU (one engine per worker / device)."""
 
@@ -182,13 +241,19 @@ class BathymetricPipeline:
 
     # ---- whole grid ----------------------------------------------------------------------------
     def process_survey_device(self, depth_t: torch.Tensor, valid_t: torch.Tensor, unc_t: Optional[torch.Tensor],
-                              resolution) -> torch.Tensor:
+                              resolution, shard: Optional[Tuple[int, int]] = None):
         """Survey resident in HBM in, ``[4, H, W]`` float32 device tensor out (classification, confidence,
         correction, cleaned depth): tiles are cut (``bgnn_cut_tiles``), filtered by ``min_valid_ratio``
         (``bgnn_tile_valid_counts``), classified batch by batch into three long per-tile result arrays and
         stitched / post-processed by ``bgnn_stitch_tiles``.  Nothing crosses PCIe in between; sized for one
         GPU's 288 GB (a 60000 x 60000 survey @512/128 holds 14 GB of depth, 77 GB of per-tile results and
-        58 GB of outputs)."""
+        58 GB of outputs).
+
+        ``shard=(rank, world)`` (one process per GPU, ``torch.distributed`` initialised, every rank holding the
+        survey): the rank classifies the tile rows ``survey_shard_plan`` gives it, receives the few earlier tile
+        rows that reach into its band of survey rows (``exchange_halo_tile_rows``, the only inter-GPU traffic)
+        and stitches that band; returns ``(row0, row1, [4, row1-row0, W])``.  Every cell sees the same tiles in
+        the same ascending order as on one GPU, so the bands concatenate to the single-GPU result bit for bit."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
         eng, ctx, dev = self._engine, self._engine.ctx, self._engine.ctx.device
@@ -199,67 +264,111 @@ class BathymetricPipeline:
         ntr, ntc, specs = tm.compute_tile_grid((H, W))
         sa = np.array([[s.row_start, s.col_start, s.row_end, s.col_end] for s in specs], np.int64)
         th, tw = int(sa[0, 2] - sa[0, 0]), int(sa[0, 3] - sa[0, 1])     # every tile has this extent (shift-back rule)
-        size = (sa[:, 2] - sa[:, 0]) * (sa[:, 3] - sa[:, 1])
-        assert np.all(size == th * tw)
-        org_t = torch.from_numpy(np.ascontiguousarray(sa[:, :2], dtype=np.int32)).to(dev)
-        cnt_t = torch.empty(len(specs), dtype=torch.int64, device=dev)
-        ctx.begin()
-        rt.check(ctx.lib.bgnn_tile_valid_counts(ctx.handle, H, W, rt.ptr(valid_u8), len(specs), rt.ptr(org_t), th, tw, rt.ptr(cnt_t)))
-        ctx.end()
-        cnt = cnt_t.cpu().numpy()
-        keep = ~((cnt / size) < tm.min_valid_ratio)                      # same float64 test as iterate_tiles
-        proc = np.nonzero(keep)[0]
+        cells = th * tw
+        assert np.all((sa[:, 2] - sa[:, 0]) * (sa[:, 3] - sa[:, 1]) == cells)
+        rs = sa[::ntc, 0].copy(); re = sa[::ntc, 2].copy(); cs = sa[:ntc, 1].copy(); ce = sa[:ntc, 3].copy()
+        rank, world = shard if shard is not None else (0, 1)
+        plan = survey_shard_plan(rs, re, H, world)
+        me = plan[rank]
+        ta, tb = me["tile_rows"]; R0, R1 = me["cell_rows"]
+        own = np.arange(ta * ntc, tb * ntc)                              # my tiles, ascending spec order
+        # ---- min_valid_ratio filter (iterate_tiles, tiling.py:203-209), exact integer counts ----
+        keep = np.zeros(0, bool)
+        if len(own):
+            org_t = torch.from_numpy(np.ascontiguousarray(sa[own, :2], dtype=np.int32)).to(dev)
+            cnt_t = torch.empty(len(own), dtype=torch.int64, device=dev)
+            ctx.begin()
+            rt.check(ctx.lib.bgnn_tile_valid_counts(ctx.handle, H, W, rt.ptr(valid_u8), len(own), rt.ptr(org_t), th, tw, rt.ptr(cnt_t)))
+            ctx.end()
+            keep = ~((cnt_t.cpu().numpy() / cells) < tm.min_valid_ratio)    # same float64 test as iterate_tiles
+        proc = np.nonzero(keep)[0]                                       # positions in `own`
         n_proc = len(proc)
-        tile_off = np.full(len(specs), -1, np.int64)
-        tile_off[proc] = np.arange(n_proc, dtype=np.int64) * (th * tw)
-        total = max(n_proc, 1) * th * tw
+        halo_rows = [t for _, t in me["need"]]
+        n_slots = n_proc + len(halo_rows) * ntc
+        total = max(n_slots, 1) * cells
         r_cls = torch.empty(total, dtype=torch.float32, device=dev)
         r_conf = torch.empty(total, dtype=torch.float32, device=dev)
         r_corr = torch.empty(total, dtype=torch.float32, device=dev)
         resol = np.array([[float(resolution[0]), float(resolution[1])]], np.float64)
-        nbmax = min(self.tile_batch, max(n_proc, 1))
-        d_b = torch.empty(nbmax * th * tw, dtype=torch.float32, device=dev)
-        m_b = torch.empty(nbmax * th * tw, dtype=torch.uint8, device=dev)
-        u_b = torch.empty(nbmax * th * tw, dtype=torch.float32, device=dev) if unc_t is not None else None
-        for b0 in range(0, n_proc, self.tile_batch):
-            idx = proc[b0:b0 + self.tile_batch]
-            nb = len(idx)
-            o_b = org_t[torch.from_numpy(idx).to(dev)].contiguous()
+        if n_proc:
+            nbmax = min(self.tile_batch, n_proc)
+            d_b = torch.empty(nbmax * cells, dtype=torch.float32, device=dev)
+            m_b = torch.empty(nbmax * cells, dtype=torch.uint8, device=dev)
+            u_b = torch.empty(nbmax * cells, dtype=torch.float32, device=dev) if unc_t is not None else None
+            proc_t = torch.from_numpy(proc).to(dev)
+            for b0 in range(0, n_proc, self.tile_batch):
+                nb = min(self.tile_batch, n_proc - b0)
+                o_b = org_t[proc_t[b0:b0 + nb]].contiguous()
+                ctx.begin()
+                rt.check(ctx.lib.bgnn_cut_tiles(ctx.handle, H, W, rt.ptr(depth_t), rt.ptr(valid_u8), rt.ptr(unc_t), nb, rt.ptr(o_b),
+                                                th, tw, rt.ptr(d_b), rt.ptr(m_b), rt.ptr(u_b)))
+                ctx.end()
+                lo, hi, n = b0 * cells, (b0 + nb) * cells, nb * cells
+                eng.infer_device(np.tile(np.array([[th, tw]], np.int32), (nb, 1)), np.tile(resol, (nb, 1)), d_b[:n], m_b[:n],
+                                 u_b[:n] if u_b is not None else None, out=(r_cls[lo:hi], r_conf[lo:hi], r_corr[lo:hi]))
+            del d_b, m_b, u_b
+        # ---- tile offsets of my own tiles, by (tile row, tile col) ----
+        off_own = np.full(len(own), -1, np.int64)
+        off_own[proc] = np.arange(n_proc, dtype=np.int64) * cells
+        # ---- the only inter-GPU step: earlier tile rows that reach into my band ----
+        off_halo = np.full((len(halo_rows), ntc), -1, np.int64)
+        if world > 1:
+            blk = 3 * ntc * cells
+            for p in plan:
+                p["_halo_shape"], p["_halo_dtype"], p["_halo_device"] = (blk + ntc,), torch.float32, dev
+            wanted = sorted({t for p in plan for src, t in p["need"] if src == rank})
+            local = {}
+            for t in wanted:                                             # pack [3][ntc][cells] + keep flags
+                k0 = (t - ta) * ntc
+                kept = np.nonzero(keep[k0:k0 + ntc])[0]
+                buf = torch.zeros(blk + ntc, dtype=torch.float32, device=dev)
+                if len(kept):
+                    cols = torch.from_numpy(kept).to(dev)
+                    p0 = int(off_own[k0 + kept[0]]); p1 = p0 + len(kept) * cells     # kept tiles of a row are consecutive slots
+                    for c, r in enumerate((r_cls, r_conf, r_corr)):
+                        buf[c * ntc * cells:(c + 1) * ntc * cells].view(ntc, cells)[cols] = r[p0:p1].view(len(kept), cells)
+                    buf[blk + cols] = 1.0
+                local[t] = buf
+            torch.cuda.synchronize(dev)
+            got = exchange_halo_tile_rows(plan, rank, local)
+            for j, t in enumerate(halo_rows):
+                buf = got[t]
+                base = (n_proc + j * ntc) * cells
+                for c, r in enumerate((r_cls, r_conf, r_corr)):
+                    r[base:base + ntc * cells] = buf[c * ntc * cells:(c + 1) * ntc * cells]
+                kp = buf[blk:].cpu().numpy() > 0
+                off_halo[j, kp] = base + np.nonzero(kp)[0].astype(np.int64) * cells
+        # ---- stitch my band: tile rows involved = halo rows (earlier, ascending) then my own ----
+        rows_inv = np.array(halo_rows + list(range(ta, tb)), np.int64)
+        o = torch.empty((4, R1 - R0, W), dtype=torch.float32, device=dev)
+        if R1 > R0:
+            rs_b = (rs[rows_inv] - R0).astype(np.int32); re_b = (re[rows_inv] - R0).astype(np.int32)
+            pitch = max(th, tw)
+            roww = np.zeros((len(rows_inv), pitch), np.float32); colw = np.zeros((ntc, pitch), np.float32)
+            for i, t in enumerate(rows_inv):                             # numpy, exactly TileManager._create_1d_blend
+                roww[i, :re[t] - rs[t]] = tm._create_1d_blend(int(re[t] - rs[t]))
+            for j in range(ntc):
+                colw[j, :ce[j] - cs[j]] = tm._create_1d_blend(int(ce[j] - cs[j]))
+            tile_off = np.concatenate([off_halo.reshape(-1), off_own])
+            dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            rs_t, re_t, cs_t, ce_t = dv(rs_b), dv(re_b), dv(cs.astype(np.int32)), dv(ce.astype(np.int32))
+            rw_t, cw_t, off_t = dv(roww), dv(colw), dv(tile_off)
             ctx.begin()
-            rt.check(ctx.lib.bgnn_cut_tiles(ctx.handle, H, W, rt.ptr(depth_t), rt.ptr(valid_u8), rt.ptr(unc_t), nb, rt.ptr(o_b),
-                                            th, tw, rt.ptr(d_b), rt.ptr(m_b), rt.ptr(u_b)))
+            rt.check(ctx.lib.bgnn_stitch_tiles(
+                ctx.handle, R1 - R0, W, len(rows_inv), ntc, rt.ptr(rs_t), rt.ptr(re_t), rt.ptr(cs_t), rt.ptr(ce_t), rt.ptr(rw_t),
+                rt.ptr(cw_t), pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr), rt.ptr(depth_t[R0:R1]),
+                rt.ptr(valid_u8[R0:R1]), C.c_float(self.config.inference.auto_correct_threshold),
+                rt.ptr(o[0]), rt.ptr(o[1]), rt.ptr(o[2]), rt.ptr(o[3])))
             ctx.end()
-            lo, hi = b0 * th * tw, (b0 + nb) * th * tw
-            n = nb * th * tw
-            eng.infer_device(np.tile(np.array([[th, tw]], np.int32), (nb, 1)), np.tile(resol, (nb, 1)), d_b[:n], m_b[:n],
-                             u_b[:n] if u_b is not None else None, out=(r_cls[lo:hi], r_conf[lo:hi], r_corr[lo:hi]))
-        del d_b, m_b, u_b
-        # extents and blend windows per tile row / column (numpy, exactly TileManager._create_1d_blend)
-        rs = np.array([specs[i * ntc].row_start for i in range(ntr)], np.int32); re = np.array([specs[i * ntc].row_end for i in range(ntr)], np.int32)
-        cs = np.array([specs[j].col_start for j in range(ntc)], np.int32); ce = np.array([specs[j].col_end for j in range(ntc)], np.int32)
-        pitch = max(th, tw)
-        roww = np.zeros((ntr, pitch), np.float32); colw = np.zeros((ntc, pitch), np.float32)
-        for i in range(ntr):
-            roww[i, :re[i] - rs[i]] = tm._create_1d_blend(int(re[i] - rs[i]))
-        for j in range(ntc):
-            colw[j, :ce[j] - cs[j]] = tm._create_1d_blend(int(ce[j] - cs[j]))
-        dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        rs_t, re_t, cs_t, ce_t, rw_t, cw_t, off_t = dv(rs), dv(re), dv(cs), dv(ce), dv(roww), dv(colw), dv(tile_off)
-        o = torch.empty((4, H, W), dtype=torch.float32, device=dev)
-        ctx.begin()
-        rt.check(ctx.lib.bgnn_stitch_tiles(
-            ctx.handle, H, W, ntr, ntc, rt.ptr(rs_t), rt.ptr(re_t), rt.ptr(cs_t), rt.ptr(ce_t), rt.ptr(rw_t), rt.ptr(cw_t),
-            pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr), rt.ptr(depth_t), rt.ptr(valid_u8),
-            C.c_float(self.config.inference.auto_correct_threshold), rt.ptr(o[0]), rt.ptr(o[1]), rt.ptr(o[2]), rt.ptr(o[3])))
-        ctx.end()
-        self.last_tile_counts = (n_proc, len(specs) - n_proc)
-        logger.info(f"Processed {n_proc} tiles ({len(specs) - n_proc} skipped below min_valid_ratio)")
-        return o
+        self.last_tile_counts = (n_proc, len(own) - n_proc)
+        logger.info(f"Processed {n_proc} tiles ({len(own) - n_proc} skipped below min_valid_ratio)")
+        return o if shard is None else (R0, R1, o)
 
     def process_grid_device(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
-        """Single-GPU survey path with everything between the two PCIe crossings on the device: the survey is
-        uploaded once, processed by ``process_survey_device`` and the four result grids come back in one copy.
-        Same results as the host merge (``process_grid`` under torch.distributed uses that one), bit for bit."""
+        """Survey path with everything between the two PCIe crossings on the device: the survey is uploaded once,
+        processed by ``process_survey_device`` (row-band sharded when torch.distributed is initialised) and the
+        four result grids come back in one copy.  Same results as the host merge (``host_stitch = True``), bit for
+        bit, for any number of GPUs."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
         dev = self._engine.ctx.device
@@ -268,23 +377,34 @@ class BathymetricPipeline:
         valid_t = torch.from_numpy(np.ascontiguousarray(valid_np).view(np.uint8)).to(dev)
         use_unc = self.model.in_channels == 8 and grid.uncertainty is not None
         unc_t = torch.from_numpy(np.ascontiguousarray(grid.uncertainty, dtype=np.float32)).to(dev) if use_unc else None
-        host = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution).cpu().numpy()
+        rank, world = shard_info()
+        if world == 1:
+            host = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution).cpu().numpy()
+        else:               # row bands: each rank stitches its own band; the bands are gathered once at the end
+            import torch.distributed as dist
+            r0, r1, band = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution, shard=(rank, world))
+            parts = [None] * world
+            dist.all_gather_object(parts, (r0, r1, band.cpu().numpy()))
+            host = np.empty((4,) + tuple(grid.shape), np.float32)
+            for a, b, arr in parts:
+                host[:, a:b] = arr
         return {"cleaned_depth": host[3], "classification": host[0], "confidence": host[1], "correction": host[2],
                 "valid_mask": valid_np.astype(np.float32)}
 
     def process_grid(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
         """The body of ``process`` between load and save (reference :163-211), tiles batched.
 
-        Multi-GPU: when ``torch.distributed`` is initialised (one process per GPU), the tiles that
-        pass the ``min_valid_ratio`` filter are dealt round-robin by index to the ranks, each rank
-        classifies its share on its own GPU, the per-tile grids are exchanged once
-        (``all_gather_object``; tiles are independent, so there is no collective inside the data
-        path) and EVERY rank stitches them in ascending spec order -- the float32 blend sums and the
+        Default: the device path (``process_grid_device``), on one GPU or row-band sharded over the ranks of an
+        initialised ``torch.distributed`` job.  With ``host_stitch = True`` (or without a device engine) the
+        reference-shaped host merge below runs instead: the tiles that pass the ``min_valid_ratio`` filter are
+        dealt round-robin by index to the ranks, each rank classifies its share, the per-tile grids are
+        exchanged once (``all_gather_object``; tiles are independent, so there is no collective inside the
+        data path) and EVERY rank stitches them in ascending spec order -- the float32 blend sums and the
         ``>`` tie rule of the discrete channel therefore do not depend on the number of GPUs."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
-        if shard_info()[1] == 1 and getattr(self, "_engine", None) is not None and not getattr(self, "host_stitch", False):
-            return self.process_grid_device(grid)
+        if getattr(self, "_engine", None) is not None and not getattr(self, "host_stitch", False):
+            return self.process_grid_device(grid)      # one GPU, or row bands over the ranks' GPUs
         _, _, specs = self.tile_manager.compute_tile_grid(grid.shape)
         by_pos = {(s.tile_row, s.tile_col): s for s in specs}
         tiles = list(self.tile_manager.iterate_tiles(grid, skip_empty=True))

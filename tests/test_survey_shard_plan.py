@@ -1,0 +1,96 @@
+"""Row-band sharding of a tiled survey (BASELINE config 5): the ownership plan is pure host logic, and
+the halo exchange is rehearsed with world_size-3 gloo on CPU tensors (the GPU run of the full path is
+tools/survey_sharded_check.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _rows(H, tile, overlap):
+    from bathymetric_gnn_amd.data import TileManager
+    ntr, ntc, specs = TileManager(tile, overlap).compute_tile_grid((H, tile))
+    rs = np.array([specs[i * ntc].row_start for i in range(ntr)]); re = np.array([specs[i * ntc].row_end for i in range(ntr)])
+    return rs, re
+
+
+@pytest.mark.parametrize("H,tile,overlap,world", [(60000, 512, 128, 8), (1300, 512, 128, 2), (1300, 512, 128, 8), (500, 64, 16, 3),
+                                                  (1000, 512, 128, 3), (200, 512, 128, 4), (6000, 512, 128, 5)])
+def test_plan_partitions_and_needs(H, tile, overlap, world):
+    from bathymetric_gnn_amd.models.pipeline import survey_shard_plan
+    rs, re = _rows(H, tile, overlap)
+    plan = survey_shard_plan(rs, re, H, world)
+    assert len(plan) == world
+    # tile rows: contiguous blocks covering 0..ntr; cell rows: bands covering [0, H) without gaps or overlap
+    rows = [t for p in plan for t in range(*p["tile_rows"])]
+    assert rows == list(range(len(rs)))
+    pos = 0
+    for p in plan:
+        a, b = p["cell_rows"]
+        if p["tile_rows"][0] == p["tile_rows"][1]:
+            assert a == b
+            continue
+        assert a == pos and b > a
+        pos = b
+    assert pos == H
+    for k, p in enumerate(plan):
+        R0, R1 = p["cell_rows"]
+        if R0 == R1:
+            assert p["need"] == []
+            continue
+        a, b = p["tile_rows"]
+        covering = [t for t in range(len(rs)) if rs[t] < R1 and re[t] > R0]      # tile rows touching the band
+        have = sorted([t for _, t in p["need"]] + list(range(a, b)))
+        assert set(covering) <= set(have)
+        assert all(t < a for _, t in p["need"]) and [t for _, t in p["need"]] == sorted(t for _, t in p["need"])
+        for src, t in p["need"]:
+            assert plan[src]["tile_rows"][0] <= t < plan[src]["tile_rows"][1] and src < k
+    if world == 1 or len(rs) == 1:
+        assert all(p["need"] == [] for p in plan)
+    # the shift-back rule can make the last tile row overlap two earlier ones: then a band needs two halo rows
+    if (H, tile, overlap, world) == (1000, 512, 128, 3):
+        assert len(plan[2]["need"]) == 2
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bathymetric_gnn_amd.models.pipeline import exchange_halo_tile_rows, survey_shard_plan
+    rs, re = _rows(1000, 512, 128)                                  # tile rows 0,384,488 -> rank 2 needs rows 0 and 1
+    plan = survey_shard_plan(rs, re, 1000, world)
+    for p in plan:
+        p["_halo_shape"], p["_halo_dtype"], p["_halo_device"] = (1000,), torch.float32, torch.device("cpu")
+    mine = {t: torch.full((1000,), float(100 * rank + t)) + torch.arange(1000) for t in range(*plan[rank]["tile_rows"])}
+    got = exchange_halo_tile_rows(plan, rank, mine)
+    q.put((rank, {t: v.numpy().copy() for t, v in got.items()}, plan[rank]["need"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_gloo_three_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=180) for _ in range(3)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    n_recv = 0
+    for rank, got, need in res:
+        assert sorted(got) == sorted(t for _, t in need)
+        for src, t in need:
+            assert np.array_equal(got[t], 100 * src + t + np.arange(1000, dtype=np.float32))
+            n_recv += 1
+    assert n_recv == 3            # rank 1 <- row 0; rank 2 <- rows 0 and 1

@@ -48,6 +48,19 @@ out = {"survey": f"{S}x{S}", "tiles": len(specs), "tiles_processed": n_proc, "ti
        "class_histogram": [int((o[0] == k).sum().item()) for k in range(3)],
        "nan_cells": int(torch.isnan(o[0]).sum().item()),
        "checksum_confidence": float(torch.nan_to_num(o[1]).double().sum().item())}
+# size-independent property: a crop whose origin sits on the tile lattice (stride 384) re-creates the same tiles, so the
+# crop's cells that only those tiles cover -- rows / cols [128, 1152) of a 1280 crop -- must come out bit-identical.
+# Taken at the far corner, where cell offsets exceed 2^31 and per-tile result offsets exceed 2^32.
+if S >= 4 * 1280:
+    k = (S - 1280) // 384 - 1
+    r0 = c0 = 384 * k
+    sub = pipe.process_survey_device(depth[r0:r0 + 1280, c0:c0 + 1280].contiguous(), valid[r0:r0 + 1280, c0:c0 + 1280].contiguous(),
+                                     None, (0.5, 0.5))
+    a = o[:, r0 + 128:r0 + 1152, c0 + 128:c0 + 1152].contiguous().view(torch.int32)
+    b = sub[:, 128:1152, 128:1152].contiguous().view(torch.int32)
+    out["crop_origin"] = [r0, c0]
+    out["crop_bit_identical"] = bool(torch.equal(a, b))
+    out["crop_confidence_range"] = [float(sub[1, 128:1152, 128:1152].min().item()), float(sub[1, 128:1152, 128:1152].max().item())]
 if args.d2h:
     t0 = time.perf_counter(); host = o.cpu(); out["d2h_s"] = time.perf_counter() - t0
 print(json.dumps(out))
