@@ -181,11 +181,48 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
   const int tr = cell / TILE_W, tc = cell % TILE_W;
   const int self_idx = (tr + 1) * HW_ + tc + 1;
 
+  // Prologue loads, two dependent rounds with everything of a round in flight together:
+  //   round 1: node id of this thread's halo row (HR <= NTH: one row per thread) and of this lane's own cell;
+  //   round 2: alpha_src of the halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...
+  //            for NS = 1) -- consumed in phase A, so their latency hides behind the halo bookkeeping.
+  static_assert(HR <= NTH, "one halo row per thread");
+  constexpr int NHL = (H + 2 * NS - 1) / (2 * NS);      // heads per lane
+  const bool pre = a.ED == 3 && !(a.dbg & 32);
+  int my_pre = -1, hid_v = -1;
+  {
+    const int gr = pos.r0 + tid / HW_ - 1, gc = pos.c0 + tid % HW_ - 1;
+    if (tid < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) hid_v = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
+  }
+  if (pre) {
+    const int gr = pos.r0 + tr, gc = pos.c0 + tc;
+    if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
+  }
   if (tid == 0) *minid = 0x7fffffff;
   // rows without a node are never written by the DMA: zero them once
   for (int i = tid; i < HR * 8; i += NTH) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  load_halo_ids<H, NTH, HR>(pos, a.node_id, a.asd, hid, has);
   for (int i = tid; i < HC; i += NTH) { scsh[i] = a.scale[i]; scsh[HC + i] = a.shift[i]; }
+  if (hid_v < 0) hid_v = -1;
+  float eraw[K * 3], adv[NHL], hasv[H];
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) hasv[hh] = hid_v >= 0 ? a.asd[(int64_t)hid_v * 2 * H + hh] : 0.0f;
+  if (my_pre >= 0) {
+    const float4 *ep = reinterpret_cast<const float4 *>(a.eattr + (int64_t)my_pre * K * 3);
+#pragma unroll
+    for (int i = 0; i < K * 3 / 4; ++i) {
+      const float4 q = ep[i];
+      eraw[4 * i] = q.x; eraw[4 * i + 1] = q.y; eraw[4 * i + 2] = q.z; eraw[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) {
+      const int hh = nh * 2 + hl + i * 2 * NS;
+      adv[i] = hh < H ? a.asd[(int64_t)my_pre * 2 * H + H + hh] : 0.0f;
+    }
+  }
+  if (tid < HR) {
+    hid[tid] = hid_v;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hasv[hh];
+  }
   __syncthreads();
   {
     int m = 0x7fffffff;
@@ -231,13 +268,20 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
   // take the heads round-robin.
   {
     const int my = (a.dbg & 32) ? -1 : hid[self_idx];
-    for (int hh = nh * 2 + hl; hh < H; hh += 2 * NS) {
-      float part[K + 1];
 #pragma unroll
-      for (int i = 0; i <= K; ++i) part[i] = 0.0f;
-      if (my >= 0) attention_coefficients_head<H, K>(my, self_idx, hh, hid, has, a.asd, a.eattr, a.V, a.ED, part);
+    for (int i = 0; i < NHL; ++i) {
+      const int hh = nh * 2 + hl + i * 2 * NS;
+      if (hh < H) {
+        float part[K + 1];
 #pragma unroll
-      for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + hh * (K + 1) + b] = part[b];
+        for (int b = 0; b <= K; ++b) part[b] = 0.0f;
+        if (my >= 0) {
+          if (pre) attention_coefficients_head_pre<H, K>(self_idx, hh, hid, has, eraw, adv[i], a.V, part);
+          else attention_coefficients_head<H, K>(my, self_idx, hh, hid, has, a.asd, a.eattr, a.V, a.ED, part);
+        }
+#pragma unroll
+        for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + hh * (K + 1) + b] = part[b];
+      }
     }
     // (consumers wait at the barrier at the top of the slab loop)
   }
@@ -266,6 +310,13 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
       // (when the pieces do not divide evenly some waves issue one more: the floor only makes their wait conservative)
       wait_vm_lgkm<2 * WH>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
+      if (EPI == EPI_NEXT && s == 0 && wave < 2) {
+        // phase A is over on every wave: `has` is dead.  Park the next layer's att_src | att_dst there for the
+        // epilogue (one more VM op behind WB(0) on waves 0/1: the counted waits below only get more conservative).
+        if (lane * 4 < NC)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>((wave == 0 ? a.att_src : a.att_dst) + lane * 4),
+                                           (__attribute__((address_space(3))) void *)(has + wave * NC), 16, 0, 0);
+      }
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
       f32x4 g[4];
@@ -325,12 +376,11 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
     }
   }
 
-  float *attl = wbuf + 32 * NC - 2 * NC;                // att_src | att_dst, parked at the END of wbuf: the store
-  if (EPI == EPI_NEXT) {                                 // patches below grow from the slab into the start of wbuf
-    __syncthreads();                                    // every wave is done with wbuf
-    for (int i = tid; i < NC; i += NTH) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
-    __syncthreads();
-  }
+  static_assert(EPI != EPI_NEXT || HR * H >= 2 * NC, "att_src | att_dst are parked in the halo alpha_src table");
+  const float *attl = has;                              // att_src | att_dst (DMA'd there during slab 0)
+  // NS == 1: the store patches below stay inside the slab region, which every wave left at the last slab's second
+  // barrier -- a wave goes straight from its last MFMA into its own epilogue.  NS == 2: the patches reach into wbuf.
+  if (EPI == EPI_NEXT && NS > 1) __syncthreads();
   if (!(a.dbg & 64)) {
     const int mr = tr, mc = tc;
     const int id = hid[self_idx];
@@ -342,7 +392,7 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
       float ps[H2L], pd[H2L];
 #pragma unroll
       for (int hd = 0; hd < H2L; ++hd) { ps[hd] = 0.0f; pd[hd] = 0.0f; }
-      const float *asl = attl + nh * NTL * 32 + 4 * hl, *adl = attl + NC + nh * NTL * 32 + 4 * hl;
+      const uint32_t asl = lds_addr(attl + nh * NTL * 32 + 4 * hl);
       // Row-per-lane stores (32 rows x 32 B per instruction) are store-issue bound; instead each 32x32 tile
       // is transposed through a wave-private LDS patch (the slab region is free now) and written out as whole
       // 128-byte row segments, 8 rows per instruction.
@@ -354,21 +404,32 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
         const int rid = hid[(c / TILE_W + 1) * HW_ + c % TILE_W + 1];
         prow[k] = (rid >= 0 ? a.out + (int64_t)rid * NC : a.dump) + nh * NTL * 32 + (lane & 7) * 4;
       }
+      // The att reads go through the asm path with an explicit wait per tile: left to the scheduler, all 2*NT*4
+      // of them are hoisted above the stores, which -- next to 128 live accumulators -- spills them to scratch, and
+      // every scratch reload then waits (vmcnt) for the stores in flight.
+      static_assert(NC * 4 + 96 + 7 * 128 < 65536, "att offsets fit the ds_read immediate");
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
+        f32x4 s4[4], d4[4];
+        s4[0] = lds_read4<0>(asl + t * 128); s4[1] = lds_read4<32>(asl + t * 128);
+        s4[2] = lds_read4<64>(asl + t * 128); s4[3] = lds_read4<96>(asl + t * 128);
+        d4[0] = lds_read4<NC * 4>(asl + t * 128); d4[1] = lds_read4<NC * 4 + 32>(asl + t * 128);
+        d4[2] = lds_read4<NC * 4 + 64>(asl + t * 128); d4[3] = lds_read4<NC * 4 + 96>(asl + t * 128);
+        lds_reads_done();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 s4 = *reinterpret_cast<const float4 *>(asl + t * 32 + 8 * g);
-          const float4 d4 = *reinterpret_cast<const float4 *>(adl + t * 32 + 8 * g);
           const float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-          ps[t / TPH] += v.x * s4.x + v.y * s4.y + v.z * s4.z + v.w * s4.w;
-          pd[t / TPH] += v.x * d4.x + v.y * d4.y + v.z * d4.z + v.w * d4.w;
+          ps[t / TPH] += v.x * s4[g].x + v.y * s4[g].y + v.z * s4[g].z + v.w * s4[g].w;
+          pd[t / TPH] += v.x * d4[g].x + v.y * d4[g].y + v.z * d4[g].z + v.w * d4[g].w;
           *reinterpret_cast<float4 *>(patch + r * TILED_PITCH + 8 * g + 4 * hl) = v;
         }
+        asm volatile("" : "+v"(ps[t / TPH]), "+v"(pd[t / TPH]));   // the dots are due HERE (not sunk below the stores)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           *reinterpret_cast<float4 *>(prow[k] + t * 32) =
               *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int hd = 0; hd < H2L; ++hd) {

@@ -227,4 +227,59 @@ __device__ __forceinline__ void attention_coefficients_head(int my, int self_idx
   for (int b = 0; b <= K; ++b) out[b] = lg[b] / den;
 }
 
+// attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
+// edge-attribute block, `ad` = its alpha_dst for head hh.  Lets the caller issue those global loads before the
+// halo ids are known (one latency less on the workgroup's critical path).
+template <int H, int K>
+__device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, int hh, const int *hid, const float *has,
+                                                                const float (&eraw)[K * 3], float ad, const float *V,
+                                                                float *out) {
+  using Off = StencilOffsets<K>;
+  float v[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) v[f] = V[hh * 3 + f];
+  float ea_sum[3] = {0.f, 0.f, 0.f};
+  int deg = 0;
+  float mx = -__builtin_inff();
+  float lg[K + 1];
+  bool present[K];
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    const int nidx = self_idx - Off::dr[b] * HALO_W - Off::dc[b];
+    present[b] = hid[nidx] >= 0;
+    float dot = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const float e = present[b] ? eraw[b * 3 + f] : 0.0f;
+      ea_sum[f] += e;
+      dot += e * v[f];
+    }
+    float x = has[nidx * H + hh] + ad + dot;
+    x = x > 0.0f ? x : 0.2f * x;
+    lg[b] = x;
+    if (present[b]) { mx = fmaxf(mx, x); ++deg; }
+  }
+  {
+    const float cnt = (float)(deg > 0 ? deg : 1);
+    float dot = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) dot += (ea_sum[f] / cnt) * v[f];
+    float x = has[self_idx * H + hh] + ad + dot;
+    x = x > 0.0f ? x : 0.2f * x;
+    lg[K] = x;
+    mx = fmaxf(mx, x);
+  }
+  float den = 0.0f;
+#pragma unroll
+  for (int b = 0; b <= K; ++b) {
+    const bool on = b == K ? true : present[b];
+    const float pe = on ? expf(lg[b] - mx) : 0.0f;
+    lg[b] = pe;
+    den += pe;
+  }
+  den += 1e-16f;
+#pragma unroll
+  for (int b = 0; b <= K; ++b) out[b] = lg[b] / den;
+}
+
 }  // namespace bgnn

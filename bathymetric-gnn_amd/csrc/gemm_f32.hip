@@ -23,6 +23,7 @@
 namespace bgnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_KC = 32;   // k-chunk staged in LDS
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ void stage_w(const float *Wt, float *dst, int kc, int
 template <int NT, bool ATT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
   constexpr int NC = NT * 32;
-  constexpr int WL = 2 * GEMM_KC * NC > 4 * 32 * 36 ? 2 * GEMM_KC * NC : 4 * 32 * 36;   // also holds the store patches
+  constexpr int WL = 2 * GEMM_KC * NC > 4 * 32 * 36 + 2 * NC ? 2 * GEMM_KC * NC : 4 * 32 * 36 + 2 * NC;   // also holds the store patches + att
   __shared__ float wl_[WL];
   float (*wl)[GEMM_KC * NC] = reinterpret_cast<float (*)[GEMM_KC * NC]>(wl_);
   const int64_t M = *a.d_m;
@@ -120,39 +121,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
 
   // epilogue.  Transposed C/D layout: lane (r, h) holds row r; reg i -> channel
   // t*32 + 8*(i>>2) + 4*h + (i&3)
-  const bool ok = row < M;
-  if (ATT) {
-    const int H = a.H, tph = a.C / 32;              // tiles per head
-    for (int hd = 0; hd < H; ++hd) {
-      float ps = 0.0f, pd = 0.0f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (t / tph == hd) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 s4 = *reinterpret_cast<const float4 *>(a.att_src + t * 32 + 8 * g + 4 * h);
-            const float4 d4 = *reinterpret_cast<const float4 *>(a.att_dst + t * 32 + 8 * g + 4 * h);
-            ps += acc[t][4 * g] * s4.x + acc[t][4 * g + 1] * s4.y + acc[t][4 * g + 2] * s4.z + acc[t][4 * g + 3] * s4.w;
-            pd += acc[t][4 * g] * d4.x + acc[t][4 * g + 1] * d4.y + acc[t][4 * g + 2] * d4.z + acc[t][4 * g + 3] * d4.w;
-          }
-        }
-      }
-      ps += __shfl_xor(ps, 32);
-      pd += __shfl_xor(pd, 32);
-      if (ok && h == 0) {
-        a.asd[row * 2 * H + hd] = ps;
-        a.asd[row * 2 * H + H + hd] = pd;
-      }
-    }
-  }
   // Row-per-lane stores are store-issue bound (32 rows x 32 B per instruction).  Each 32x32 tile goes through
   // a wave-private LDS patch (wl is free now) and leaves as whole 128-byte row segments, 8 rows per instruction.
+  // With ATT the attention dot products of the same tile are taken on the way (per-tile partials, folded into
+  // heads at the end); att_src | att_dst sit in LDS behind the patches.
   __syncthreads();                                   // every wave is past its last read of wl
+  float *attl = wl_ + 4 * 32 * 36;
+  if (ATT) {
+    for (int i = threadIdx.x; i < NC; i += 256) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
+    __syncthreads();
+  }
+  float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
   {
     float *patch = wl_ + wave * (32 * 36);
     const int64_t wrow0 = row_block + wave * 32;
+    float *dst[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = (lane >> 3) + 8 * k;
+      dst[k] = (wrow0 + rr < M ? a.Y + (wrow0 + rr) * a.ldy : a.dump) + (lane & 7) * 4;
+    }
+    const uint32_t asl = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)(attl + 4 * h);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (ATT) {
+        // asm reads + an explicit wait per tile: left to the scheduler the 8*NT att reads are hoisted above the
+        // stores and, next to the live accumulators, spilled -- and a scratch reload waits for the stores in flight
+        f32x4 s4[4], d4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(s4[g]) : "v"(asl + (t * 32 + 8 * g) * 4));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(d4[g]) : "v"(asl + (NC + t * 32 + 8 * g) * 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float ps = 0.0f, pd = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ps += acc[t][4 * g] * s4[g].x + acc[t][4 * g + 1] * s4[g].y + acc[t][4 * g + 2] * s4[g].z + acc[t][4 * g + 3] * s4[g].w;
+          pd += acc[t][4 * g] * d4[g].x + acc[t][4 * g + 1] * d4[g].y + acc[t][4 * g + 2] * d4[g].z + acc[t][4 * g + 3] * d4[g].w;
+        }
+        asm volatile("" : "+v"(ps), "+v"(pd));      // due here, not sunk below the stores
+        pts[t] = ps; ptd[t] = pd;
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
@@ -166,11 +177,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
         }
         *reinterpret_cast<float4 *>(patch + r * 36 + 8 * g + 4 * h) = v;
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int rr = (lane >> 3) + 8 * k;
-        float *dst = (wrow0 + rr < M ? a.Y + (wrow0 + rr) * a.ldy : a.dump) + t * 32 + (lane & 7) * 4;
-        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(patch + rr * 36 + (lane & 7) * 4);
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4 *>(dst[k] + t * 32) =
+            *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (ATT) {
+    // per-tile partials -> heads, in ascending tile order (the order the single-pass form summed them in)
+    const bool ok = row < M;
+    const int H = a.H, tph = a.C / 32;              // tiles per head
+    for (int hd = 0; hd < H; ++hd) {
+      float ps = 0.0f, pd = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t / tph == hd) { ps += pts[t]; pd += ptd[t]; }
+      ps += __shfl_xor(ps, 32);
+      pd += __shfl_xor(pd, 32);
+      if (ok && h == 0) {
+        a.asd[row * 2 * H + hd] = ps;
+        a.asd[row * 2 * H + H + hd] = pd;
       }
     }
   }

@@ -37,7 +37,7 @@ def worker(rank, world, port, size, tile, overlap, q):
     if rank == 0:
         full = pipe.process_survey_device(depth, valid, None, (0.5, 0.5)).cpu().numpy()
         got = np.concatenate([p[2] for p in parts], axis=1)
-        same = got.shape == full.shape and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(full).view(np.uint32)) \\
+        same = got.shape == full.shape and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(full).view(np.uint32)) \
             and np.array_equal(np.isnan(got), np.isnan(full))
         q.put({"world": world, "survey": list(d.shape), "tile": [tile, overlap], "bands": [[int(p[0]), int(p[1])] for p in parts],
                "tiles_per_rank": [list(p[3]) for p in parts], "sharded_wall_s": dt, "bit_identical_to_single_gpu": bool(same)})
