@@ -197,12 +197,17 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
     const int gr = pos.r0 + tr, gc = pos.c0 + tc;
     if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
-  if (tid == 0) *minid = 0x7fffffff;
   // rows without a node are never written by the DMA: zero them once
   for (int i = tid; i < HR * 8; i += NTH) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < HC; i += NTH) { scsh[i] = a.scale[i]; scsh[HC + i] = a.shift[i]; }
   if (hid_v < 0) hid_v = -1;
-  float eraw[K * 3], adv[NHL], hasv[H];
+  float eraw[K * 3], adv[NHL], hasv[H], vpre[NHL][3];
+#pragma unroll
+  for (int i = 0; i < NHL; ++i) {
+    const int hh = nh * 2 + hl + i * 2 * NS;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) vpre[i][f] = (pre && hh < H) ? a.V[hh * 3 + f] : 0.0f;
+  }
 #pragma unroll
   for (int hh = 0; hh < H; ++hh) hasv[hh] = hid_v >= 0 ? a.asd[(int64_t)hid_v * 2 * H + hh] : 0.0f;
   if (my_pre >= 0) {
@@ -223,15 +228,17 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hasv[hh];
   }
-  __syncthreads();
   {
-    int m = 0x7fffffff;
-    for (int i = tid; i < HR; i += NTH) { const int v = hid[i]; if (v >= 0 && v < m) m = v; }
-    if (m != 0x7fffffff) atomicMin(minid, m);
+    static_assert(HR <= 192, "halo rows live in waves 0-2");
+    int m = hid_v >= 0 ? hid_v : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o));
+    if (lane == 0 && wave < 3) minid[wave] = m;
   }
   __syncthreads();
   BGNN_STAMP(0)   // halo ids, zero fill, min id
-  const int id0 = *minid;                              // smallest node id of the halo (0x7fffffff: block has no node)
+  // smallest node id of the halo (0x7fffffff: block has no node); the halo rows sit in waves 0-2
+  const int id0 = min(min(minid[0], minid[1]), minid[2]);
 
   // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B;
   // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
 #pragma unroll
         for (int b = 0; b <= K; ++b) part[b] = 0.0f;
         if (my >= 0) {
-          if (pre) attention_coefficients_head_pre<H, K>(self_idx, hh, hid, has, eraw, adv[i], a.V, part);
+          if (pre) attention_coefficients_head_pre<H, K>(self_idx, hh, hid, has, eraw, adv[i], vpre[i], part);
           else attention_coefficients_head<H, K>(my, self_idx, hh, hid, has, a.asd, a.eattr, a.V, a.ED, part);
         }
 #pragma unroll

@@ -228,16 +228,13 @@ __device__ __forceinline__ void attention_coefficients_head(int my, int self_idx
 }
 
 // attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
-// edge-attribute block, `ad` = its alpha_dst for head hh.  Lets the caller issue those global loads before the
+// edge-attribute block, `ad` = its alpha_dst for head hh, `v` = V[hh][0..2].  Lets the caller issue those global loads before the
 // halo ids are known (one latency less on the workgroup's critical path).
 template <int H, int K>
 __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, int hh, const int *hid, const float *has,
-                                                                const float (&eraw)[K * 3], float ad, const float *V,
+                                                                const float (&eraw)[K * 3], float ad, const float (&v)[3],
                                                                 float *out) {
   using Off = StencilOffsets<K>;
-  float v[3];
-#pragma unroll
-  for (int f = 0; f < 3; ++f) v[f] = V[hh * 3 + f];
   float ea_sum[3] = {0.f, 0.f, 0.f};
   int deg = 0;
   float mx = -__builtin_inff();

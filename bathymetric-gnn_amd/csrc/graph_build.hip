@@ -352,17 +352,16 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
     a.node_local_std[id] = nan_to_num_f32(lstd);
     // ---- in-edges: slot b <- source cell (r - dr[b], c - dc[b])  (:196-223, :329-376) ----
     const float dz_tgt = a.depth[idx];
-    for (int b = 0; b < st.K; ++b) {
+    auto edge_slot = [&](int b, int &sid, float (&ev)[4]) {
       const int sr = r - st.dr[b], sc = c - st.dc[b];
-      int sid = -1;
+      sid = -1;
       int64_t sidx = 0;
       if (sr >= 0 && sr < h && sc >= 0 && sc < w) {
         sidx = tb + (int64_t)sr * w + sc;
         sid = a.node_id[sidx];
         if (sid < 0) sid = -1;
       }
-      a.nbr[(int64_t)id * st.K + b] = sid;
-      float ev[4] = {0.f, 0.f, 0.f, 0.f};
+      ev[0] = ev[1] = ev[2] = ev[3] = 0.0f;
       if (sid >= 0) {
         const double dx = (double)st.dc[b] * t.rx;       // (tgt_c - src_c) * res_x
         const double dy = (double)st.dr[b] * t.ry;
@@ -379,7 +378,32 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
           ev[f] = v;
         }
       }
-      for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f];
+    };
+    if (st.K == 8 && a.ED == 3) {
+      // the usual shape: the node's stencil row (8 ids = 32 B) and attribute block (8 x 3 floats = 96 B) leave as
+      // whole 16-byte stores instead of 32 scattered dwords
+      int sids[8];
+      float evs[24];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        float ev[4];
+        edge_slot(b, sids[b], ev);
+        evs[3 * b] = ev[0]; evs[3 * b + 1] = ev[1]; evs[3 * b + 2] = ev[2];
+      }
+      int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * 8);
+      np[0] = make_int4(sids[0], sids[1], sids[2], sids[3]);
+      np[1] = make_int4(sids[4], sids[5], sids[6], sids[7]);
+      float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * 24);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) ep[q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+    } else {
+      for (int b = 0; b < st.K; ++b) {
+        int sid;
+        float ev[4];
+        edge_slot(b, sid, ev);
+        a.nbr[(int64_t)id * st.K + b] = sid;
+        for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f];
+      }
     }
   }
 }
