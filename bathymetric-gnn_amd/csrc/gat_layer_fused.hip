@@ -149,8 +149,18 @@ __device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k
 constexpr int FT_H = 8;                                  // fused kernel: 8 x 16 cell blocks
 constexpr int FHR = (FT_H + 2) * HALO_W;                 // 180 halo rows
 
+template <int HC, int C, int K, int NT, int EPI>
+struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and launcher agree through this)
+  static constexpr int H = HC / C, NC = NT * 32;
+  static constexpr int RA = FHR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : 0);
+  static constexpr int RSZ = RA > RB ? RA : RB;
+  static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
+  static constexpr int FLOATS = FHR * 32 + 32 * NC + RSZ + FHR + 4 + 128 * APITCH;
+};
+
 template <int HC, int C, int K, int NT, int EPI, int NS>
-__global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fused_kernel(FusedArgs a) {
+  // (narrow next stages leave registers and LDS for a third workgroup per CU)
   // 4*NS waves, two workgroups per CU.  Wave w: node group ng = w & 3 (cells 32ng..32ng+31, two tile rows) and,
   // for NS = 2, column half nh = w >> 2 of the NC output channels.  Lane (r, hl): node r of the group, k-half hl.
   // NS = 2 halves the accumulator (64 registers) so that 16 waves fit a CU: the two waves of a node group each
@@ -166,11 +176,15 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
   extern __shared__ __attribute__((aligned(128))) float lds[];
   float *slab = lds;                                   // [HR][32]  halo rows of the current slab, 16-B chunks XOR-swizzled
   float *wbuf = slab + HR * 32;                        // [32][NC]  W_{l+1} rows of the current slab
-  float *scsh = wbuf + 32 * NC;                        // [2][HC]   folded scale / shift
-  int *hid = reinterpret_cast<int *>(scsh + 2 * HC);   // [HR]
-  float *has = reinterpret_cast<float *>(hid + HR);    // [HR][H]
-  int *minid = reinterpret_cast<int *>(has + HR * H);  // [4]
-  float *alx = reinterpret_cast<float *>(minid + 4);   // [128][36]  alpha[cell][head][K+1]
+  // Region R is time-shared: alpha_src of the halo rows during phase A, then (from the first slab barrier on)
+  // the folded scale / shift table and, behind it, the next layer's att_src | att_dst for the epilogue.
+  constexpr int RSZ = FusedLds<HC, C, K, NT, EPI>::RSZ, APITCH = FusedLds<HC, C, K, NT, EPI>::APITCH;
+  float *has = wbuf + 32 * NC;                         // [HR][H]   (phase A)
+  float *scsh = has;                                   // [2][HC]   folded scale / shift (slab loop)
+  float *attr = has + 2 * HC;                          // [2][NC]   att_src | att_dst (epilogue, EPI_NEXT)
+  int *hid = reinterpret_cast<int *>(has + RSZ);       // [HR]
+  int *minid = hid + HR;                               // [4]
+  float *alx = reinterpret_cast<float *>(minid + 4);   // [128][APITCH]  alpha[cell][head][K+1]
 
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
   const BlockPos pos = decode_block<FT_H>(a.tb);
@@ -199,7 +213,13 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
   }
   // rows without a node are never written by the DMA: zero them once
   for (int i = tid; i < HR * 8; i += NTH) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < HC; i += NTH) { scsh[i] = a.scale[i]; scsh[HC + i] = a.shift[i]; }
+  constexpr int NSC = (HC + NTH - 1) / NTH;
+  float scv[NSC], shv[NSC];                             // folded scale / shift: to LDS once phase A has released R
+#pragma unroll
+  for (int i = 0; i < NSC; ++i) {
+    const int c = tid + i * NTH;
+    scv[i] = c < HC ? a.scale[c] : 0.0f; shv[i] = c < HC ? a.shift[c] : 0.0f;
+  }
   if (hid_v < 0) hid_v = -1;
   float eraw[K * 3], adv[NHL], hasv[H], vpre[NHL][3];
 #pragma unroll
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
           else attention_coefficients_head<H, K>(my, self_idx, hh, hid, has, a.asd, a.eattr, a.V, a.ED, part);
         }
 #pragma unroll
-        for (int b = 0; b <= K; ++b) alx[cell * TILED_PITCH + hh * (K + 1) + b] = part[b];
+        for (int b = 0; b <= K; ++b) alx[cell * APITCH + hh * (K + 1) + b] = part[b];
       }
     }
     // (consumers wait at the barrier at the top of the slab loop)
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
   const uint32_t slab0 = lds_addr(slab);
   const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + nh * NTL * 32 + r);
   const uint32_t scsh0 = lds_addr(scsh) + hl * 16;
-  const uint32_t alx0 = lds_addr(alx + cell * TILED_PITCH);
+  const uint32_t alx0 = lds_addr(alx + cell * APITCH);
 
   // ---- slabs.  Lane (r, hl) gathers exactly the 16 values it feeds to the MFMA as B operand: channel chunks
   // 2j + hl (j = 0..3) of node r, i.e. k = 8j + 4hl + i of k-step j -- no LDS round trip, no lane exchange.
@@ -317,12 +337,20 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
       // (when the pieces do not divide evenly some waves issue one more: the floor only makes their wait conservative)
       wait_vm_lgkm<2 * WH>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
-      if (EPI == EPI_NEXT && s == 0 && wave < 2) {
-        // phase A is over on every wave: `has` is dead.  Park the next layer's att_src | att_dst there for the
-        // epilogue (one more VM op behind WB(0) on waves 0/1: the counted waits below only get more conservative).
-        if (lane * 4 < NC)
+      if (s == 0) {
+        // phase A is over on every wave: R changes hands.  Scale / shift from the registers they waited in; the
+        // next layer's att_src | att_dst by DMA (one more VM op behind WB(0) on waves 0/1: the counted waits below
+        // only get more conservative).
+#pragma unroll
+        for (int i = 0; i < NSC; ++i) {
+          const int c = tid + i * NTH;
+          if (c < HC) { scsh[c] = scv[i]; scsh[HC + c] = shv[i]; }
+        }
+        if (EPI == EPI_NEXT && wave < 2 && lane * 4 < NC)
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>((wave == 0 ? a.att_src : a.att_dst) + lane * 4),
-                                           (__attribute__((address_space(3))) void *)(has + wave * NC), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void *)(attr + wave * NC), 16, 0, 0);
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();                   // scale / shift visible
       }
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
@@ -383,8 +411,7 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
     }
   }
 
-  static_assert(EPI != EPI_NEXT || HR * H >= 2 * NC, "att_src | att_dst are parked in the halo alpha_src table");
-  const float *attl = has;                              // att_src | att_dst (DMA'd there during slab 0)
+  const float *attl = attr;                             // att_src | att_dst (DMA'd there during slab 0)
   // NS == 1: the store patches below stay inside the slab region, which every wave left at the last slab's second
   // barrier -- a wave goes straight from its last MFMA into its own epilogue.  NS == 2: the patches reach into wbuf.
   if (EPI == EPI_NEXT && NS > 1) __syncthreads();
@@ -543,7 +570,7 @@ __global__ __launch_bounds__(256 * NS, 2 * NS) void gat_layer_fused_kernel(Fused
 template <int HC, int C, int K, int NT, int EPI, int NS = 1>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr int H = HC / C;
-  constexpr size_t lds_bytes = (size_t)(FHR * 32 + 32 * NT * 32 + 2 * HC + FHR + FHR * H + 4 + 128 * TILED_PITCH) * 4;
+  constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI>::FLOATS * 4;
   static bool configured = false;     // per instantiation
   auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS>;
   size_t lds_launch = lds_bytes;
