@@ -137,6 +137,7 @@ __device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k
   constexpr int NC = NT * 32;
   const char *src = reinterpret_cast<const char *>(Wt + (int64_t)k0 * NC);
   constexpr int NQ = ROWS * NT / 8;
+  if (NW > 4) asm volatile("" : "+v"(lane));          // 128-register budget: do not keep per-piece 64-bit offsets alive
 #pragma unroll
   for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
     const int q = j * NW + wave;
@@ -354,13 +355,15 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       }
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
+      int sidx = self_idx;
+      if (NS > 1) asm volatile("" : "+v"(sidx));        // 128-register budget: re-derive the 9 row addresses per slab
       f32x4 g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (!(a.dbg & 1))
 #pragma unroll
       for (int b = 0; b <= K; ++b) {
-        const int nidx = b == K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
+        const int nidx = b == K ? sidx : sidx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
         // slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5))
         const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ hl) << 4);
         f32x4 x[4];
