@@ -196,12 +196,20 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   const int tr = cell / TILE_W, tc = cell % TILE_W;
   const int self_idx = (tr + 1) * HW_ + tc + 1;
 
+  // W rows of slab 0 depend on nothing: first in the VM queue.
+  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, 0, wave, lane);
+  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, 16, wave, lane);
+
   // Prologue loads, two dependent rounds with everything of a round in flight together:
-  //   round 1: node id of this thread's halo row (HR <= NTH: one row per thread) and of this lane's own cell;
+  //   round 1: node id of this thread's halo row (HR <= NTH: one row per thread), of this lane's own cell, and of
+  //            the <= NPIECE halo rows whose chunks this thread moves by DMA (8 lanes share a row);
+  //   -> slab 0's DMA is issued straight from those registers (no LDS round trip, no barrier);
   //   round 2: alpha_src of the halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...
   //            for NS = 1) -- consumed in phase A, so their latency hides behind the halo bookkeeping.
   static_assert(HR <= NTH, "one halo row per thread");
   constexpr int NHL = (H + 2 * NS - 1) / (2 * NS);      // heads per lane
+  constexpr int NPIECE = (HR * 8 + NTH - 1) / NTH;
+  static_assert((NPIECE - 2) * NTH + NTH - 64 < HR * 8, "every wave moves NPIECE or NPIECE - 1 pieces");
   const bool pre = a.ED == 3 && !(a.dbg & 32);
   int my_pre = -1, hid_v = -1;
   {
@@ -212,8 +220,14 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
     const int gr = pos.r0 + tr, gc = pos.c0 + tc;
     if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
-  // rows without a node are never written by the DMA: zero them once
-  for (int i = tid; i < HR * 8; i += NTH) *reinterpret_cast<f32x4 *>(slab + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int drow[NPIECE];
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) {
+    const int row = (p * NTH + tid) >> 3;
+    const int gr = pos.r0 + row / HW_ - 1, gc = pos.c0 + row % HW_ - 1;
+    drow[p] = -1;
+    if (row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) drow[p] = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
+  }
   constexpr int NSC = (HC + NTH - 1) / NTH;
   float scv[NSC], shv[NSC];                             // folded scale / shift: to LDS once phase A has released R
 #pragma unroll
@@ -221,14 +235,57 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
     const int c = tid + i * NTH;
     scv[i] = c < HC ? a.scale[c] : 0.0f; shv[i] = c < HC ? a.shift[c] : 0.0f;
   }
-  if (hid_v < 0) hid_v = -1;
-  float eraw[K * 3], adv[NHL], hasv[H], vpre[NHL][3];
+  float vpre[NHL][3];
 #pragma unroll
   for (int i = 0; i < NHL; ++i) {
     const int hh = nh * 2 + hl + i * 2 * NS;
 #pragma unroll
     for (int f = 0; f < 3; ++f) vpre[i][f] = (pre && hh < H) ? a.V[hh * 3 + f] : 0.0f;
   }
+
+  // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B;
+  // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk
+  // p ^ ((row >> 1) & 7).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
+  // offsets (32 bits, relative to the smallest node id this WAVE touches) are computed once.
+  int id0;
+  {
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) if (drow[p] >= 0 && drow[p] < m) m = drow[p];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o));
+    id0 = __builtin_amdgcn_readfirstlane(m);             // 0x7fffffff: the wave's rows hold no node
+  }
+  uint32_t doff[NPIECE];
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) {
+    const int idx = p * NTH + tid;
+    const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
+    doff[p] = drow[p] >= 0 ? (uint32_t)(drow[p] - id0) * (uint32_t)(HC * 4) + (uint32_t)(c * 16) : 0xffffffffu;
+  }
+  const char *xbase = reinterpret_cast<const char *>(a.xw + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * HC);
+  // Rows without a node read the context's zero page, so that EVERY wave issues a fixed number of slab pieces
+  // (npc: 6 / 6 / 6 / 5 for NTH = 256) and the counted waits below can leave exactly the next slab in flight.
+  const char *zp = reinterpret_cast<const char *>(a.zero_page);
+  int npc = 0;
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) npc += (p * NTH + wave * 64 < HR * 8) ? 1 : 0;
+  auto issue_slab = [&](int s) {
+    const char *sb = xbase + s * 128;                  // wave-uniform
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      if (p * NTH + tid < HR * 8) {
+        const char *src = doff[p] != 0xffffffffu ? sb + doff[p] : zp;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src),
+                                         (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
+      }
+    }
+  };
+  issue_slab(0);
+  BGNN_STAMP(0)   // round 1, slab 0 issued
+
+  if (hid_v < 0) hid_v = -1;
+  float eraw[K * 3], adv[NHL], hasv[H];
 #pragma unroll
   for (int hh = 0; hh < H; ++hh) hasv[hh] = hid_v >= 0 ? a.asd[(int64_t)hid_v * 2 * H + hh] : 0.0f;
   if (my_pre >= 0) {
@@ -249,48 +306,8 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hasv[hh];
   }
-  {
-    static_assert(HR <= 192, "halo rows live in waves 0-2");
-    int m = hid_v >= 0 ? hid_v : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o));
-    if (lane == 0 && wave < 3) minid[wave] = m;
-  }
   __syncthreads();
-  BGNN_STAMP(0)   // halo ids, zero fill, min id
-  // smallest node id of the halo (0x7fffffff: block has no node); the halo rows sit in waves 0-2
-  const int id0 = min(min(minid[0], minid[1]), minid[2]);
-
-  // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B;
-  // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk
-  // p ^ ((row >> 1) & 7).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
-  // offsets (relative to node id0, 32 bits) are computed once.
-  constexpr int NPIECE = (HR * 8 + NTH - 1) / NTH;
-  uint32_t doff[NPIECE];
-#pragma unroll
-  for (int p = 0; p < NPIECE; ++p) {
-    const int idx = p * NTH + tid;
-    doff[p] = 0xffffffffu;
-    if (idx < HR * 8) {
-      const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
-      const int id = hid[row];
-      if (id >= 0) doff[p] = (uint32_t)(id - id0) * (uint32_t)(HC * 4) + (uint32_t)(c * 16);
-    }
-  }
-  const char *xbase = reinterpret_cast<const char *>(a.xw + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * HC);
-  auto issue_slab = [&](int s) {
-    const char *sb = xbase + s * 128;                  // wave-uniform
-#pragma unroll
-    for (int p = 0; p < NPIECE; ++p) {
-      if (doff[p] != 0xffffffffu)
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(sb + doff[p]),
-                                         (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
-    }
-  };
-  issue_slab(0);
-  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, 0, wave, lane);
-  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, 16, wave, lane);
-  BGNN_STAMP(1)   // DMA offsets + first issue
+  BGNN_STAMP(1)   // round 2, halo tables in LDS
 
   // ---- phase A: attention coefficients -> LDS.  The 2*NS lanes that share a cell (lane halves x column halves)
   // take the heads round-robin.
@@ -336,7 +353,8 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       // counted on: a wait that must cover a W half uses only the W pieces issued after it.
       constexpr int WH = (16 * NT / 8) / (4 * NS);       // pieces per wave in one W half
       // (when the pieces do not divide evenly some waves issue one more: the floor only makes their wait conservative)
-      wait_vm_lgkm<2 * WH>();
+      if (s == 0) wait_vm_lgkm<0>();                    // (slab 0 was queued BEHIND its W rows: wait for everything)
+      else wait_vm_lgkm<2 * WH>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
       if (s == 0) {
         // phase A is over on every wave: R changes hands.  Scale / shift from the registers they waited in; the
@@ -400,7 +418,9 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
       // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
       if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
-      wait_vm_lgkm<0>();                                // WB(s) landed (and, conservatively, slab s+1)
+      // WB(s) landed; the npc pieces of slab s+1 issued above stay in flight
+      if (s + 1 < NSLAB && !(a.dbg & 4)) { if (npc == NPIECE) wait_vm_lgkm<NPIECE>(); else wait_vm_lgkm<NPIECE - 1>(); }
+      else wait_vm_lgkm<0>();
       __builtin_amdgcn_s_barrier();                     // every wave is done with W rows 0-15
       if (s + 1 < NSLAB && !(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
       if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
