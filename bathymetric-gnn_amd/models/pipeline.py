@@ -162,6 +162,75 @@ class TileBatchEngine:
         return results
 
 
+class HostTilePipeline:
+    """Host tiles in, host grids out, with both PCIe crossings overlapped with compute.
+
+    The reference's ``_process_tile`` hands host arrays across the boundary one tile at a time
+    (models/pipeline.py:253-262 ``.to(device)``, :288-295 ``.cpu()``).  Here a batch of equally sized tiles
+    is staged in pinned host memory, copied on a dedicated H2D stream, classified on the engine's stream and
+    copied back on a D2H stream; ``depth`` slots (default 2) of pinned + device buffers let batch i+1 upload
+    and batch i-1 download while batch i computes.  ``submit`` enqueues a batch and returns the result of the
+    batch submitted ``depth`` calls earlier (or None); ``drain`` yields what is still in flight, in order.
+    Result arrays are views of the slot's pinned buffer: valid until that slot is submitted again."""
+
+    def __init__(self, engine: TileBatchEngine, n_tiles: int, h: int, w: int, with_uncertainty: bool = False,
+                 resolution=(1.0, 1.0), depth: int = 2):
+        self.eng, self.ctx = engine, engine.ctx
+        dev = self.ctx.device
+        self.n, self.h, self.w = int(n_tiles), int(h), int(w)
+        self.cells = self.n * self.h * self.w
+        self.hw = np.tile(np.array([[h, w]], np.int32), (self.n, 1))
+        self.res = np.tile(np.array([[float(resolution[0]), float(resolution[1])]], np.float64), (self.n, 1))
+        self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        mk = lambda dt, shape=None: torch.empty(shape or self.cells, dtype=dt, device=dev)
+        pin = lambda dt, shape=None: torch.empty(shape or self.cells, dtype=dt, pin_memory=True)
+        self.slots = []
+        for _ in range(depth):
+            self.slots.append({
+                "h_depth": pin(torch.float32), "h_mask": pin(torch.uint8), "h_unc": pin(torch.float32) if with_uncertainty else None,
+                "d_depth": mk(torch.float32), "d_mask": mk(torch.uint8), "d_unc": mk(torch.float32) if with_uncertainty else None,
+                "d_out": mk(torch.float32, (3, self.cells)), "h_out": pin(torch.float32, (3, self.cells)),
+                "up": torch.cuda.Event(), "done": torch.cuda.Event(), "down": torch.cuda.Event(), "busy": False, "tag": None})
+        self.i = 0
+
+    def _result(self, slot):
+        slot["down"].synchronize()
+        slot["busy"] = False
+        o = slot["h_out"].numpy().reshape(3, self.n, self.h, self.w)
+        return slot["tag"], {"classification": o[0], "confidence": o[1], "correction": o[2]}
+
+    def submit(self, depth: np.ndarray, mask: np.ndarray, unc: Optional[np.ndarray] = None, tag=None):
+        slot = self.slots[self.i % len(self.slots)]
+        self.i += 1
+        ready = self._result(slot) if slot["busy"] else None       # also: its device/pinned buffers are free again
+        slot["h_depth"].numpy()[:] = np.asarray(depth, np.float32).reshape(-1)
+        slot["h_mask"].numpy()[:] = np.asarray(mask).reshape(-1).view(np.uint8)
+        if slot["h_unc"] is not None:
+            slot["h_unc"].numpy()[:] = np.asarray(unc, np.float32).reshape(-1)
+        with torch.cuda.stream(self.h2d):
+            slot["d_depth"].copy_(slot["h_depth"], non_blocking=True)
+            slot["d_mask"].copy_(slot["h_mask"], non_blocking=True)
+            if slot["h_unc"] is not None:
+                slot["d_unc"].copy_(slot["h_unc"], non_blocking=True)
+            slot["up"].record(self.h2d)
+        with torch.cuda.stream(self.ctx.stream):                   # the engine orders its work behind the current stream
+            self.ctx.stream.wait_event(slot["up"])
+            self.eng.infer_device(self.hw, self.res, slot["d_depth"], slot["d_mask"], slot["d_unc"], out=slot["d_out"])
+            slot["done"].record(self.ctx.stream)
+        with torch.cuda.stream(self.d2h):
+            self.d2h.wait_event(slot["done"])
+            slot["h_out"].copy_(slot["d_out"], non_blocking=True)
+            slot["down"].record(self.d2h)
+        slot["busy"], slot["tag"] = True, tag
+        return ready
+
+    def drain(self):
+        for k in range(len(self.slots)):
+            slot = self.slots[(self.i + k) % len(self.slots)]
+            if slot["busy"]:
+                yield self._result(slot)
+
+
 class BathymetricPipeline:
     """Complete inference pipeline (reference ``BathymetricPipeline``, models/pipeline.py:36-382)."""
 

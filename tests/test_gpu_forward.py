@@ -288,3 +288,27 @@ def test_k16_dilated_extension(gpu_device):
     assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
     sd = synthetic.synthetic_state_dict(seed=1234)
     _compare(_model(sd).predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
+
+
+def test_host_tile_pipeline_matches_blocking_path(gpu_device):
+    """Pinned, double-buffered H2D / compute / D2H pipeline == the blocking host path, batch by batch, in order."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import HostTilePipeline, TileBatchEngine
+    sd = synthetic.synthetic_state_dict(in_channels=8, seed=1234)
+    eng = TileBatchEngine(_model(sd, in_channels=8), GraphBuilder(device=gpu_device), gpu_device)
+    n, h, w = 3, 40, 56
+    hp = HostTilePipeline(eng, n, h, w, with_uncertainty=True, resolution=(0.5, 1.0))
+    batches = [synthetic.synthetic_tile_batch(n, h, w, 500 + 10 * i, "V1", True) for i in range(5)]
+    got = []
+    for i, (d, m, u) in enumerate(batches):
+        r = hp.submit(d, m, u, tag=i)
+        if r is not None:
+            got.append((r[0], {k: v.copy() for k, v in r[1].items()}))
+    got += [(t, {k: v.copy() for k, v in r.items()}) for t, r in hp.drain()]
+    assert [t for t, _ in got] == list(range(5))
+    for (t, r), (d, m, u) in zip(got, batches):
+        ref = eng.infer(list(d), list(m), list(u), [(0.5, 1.0)] * n)
+        for k in range(n):
+            for ch in ("classification", "confidence", "correction"):
+                assert np.array_equal(r[ch][k].view(np.uint32), ref[k][ch].view(np.uint32)), (t, k, ch)
