@@ -319,6 +319,21 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     return BGNN_ERR_INVALID;
   }
 
+  // LocalFeatureExtractor ends in a Linear without activation (gnn.py:52-68) and GATConv's lin follows directly:
+  // y = z W1^T + b1, xw = y W0^T  ==>  xw = z (W1^T W0^T) + b1 W0^T.  Folded in float64, one GEMM less per forward.
+  const int HC0 = (L > 1 ? d->heads : 1) * hid;
+  size_t o_l0f_Wt = reserve((size_t)hid * HC0), o_l0f_b = reserve(HC0);
+  for (int o = 0; o < HC0; ++o) {
+    for (int i = 0; i < hid; ++i) {
+      double s = 0.0;
+      for (int k = 0; k < hid; ++k) s += (double)pk[o_fe_W1t + (size_t)i * hid + k] * (double)pk[lo[0].Wt + (size_t)k * HC0 + o];
+      pk[o_l0f_Wt + (size_t)i * HC0 + o] = (float)s;
+    }
+    double s = 0.0;
+    for (int k = 0; k < hid; ++k) s += (double)pk[o_fe_b1 + k] * (double)pk[lo[0].Wt + (size_t)k * HC0 + o];
+    pk[o_l0f_b + o] = (float)s;
+  }
+
   bgnn_model *m = new bgnn_model();
   m->ctx = ctx; m->desc = *d; m->blob_floats = pk.size();
   hipError_t e = hipMalloc((void **)&m->blob, pk.size() * sizeof(float));
@@ -326,6 +341,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   e = hipMemcpy(m->blob, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(m->blob); delete m; set_error("hipMemcpy(model) failed: %s", hipGetErrorString(e)); return BGNN_ERR_HIP; }
   m->fe_W0t = m->blob + o_fe_W0t; m->fe_b0 = m->blob + o_fe_b0; m->fe_W1t = m->blob + o_fe_W1t; m->fe_b1 = m->blob + o_fe_b1;
+  m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
   m->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     const bool last = l == L - 1;
@@ -555,12 +571,18 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   const int64_t *dm = g->d_counts;
   const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr;
   // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid); then lin of layer 0
-  BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
-  BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));
   {
     const BgnnLayer &L0 = m->layers[0];
-    BGNN_TRY(launch_gemm_f32(ctx, Y, L0.d_in, L0.Wt, nullptr, X, L0.heads * hid, dm, rows, L0.d_in, L0.heads * hid, 0,
-                             L0.att_src, L0.att_dst, asdX, L0.heads, hid));
+    if (getenv("BGNN_NO_FOLD") == nullptr) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
+      BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
+      BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
+                               L0.att_src, L0.att_dst, asdX, L0.heads, hid));
+    } else {
+      BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
+      BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));
+      BGNN_TRY(launch_gemm_f32(ctx, Y, L0.d_in, L0.Wt, nullptr, X, L0.heads * hid, dm, rows, L0.d_in, L0.heads * hid, 0,
+                               L0.att_src, L0.att_dst, asdX, L0.heads, hid));
+    }
   }
   // GNN backbone (gnn.py:173-188).  Invariant at the top of each iteration: X = lin_l(h_l), asdX = its dots.
   const size_t nl = m->layers.size();

@@ -104,6 +104,7 @@ struct bgnn_model {
   float *blob = nullptr;      // one device allocation holding everything below
   size_t blob_floats = 0;
   float *fe_W0t, *fe_b0, *fe_W1t, *fe_b1;     // [in8][hid], [hid], [hid][hid], [hid]
+  float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
   std::vector<BgnnLayer> layers;
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]

@@ -144,6 +144,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
     const uint32_t asl = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)(attl + 4 * h);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      float4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v[g] = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4 *>(a.bias + t * 32 + 8 * g + 4 * h);
+          v[g].x += b.x; v[g].y += b.y; v[g].z += b.z; v[g].w += b.w;
+        }
+        if (a.relu) {
+          v[g].x = v[g].x > 0.f ? v[g].x : 0.f; v[g].y = v[g].y > 0.f ? v[g].y : 0.f;
+          v[g].z = v[g].z > 0.f ? v[g].z : 0.f; v[g].w = v[g].w > 0.f ? v[g].w : 0.f;
+        }
+      }
       if (ATT) {
         // asm reads + an explicit wait per tile: left to the scheduler the 8*NT att reads are hoisted above the
         // stores and, next to the live accumulators, spilled -- and a scratch reload waits for the stores in flight
@@ -158,25 +171,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
         float ps = 0.0f, pd = 0.0f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          ps += acc[t][4 * g] * s4[g].x + acc[t][4 * g + 1] * s4[g].y + acc[t][4 * g + 2] * s4[g].z + acc[t][4 * g + 3] * s4[g].w;
-          pd += acc[t][4 * g] * d4[g].x + acc[t][4 * g + 1] * d4[g].y + acc[t][4 * g + 2] * d4[g].z + acc[t][4 * g + 3] * d4[g].w;
+          ps += v[g].x * s4[g].x + v[g].y * s4[g].y + v[g].z * s4[g].z + v[g].w * s4[g].w;
+          pd += v[g].x * d4[g].x + v[g].y * d4[g].y + v[g].z * d4[g].z + v[g].w * d4[g].w;
         }
         asm volatile("" : "+v"(ps), "+v"(pd));      // due here, not sunk below the stores
         pts[t] = ps; ptd[t] = pd;
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-        if (a.bias) {
-          const float4 b = *reinterpret_cast<const float4 *>(a.bias + t * 32 + 8 * g + 4 * h);
-          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        }
-        if (a.relu) {
-          v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-          v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-        }
-        *reinterpret_cast<float4 *>(patch + r * 36 + 8 * g + 4 * h) = v;
-      }
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(patch + r * 36 + 8 * g + 4 * h) = v[g];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k)

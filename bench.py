@@ -33,7 +33,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA (= vector fp32 peak)
 def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3):
     """SURVEY.md 8(d) per-node figures (fp32, compulsory traffic: each tensor read once + written once)."""
     agg_bytes = 0
-    gemm_flops = 2 * (in_ch * hidden + hidden * hidden)            # feature extractor
+    gemm_flops = 2 * (in_ch * hidden)                              # feature extractor layer 1 (layer 2 is folded into lin_0: executed flops)
     gemm_bytes = 4 * (8 + hidden) + 4 * (hidden + hidden)
     for l in range(num_layers):
         last = l == num_layers - 1
@@ -51,7 +51,9 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
     # fused path: launch l = aggregate of layer l + GEMM of layer l+1 (last: + heads + grid scatter);
     # the front GEMMs (feature extractor + lin of layer 0) stay separate
     fused_flops, fused_bytes = 0, 0
-    front_flops = 2 * (in_ch * hidden + hidden * hidden + hidden * (hidden * (heads if num_layers > 1 else 1)))
+    # executed flops: the extractor's second Linear is folded into lin of layer 0 (no activation between them), so the
+    # hidden x hidden product of the reference is not run
+    front_flops = 2 * (in_ch * hidden + hidden * (hidden * (heads if num_layers > 1 else 1)))
     for l in range(num_layers):
         last = l == num_layers - 1
         H = 1 if last else heads
@@ -228,7 +230,7 @@ def main():
                                        "K4 gather-softmax-aggregate fused with the next layer's exact-f32 MFMA GEMM (last: heads + scatter)")
             roofs["fused_hbm"] = roof("gat_layer_fused_kernel", "fused", "hbm", am["fused_bytes"],
                                       "same launches priced by compulsory HBM bytes (read xW + attrs, write next xW)")
-            roofs["front_gemm"] = roof("gemm_f32_kernel", "gemm", "mfma", am["front_flops"], "feature extractor + lin of layer 0")
+            roofs["front_gemm"] = roof("gemm_f32_kernel", "gemm", "mfma", am["front_flops"], "feature extractor layer 1, then extractor layer 2 folded into lin of layer 0 (executed flops)")
         else:
             roofs["aggregate_hbm"] = roof("gat_aggregate_tiled_kernel", "aggregate", "hbm", am["aggregate_bytes"],
                                           "standalone K4 (LDS-tiled gather-softmax-aggregate + BN + ReLU)")
