@@ -18,6 +18,7 @@
 //   * The product is computed TRANSPOSED (W fragment as the A operand, X fragment as B): each lane
 //     then holds 16 output CHANNELS of ONE row (4 groups of 4 consecutive channels), so bias /
 //     ReLU / the attention dot products are in-lane work and stores are float4.
+#include <stdlib.h>
 #include "bgnn_internal.h"
 
 namespace bgnn {
@@ -38,6 +39,7 @@ struct GemmArgs {
   float *asd;             // [M][2H]
   float *dump;            // >= 1 KiB scratch row for rows >= M (branch-free stores)
   int ldx, ldy, K, relu, H, C;
+  int dbg;                // diagnostic ablations (BGNN_GEMM_DBG): 1 = no row stores, 2 = no MFMAs, 4 = no X loads
 };
 
 template <int NT>
@@ -206,6 +208,159 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
   }
 }
 
+// ---- W-resident persistent form (K = 64: the folded extractor-2 x lin_0 GEMM) ----------------------------------
+// The whole Wt [64][NC] (64 KiB at NC = 256) is staged into LDS ONCE per workgroup; 8 waves then walk the row blocks
+// (32 rows each, stride = grid) with no barrier at all: X fragments come per lane from global memory, the epilogue
+// (bias / ReLU / attention dots / LDS-transposed row stores) is the one above.  Against the chunked kernel this
+// drops the per-128-rows re-staging of W (65 536 x 64 KiB of L2 -> LDS traffic per launch) and every barrier.
+// Ablations (BGNN_GEMM_DBG, 8.4 M rows, NC = 256): 3.5 ms as is; 2.3 ms without the MFMAs (= 11 GB at 4.8 TB/s: the
+// memory side alone is HBM-bound); 1.75 ms is the MFMA floor; 4 instead of 8 waves per CU: 4.6 ms.  With two waves per
+// SIMD (128 accumulators each) the two phases overlap only partly; a start stagger of the second wave changes nothing.
+template <int NT, bool ATT>
+__global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
+  constexpr int NC = NT * 32, K = 64;
+  extern __shared__ __attribute__((aligned(128))) float wres_lds[];
+  float *wl = wres_lds;                              // [64][NC]
+  constexpr int PP = 68;                              // patch pitch: two 32-column tiles side by side + 4 pad
+  float *patches = wl + K * NC;                      // [8][32 * PP]
+  float *attl = patches + 8 * 32 * PP;               // [2][NC]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int NW = blockDim.x >> 6;                    // 8 (4 only in the occupancy experiment)
+  {
+    const char *src = reinterpret_cast<const char *>(a.Wt);
+    constexpr int NQ = K * NC * 4 / 1024;            // 1-KiB pieces
+    for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
+      const int q = j * NW + wave;
+      if (q < NQ)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(wl + q * 256), 16, 0, 0);
+    }
+    if (ATT)
+      for (int i = threadIdx.x; i < NC; i += blockDim.x) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
+  }
+  __syncthreads();                                   // (vmcnt(0): W has landed)
+  const int64_t M = *a.d_m;
+  float *patch = patches + wave * (32 * PP);
+  const uint32_t asl = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)(attl + 4 * h);
+  const int64_t stride = (int64_t)gridDim.x * NW * 32;
+  int64_t row0 = (int64_t)blockIdx.x * NW * 32 + wave * 32;
+  float4 ax[K / 8];
+  auto load_x = [&](int64_t rb) {
+    const int64_t row = rb + r;
+    const float *xp = a.X + (row < M ? row : M - 1) * a.ldx + 4 * h;
+#pragma unroll
+    for (int s = 0; s < K / 8; ++s) ax[s] = *reinterpret_cast<const float4 *>(xp + s * 8);
+  };
+  if (row0 < M) load_x(row0);
+  for (; row0 < M; row0 += stride) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    if (!(a.dbg & 2))
+#pragma unroll
+    for (int s = 0; s < K / 8; ++s) {
+      const float av[4] = {ax[s].x, ax[s].y, ax[s].z, ax[s].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float *wrow = wl + (s * 8 + 4 * h + i) * NC + r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 32], av[i], acc[t], 0, 0, 0);
+      }
+    }
+    if (row0 + stride < M && !(a.dbg & 4)) load_x(row0 + stride);    // next block's X flies under this block's epilogue
+    // stores leave as 256-byte row segments (two tiles side by side in the patch): 16 lanes x 16 B per row, 4 rows per
+    // instruction -- half as many separate DRAM bursts per 1-KiB output row as 128-byte segments
+    static_assert(NT % 2 == 0, "tiles are stored in pairs");
+    float *dst[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t rr = row0 + (lane >> 4) + 4 * k;
+      dst[k] = (rr < M ? a.Y + rr * a.ldy : a.dump) + (lane & 15) * 4;
+    }
+    float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v[g] = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4 *>(a.bias + t * 32 + 8 * g + 4 * h);
+          v[g].x += b.x; v[g].y += b.y; v[g].z += b.z; v[g].w += b.w;
+        }
+        if (a.relu) {
+          v[g].x = v[g].x > 0.f ? v[g].x : 0.f; v[g].y = v[g].y > 0.f ? v[g].y : 0.f;
+          v[g].z = v[g].z > 0.f ? v[g].z : 0.f; v[g].w = v[g].w > 0.f ? v[g].w : 0.f;
+        }
+      }
+      if (ATT) {
+        f32x4 s4[4], d4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(s4[g]) : "v"(asl + (t * 32 + 8 * g) * 4));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(d4[g]) : "v"(asl + (NC + t * 32 + 8 * g) * 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float ps = 0.0f, pd = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ps += v[g].x * s4[g].x + v[g].y * s4[g].y + v[g].z * s4[g].z + v[g].w * s4[g].w;
+          pd += v[g].x * d4[g].x + v[g].y * d4[g].y + v[g].z * d4[g].z + v[g].w * d4[g].w;
+        }
+        asm volatile("" : "+v"(ps), "+v"(pd));
+        pts[t] = ps; ptd[t] = pd;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(patch + r * PP + (t & 1) * 32 + 8 * g + 4 * h) = v[g];
+      __builtin_amdgcn_sched_barrier(0);
+      if ((t & 1) && !(a.dbg & 1)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          *reinterpret_cast<float4 *>(dst[k] + (t - 1) * 32) =
+              *reinterpret_cast<const float4 *>(patch + ((lane >> 4) + 4 * k) * PP + (lane & 15) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ATT) {
+      const int64_t row = row0 + r;
+      const int H = a.H, tph = a.C / 32;
+      for (int hd = 0; hd < H; ++hd) {
+        float ps = 0.0f, pd = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (t / tph == hd) { ps += pts[t]; pd += ptd[t]; }
+        ps += __shfl_xor(ps, 32);
+        pd += __shfl_xor(pd, 32);
+        if (row < M && h == 0) {
+          a.asd[row * 2 * H + hd] = ps;
+          a.asd[row * 2 * H + H + hd] = pd;
+        }
+      }
+    }
+  }
+}
+
+template <int NT, bool ATT>
+static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
+  constexpr size_t lds_bytes = (size_t)(64 * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
+  static bool configured = false;
+  auto kern = gemm_wres64_kernel<NT, ATT>;
+  if (!configured) {
+    BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    configured = true;
+  }
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  static const int nw = getenv("BGNN_GEMM_WAVES") ? atoi(getenv("BGNN_GEMM_WAVES")) : 8;
+  hipLaunchKernelGGL(kern, dim3(ctx->num_cus * per_cu), dim3(64 * nw), lds_bytes, ctx->stream, a);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
                     const float *att_dst, float *asd, int H, int C) {
@@ -214,7 +369,17 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
-  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C};
+  static const int gemm_dbg = getenv("BGNN_GEMM_DBG") ? atoi(getenv("BGNN_GEMM_DBG")) : 0;
+  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg};
+  static const bool no_wres = getenv("BGNN_NO_WRES") != nullptr;
+  if (K == 64 && !no_wres && max_rows >= 65536) {    // W-resident persistent form
+    switch (NC / 32) {
+#define BGNN_WRES_CASE(NT) case NT: return att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
+      BGNN_WRES_CASE(2) BGNN_WRES_CASE(8)
+#undef BGNN_WRES_CASE
+      default: break;
+    }
+  }
   dim3 grid((unsigned)((max_rows + 127) / 128)), block(256);
 #define BGNN_GEMM_CASE(NT)                                                                         \
   case NT:                                                                                         \
