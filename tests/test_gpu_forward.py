@@ -312,3 +312,29 @@ def test_host_tile_pipeline_matches_blocking_path(gpu_device):
         for k in range(n):
             for ch in ("classification", "confidence", "correction"):
                 assert np.array_equal(r[ch][k].view(np.uint32), ref[k][ch].view(np.uint32)), (t, k, ch)
+
+
+@pytest.mark.parametrize("conn,loops", [("4-connected", False), ("4-connected", True), ("8-connected", True)])
+def test_four_connected_and_self_loops(conn, loops, gpu_device):
+    """K = 4 instances of the tiled / fused kernels, and graphs built with include_self_loops=True (GATConv drops the
+    explicit loops and adds its own 'mean'-filled ones, so the forward must not change)."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    sd = synthetic.synthetic_state_dict(in_channels=7, seed=1234)
+    model = _model(sd)
+    gb = GraphBuilder(connectivity=conn, include_self_loops=loops)
+    tiles = [synthetic.synthetic_tile(h, w, 70 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (64, 64)])]
+    for d, m, _ in tiles[:2]:
+        g = gb.build_graph(d, m, None, (0.5, 1.0))
+        og = graph_cpu.build_graph(d, m, None, (0.5, 1.0), connectivity=conn, include_self_loops=loops)
+        assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
+        _compare(model.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
+    # and through the fused per-batch entry (ragged batch)
+    eng = TileBatchEngine(model, gb, gpu_device)
+    res = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 1.0)] * 3)
+    for (d, m, _), r in zip(tiles, res):
+        og = graph_cpu.build_graph(d, m, None, (0.5, 1.0), connectivity=conn, include_self_loops=loops)
+        ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
+        assert np.abs(r["confidence"] - ref["confidence"]).max() < TOL
+        assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4
