@@ -266,17 +266,22 @@ __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, in
     lg[K] = x;
     mx = fmaxf(mx, x);
   }
+  // exp through the hardware v_exp_f32 (2^x) and one reciprocal per head instead of libm expf and K + 1 IEEE
+  // divisions: ~1 ulp each, far inside the 1e-4 bar, and 4x fewer VALU instructions in a phase that cannot overlap
+  // the other workgroup's MFMAs (on gfx950 a wave streaming f32 MFMAs leaves the SIMD no issue slot for its
+  // neighbour: tools/mfma_overlap_probe.hip)
   float den = 0.0f;
 #pragma unroll
   for (int b = 0; b <= K; ++b) {
     const bool on = b == K ? true : present[b];
-    const float pe = on ? expf(lg[b] - mx) : 0.0f;
+    const float pe = on ? __builtin_amdgcn_exp2f((lg[b] - mx) * 1.44269504088896340736f) : 0.0f;
     lg[b] = pe;
     den += pe;
   }
   den += 1e-16f;
+  const float rden = __builtin_amdgcn_rcpf(den);
 #pragma unroll
-  for (int b = 0; b <= K; ++b) out[b] = lg[b] / den;
+  for (int b = 0; b <= K; ++b) out[b] = lg[b] * rden;
 }
 
 }  // namespace bgnn
