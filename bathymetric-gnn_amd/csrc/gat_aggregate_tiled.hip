@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256, 3) void gat_aggregate_tiled_kernel(TiledArgs a
       const int it = tid + p * 256;
       if (it < HR * 8) {
         const int row = it >> 3, q = it & 7;
-        const int id = hid[row];
+        int id = hid[row];
+        asm volatile("" : "+v"(id));        // re-derive the row address per slab: as loop invariants the 11 + 8 pointers
+                                            // are spilled, and every reload waits for the previous slab's stores
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (id >= 0) v = *reinterpret_cast<const float4 *>(a.xw + (int64_t)id * HC + s * 32 + q * 4);
         *reinterpret_cast<float4 *>(slab + row * TILED_PITCH + q * 4) = v;
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(256, 3) void gat_aggregate_tiled_kernel(TiledArgs a
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int cell = p * 32 + (tid >> 3);
-        const int id = hid[(cell / TW + 1) * HW_ + (cell % TW) + 1];
+        int id = hid[(cell / TW + 1) * HW_ + (cell % TW) + 1];
+        asm volatile("" : "+v"(id));
         if (id >= 0) {
           const float4 x = *reinterpret_cast<const float4 *>(slab + cell * TILED_PITCH + q * 4);
           float4 o;
