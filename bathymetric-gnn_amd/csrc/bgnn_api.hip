@@ -93,7 +93,26 @@ int ctx_workspace(bgnn_ctx *ctx, int slot, size_t bytes, void **out) {
 }
 
 int ctx_upload(bgnn_ctx *ctx, const void *host, size_t bytes, void *dev) {
-  BGNN_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (bytes == 0) return BGNN_OK;
+  bgnn_ctx::Staging *slot = nullptr;
+  for (auto &st : ctx->staging) {
+    if (st.cap < bytes) continue;
+    if (st.in_flight && hipEventQuery(st.ev) != hipSuccess) continue;
+    slot = &st;
+    break;
+  }
+  (void)hipGetLastError();                            // hipEventQuery reports "not ready" as an error code
+  if (!slot) {
+    bgnn_ctx::Staging st{nullptr, std::max<size_t>(bytes, 64 * 1024), nullptr, false};
+    BGNN_HIP_CHECK(hipHostMalloc(&st.p, st.cap, hipHostMallocDefault));
+    BGNN_HIP_CHECK(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    ctx->staging.push_back(st);
+    slot = &ctx->staging.back();
+  }
+  memcpy(slot->p, host, bytes);
+  BGNN_HIP_CHECK(hipMemcpyAsync(dev, slot->p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  BGNN_HIP_CHECK(hipEventRecord(slot->ev, ctx->stream));
+  slot->in_flight = true;
   return BGNN_OK;
 }
 
@@ -184,6 +203,7 @@ int bgnn_ctx_destroy(bgnn_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &r : ctx->prof_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (auto &st : ctx->staging) { (void)hipEventDestroy(st.ev); (void)hipHostFree(st.p); }
   for (int i = 0; i < 6; ++i) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   ctx->pool.trim();
@@ -229,7 +249,13 @@ size_t bgnn_model_weight_count(const bgnn_model_desc *d) {
   if (!d) return 0;
   const size_t hid = d->hidden, in = d->in_channels, hh = hid / 2;
   size_t n = hid * in + hid + hid * hid + hid;
-  for (int l = 0; l < d->num_layers; ++l) {
+  for (int l = 0; l < d->num_layers && d->gnn_type != BGNN_GNN_GAT; ++l) {
+    if (d->gnn_type == BGNN_GNN_GCN) n += hid * hid + hid;
+    else if (d->gnn_type == BGNN_GNN_SAGE) n += 2 * hid * hid + hid;
+    else n += 2 * (hid * hid + hid);                              // GIN
+    n += 4 * hid;                                                 // BatchNorm
+  }
+  for (int l = 0; l < d->num_layers && d->gnn_type == BGNN_GNN_GAT; ++l) {
     const bool last = l == d->num_layers - 1;
     const size_t H = last ? 1 : d->heads;
     const size_t D = l == 0 ? hid : hid * d->heads;
@@ -249,7 +275,9 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   BGNN_REQUIRE(d->num_layers >= 1 && d->num_layers <= 64, "num_gnn_layers=%d unsupported", d->num_layers);
   BGNN_REQUIRE(d->heads >= 1 && d->heads * d->hidden <= 256 && (d->heads & (d->heads - 1)) == 0,
                "heads=%d unsupported (power of two, heads*hidden <= 256)", d->heads);
-  BGNN_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 4, "edge_dim=%d unsupported (1..4)", d->edge_dim);
+  BGNN_REQUIRE(d->gnn_type >= BGNN_GNN_GAT && d->gnn_type <= BGNN_GNN_GIN, "gnn_type=%d unknown", d->gnn_type);
+  const bool gat = d->gnn_type == BGNN_GNN_GAT;
+  BGNN_REQUIRE(!gat || (d->edge_dim >= 1 && d->edge_dim <= 4), "edge_dim=%d unsupported (1..4)", d->edge_dim);
   BGNN_REQUIRE(d->num_classes >= 1 && d->num_classes <= 16, "num_classes=%d unsupported", d->num_classes);
   BGNN_REQUIRE(n_weights == bgnn_model_weight_count(d), "weight blob has %zu floats, expected %zu", n_weights,
                bgnn_model_weight_count(d));
@@ -270,9 +298,53 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   for (int o = 0; o < hid; ++o) for (int i = 0; i < hid; ++i) pk[o_fe_W1t + (size_t)i * hid + o] = p[(size_t)o * hid + i];
   p += (size_t)hid * hid;
   std::copy(p, p + hid, pk.begin() + o_fe_b1); p += hid;
-  struct LOff { size_t Wt, as, ad, V, sc, sh; };
+  struct LOff { size_t Wt, as, ad, V, sc, sh, b1, Wt2, b2; };
   std::vector<LOff> lo(L);
-  for (int l = 0; l < L; ++l) {
+  // BatchNorm (eval) as y = x * s + t
+  auto bn_fold = [&](const float *bw, const float *bb, const float *rm, const float *rv, int c, double &sc, double &sh) {
+    sc = (double)bw[c] / std::sqrt((double)rv[c] + (double)d->bn_eps);
+    sh = (double)bb[c] - (double)rm[c] * sc;
+  };
+  for (int l = 0; l < L && !gat; ++l) {
+    // every layer hid -> hid.  W^T layouts [in][out]; BatchNorm folded into the last linear map of the layer
+    // (GCN: into the reduce kernel's scale / shift, because the aggregate sits between lin and bias)
+    const float *W0 = p; p += (size_t)hid * hid;
+    const float *b0 = nullptr, *W1 = nullptr, *b1 = nullptr;
+    if (d->gnn_type == BGNN_GNN_GCN) { b0 = p; p += hid; }
+    else if (d->gnn_type == BGNN_GNN_SAGE) { b0 = p; p += hid; W1 = p; p += (size_t)hid * hid; }
+    else { b0 = p; p += hid; W1 = p; p += (size_t)hid * hid; b1 = p; p += hid; }
+    const float *bw = p; p += hid; const float *bb = p; p += hid; const float *rm = p; p += hid; const float *rv = p; p += hid;
+    if (d->gnn_type == BGNN_GNN_GCN) {
+      lo[l].Wt = reserve((size_t)hid * hid); lo[l].sc = reserve(hid); lo[l].sh = reserve(hid);
+      for (int o = 0; o < hid; ++o) {
+        for (int i = 0; i < hid; ++i) pk[lo[l].Wt + (size_t)i * hid + o] = W0[(size_t)o * hid + i];
+        double sc, sh; bn_fold(bw, bb, rm, rv, o, sc, sh);
+        pk[lo[l].sc + o] = (float)sc; pk[lo[l].sh + o] = (float)((double)b0[o] * sc + sh);
+      }
+    } else if (d->gnn_type == BGNN_GNN_SAGE) {
+      lo[l].Wt = reserve((size_t)2 * hid * hid); lo[l].b2 = reserve(hid);
+      for (int o = 0; o < hid; ++o) {
+        double sc, sh; bn_fold(bw, bb, rm, rv, o, sc, sh);
+        for (int i = 0; i < hid; ++i) {
+          pk[lo[l].Wt + (size_t)i * hid + o] = (float)((double)W0[(size_t)o * hid + i] * sc);           // lin_l: mean part
+          pk[lo[l].Wt + (size_t)(hid + i) * hid + o] = (float)((double)W1[(size_t)o * hid + i] * sc);     // lin_r: root part
+        }
+        pk[lo[l].b2 + o] = (float)((double)b0[o] * sc + sh);
+      }
+    } else {
+      lo[l].Wt = reserve((size_t)hid * hid); lo[l].b1 = reserve(hid); lo[l].Wt2 = reserve((size_t)hid * hid); lo[l].b2 = reserve(hid);
+      for (int o = 0; o < hid; ++o) {
+        double sc, sh; bn_fold(bw, bb, rm, rv, o, sc, sh);
+        for (int i = 0; i < hid; ++i) {
+          pk[lo[l].Wt + (size_t)i * hid + o] = W0[(size_t)o * hid + i];
+          pk[lo[l].Wt2 + (size_t)i * hid + o] = (float)((double)W1[(size_t)o * hid + i] * sc);
+        }
+        pk[lo[l].b1 + o] = b0[o];
+        pk[lo[l].b2 + o] = (float)((double)b1[o] * sc + sh);
+      }
+    }
+  }
+  for (int l = 0; l < L && gat; ++l) {
     const bool last = l == L - 1;
     const int H = last ? 1 : d->heads, D = l == 0 ? hid : hid * d->heads, HC = H * hid, W = last ? hid : HC;
     lo[l].Wt = reserve((size_t)D * HC);
@@ -323,7 +395,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   // y = z W1^T + b1, xw = y W0^T  ==>  xw = z (W1^T W0^T) + b1 W0^T.  Folded in float64, one GEMM less per forward.
   const int HC0 = (L > 1 ? d->heads : 1) * hid;
   size_t o_l0f_Wt = reserve((size_t)hid * HC0), o_l0f_b = reserve(HC0);
-  for (int o = 0; o < HC0; ++o) {
+  for (int o = 0; o < HC0 && gat; ++o) {
     for (int i = 0; i < hid; ++i) {
       double s = 0.0;
       for (int k = 0; k < hid; ++k) s += (double)pk[o_fe_W1t + (size_t)i * hid + k] * (double)pk[lo[0].Wt + (size_t)k * HC0 + o];
@@ -343,7 +415,16 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->fe_W0t = m->blob + o_fe_W0t; m->fe_b0 = m->blob + o_fe_b0; m->fe_W1t = m->blob + o_fe_W1t; m->fe_b1 = m->blob + o_fe_b1;
   m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
   m->layers.resize(L);
-  for (int l = 0; l < L; ++l) {
+  for (int l = 0; l < L && !gat; ++l) {
+    BgnnLayer &Ly = m->layers[l];
+    Ly = BgnnLayer{};
+    Ly.heads = 1; Ly.d_in = hid; Ly.width = hid; Ly.concat = l != L - 1;
+    Ly.Wt = m->blob + lo[l].Wt;
+    if (d->gnn_type == BGNN_GNN_GCN) { Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh; }
+    if (d->gnn_type == BGNN_GNN_SAGE) Ly.b2 = m->blob + lo[l].b2;
+    if (d->gnn_type == BGNN_GNN_GIN) { Ly.b1 = m->blob + lo[l].b1; Ly.Wt2 = m->blob + lo[l].Wt2; Ly.b2 = m->blob + lo[l].b2; }
+  }
+  for (int l = 0; l < L && gat; ++l) {
     const bool last = l == L - 1;
     BgnnLayer &Ly = m->layers[l];
     Ly.heads = last ? 1 : d->heads; Ly.d_in = l == 0 ? hid : hid * d->heads;
@@ -556,11 +637,12 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   const bgnn_model_desc &d = m->desc;
   BGNN_REQUIRE(g->F == d.in_channels, "mat1 and mat2 shapes cannot be multiplied (graph has %d node features, model expects %d)",
                g->F, d.in_channels);
-  BGNN_REQUIRE(g->ED == d.edge_dim, "edge_attr has %d columns, model edge_dim is %d", g->ED, d.edge_dim);
+  const bool gat = d.gnn_type == BGNN_GNN_GAT;
+  BGNN_REQUIRE(!gat || g->ED == d.edge_dim, "edge_attr has %d columns, model edge_dim is %d", g->ED, d.edge_dim);
   const int64_t rows = g->row_capacity;
   if (rows <= 0) return BGNN_OK;
   const int hid = d.hidden;
-  const int maxw = std::max(hid, d.heads * hid);
+  const int maxw = std::max(2 * hid, d.heads * hid);
   void *pa, *pb, *pasd, *phid;
   BGNN_TRY(ctx_workspace(ctx, 0, (size_t)rows * maxw * sizeof(float), &pa));
   BGNN_TRY(ctx_workspace(ctx, 1, (size_t)rows * maxw * sizeof(float), &pb));
@@ -571,7 +653,32 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   const int64_t *dm = g->d_counts;
   const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr;
   // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid); then lin of layer 0
-  {
+  if (!gat) {
+    // GCN / GraphSAGE / GIN backbones (gnn.py:120-143; torch_geometric default arguments): plain gathers + GEMMs.
+    // Not the hot path: no fusion beyond BatchNorm / bias / ReLU folded into the neighbouring kernel.
+    BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
+    BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->fe_W1t, m->fe_b1, X, hid, dm, rows, hid, hid, 0));
+    float *dinv = asdX;
+    if (d.gnn_type == BGNN_GNN_GCN) BGNN_TRY(launch_degree_inv_sqrt(ctx, g, dinv));
+    const size_t nl = m->layers.size();
+    for (size_t l = 0; l < nl; ++l) {                 // invariant: X = h_l [rows][hid]
+      const BgnnLayer &L = m->layers[l];
+      const int relu = l + 1 < nl ? 1 : 0;
+      if (d.gnn_type == BGNN_GNN_GCN) {               // lin, normalised aggregate, + bias, BatchNorm, ReLU
+        BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt, nullptr, Y, hid, dm, rows, hid, hid, 0));
+        BGNN_TRY(launch_neighbor_reduce(ctx, g, 1, Y, hid, dinv, L.scale, L.shift, relu, X, hid, nullptr));
+      } else if (d.gnn_type == BGNN_GNN_SAGE) {       // [mean_j x_j | x_i] @ [lin_l ; lin_r]^T (BatchNorm folded) + bias, ReLU
+        BGNN_TRY(launch_neighbor_reduce(ctx, g, 2, X, hid, nullptr, nullptr, nullptr, 0, Y, 2 * hid, Y + hid));
+        BGNN_TRY(launch_gemm_f32(ctx, Y, 2 * hid, L.Wt, L.b2, X, hid, dm, rows, 2 * hid, hid, relu));
+      } else {                                        // GIN: nn(sum_j x_j + x_i), nn = Linear ReLU Linear; BatchNorm; ReLU
+        BGNN_TRY(launch_neighbor_reduce(ctx, g, 3, X, hid, nullptr, nullptr, nullptr, 0, Y, hid, nullptr));
+        BGNN_TRY(launch_gemm_f32(ctx, Y, hid, L.Wt, L.b1, X, hid, dm, rows, hid, hid, 1));
+        BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt2, L.b2, Y, hid, dm, rows, hid, hid, relu));
+        std::swap(X, Y);
+      }
+    }
+    std::swap(X, Y);                                  // the tail below expects the backbone output in Y
+  } else {
     const BgnnLayer &L0 = m->layers[0];
     if (getenv("BGNN_NO_FOLD") == nullptr) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
@@ -585,7 +692,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     }
   }
   // GNN backbone (gnn.py:173-188).  Invariant at the top of each iteration: X = lin_l(h_l), asdX = its dots.
-  const size_t nl = m->layers.size();
+  const size_t nl = gat ? m->layers.size() : 0;
   for (size_t l = 0; l < nl; ++l) {
     const BgnnLayer &L = m->layers[l];
     const int relu = L.concat ? 1 : 0;

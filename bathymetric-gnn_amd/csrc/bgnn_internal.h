@@ -79,9 +79,11 @@ struct bgnn_ctx {
   // forward workspace (grow-only)
   void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
-  // pinned staging for small host->device tables
-  void *pinned = nullptr;
-  size_t pinned_bytes = 0;
+  // pinned staging for host->device tables: a table is copied into a pinned buffer at call time and DMA'd from there,
+  // so the caller's (often function-local, pageable) source may go away while the copy is still queued behind
+  // other stream work; a buffer is reused once its event has completed
+  struct Staging { void *p; size_t cap; hipEvent_t ev; bool in_flight; };
+  std::vector<Staging> staging;
   int num_cus = 256;
   float *zero_page = nullptr;   // 16 KiB: [0,4K) zeros, [4K,4K+128) diagnostic counters, [8K,16K) dump rows
   unsigned long long *stamps = nullptr;   // 16 diagnostic counters (inside the zero page allocation)
@@ -96,6 +98,11 @@ struct BgnnLayer {
   float *V;         // [heads][edge_dim]   folded lin_edge . att_edge
   float *scale;     // [width]  BN weight / sqrt(var + eps)
   float *shift;     // [width]  (conv bias - mean) * scale + BN bias
+  // non-attention backbones (desc.gnn_type != BGNN_GNN_GAT): Wt = GCN lin^T [hid][hid] | SAGE [lin_l^T ; lin_r^T] [2 hid][hid]
+  // with BatchNorm folded in | GIN nn.0^T [hid][hid]; then
+  float *b1;        // GIN nn.0 bias [hid]
+  float *Wt2;       // GIN nn.2^T [hid][hid] with BatchNorm folded in
+  float *b2;        // SAGE / GIN: bias with BatchNorm folded in [hid]
 };
 
 struct bgnn_model {
@@ -190,6 +197,9 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
                              const float *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);
+int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv);
+int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const float *x, int D, const float *dinv,
+                           const float *scale, const float *shift, int relu, float *out, int ldo, float *copy_self);
 int launch_heads_final(bgnn_ctx *ctx, const bgnn_model *m, const float *hid, int ldh, const int64_t *d_m,
                        int64_t max_rows, float thr_auto, float thr_review, const bgnn_outputs *o);
 

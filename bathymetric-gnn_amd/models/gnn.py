@@ -1,4 +1,4 @@
-"""BathymetricGNN -- drop-in for the reference's ``models/gnn.py`` (GAT backbone).
+"""BathymetricGNN -- drop-in for the reference's ``models/gnn.py`` (GAT backbone = the hot path; GCN / GraphSAGE / GIN too).
 
 The module tree and parameter names equal the reference's (and torch_geometric's ``GATConv`` /
 ``BatchNorm`` wrappers), so ``load_state_dict`` takes a reference checkpoint unchanged and
@@ -80,24 +80,61 @@ class BatchNorm(nn.Module):
         self.module = nn.BatchNorm1d(in_channels, eps=eps, momentum=momentum)
 
 
+class GCNConv(nn.Module):
+    """Parameter container with torch_geometric ``GCNConv``'s names: ``lin.weight [out, in]`` (no bias), ``bias [out]``."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        _glorot_(self.lin.weight)
+
+
+class SAGEConv(nn.Module):
+    """torch_geometric ``SAGEConv`` (mean aggregation, root weight): ``lin_l.{weight,bias}``, ``lin_r.weight``."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+
+class GINConv(nn.Module):
+    """torch_geometric ``GINConv(nn)`` with eps = 0 (not trained): parameters live under ``nn``."""
+
+    def __init__(self, mlp: nn.Module):
+        super().__init__()
+        self.nn = mlp
+
+
 class GNNBackbone(nn.Module):
-    """L x (GATConv, BatchNorm[, ReLU, Dropout]) (reference :74-188).  Only ``gnn_type='GAT'`` is on
-    the accelerated path; the other conv types of the reference are outside it."""
+    """L x (conv, BatchNorm[, ReLU, Dropout]) (reference :74-188).  ``gnn_type='GAT'`` is the accelerated hot path;
+    GCN / GraphSAGE / GIN (every layer hidden -> hidden, torch_geometric default arguments) run on plain gather +
+    GEMM kernels."""
 
     def __init__(self, in_channels, hidden_channels, num_layers, gnn_type="GAT", heads=4, dropout=0.1, edge_dim=None):
         super().__init__()
-        if gnn_type in ("GCN", "GraphSAGE", "GIN"):
-            raise NotImplementedError(f"gnn_type={gnn_type!r}: only the GAT backbone is built on the MI355X path")
-        if gnn_type != "GAT":
+        if gnn_type not in ("GAT", "GCN", "GraphSAGE", "GIN"):
             raise ValueError(f"Unknown GNN type: {gnn_type}")
         self.gnn_type, self.num_layers, self.dropout = gnn_type, num_layers, dropout
         self.convs, self.norms = nn.ModuleList(), nn.ModuleList()
         for i in range(num_layers):
             last = i == num_layers - 1
-            layer_in = in_channels if i == 0 else hidden_channels * heads
-            self.convs.append(GATConv(layer_in, hidden_channels, heads=1 if last else heads, dropout=dropout,
-                                      edge_dim=edge_dim, concat=not last))
-            self.norms.append(BatchNorm(hidden_channels if last else hidden_channels * heads))
+            if gnn_type == "GAT":
+                layer_in = in_channels if i == 0 else hidden_channels * heads
+                self.convs.append(GATConv(layer_in, hidden_channels, heads=1 if last else heads, dropout=dropout,
+                                          edge_dim=edge_dim, concat=not last))
+                self.norms.append(BatchNorm(hidden_channels if last else hidden_channels * heads))
+                continue
+            layer_in = in_channels if i == 0 else hidden_channels
+            if gnn_type == "GCN":
+                self.convs.append(GCNConv(layer_in, hidden_channels))
+            elif gnn_type == "GraphSAGE":
+                self.convs.append(SAGEConv(layer_in, hidden_channels))
+            else:
+                self.convs.append(GINConv(nn.Sequential(nn.Linear(layer_in, hidden_channels), nn.ReLU(),
+                                                        nn.Linear(hidden_channels, hidden_channels))))
+            self.norms.append(BatchNorm(hidden_channels))
 
 
 class _Head(nn.Module):
@@ -134,9 +171,10 @@ class BathymetricGNN(nn.Module):
                  heads: int = 4, num_classes: int = 3, predict_correction: bool = True, dropout: float = 0.1,
                  edge_dim: Optional[int] = None):
         super().__init__()
-        if edge_dim is None:
+        if edge_dim is None and gnn_type == "GAT":
             raise NotImplementedError("edge_dim=None (GATConv without edge features) is outside the built path; "
                                       "the reference always passes edge_dim=3")
+        self.gnn_type = gnn_type
         self.predict_correction = predict_correction
         self.num_classes = num_classes
         self.in_channels, self.hidden_channels, self.heads = in_channels, hidden_channels, heads
@@ -154,7 +192,8 @@ class BathymetricGNN(nn.Module):
     def _desc(self) -> rt.ModelDesc:
         d = rt.ModelDesc()
         d.in_channels, d.hidden, d.num_layers = self.in_channels, self.hidden_channels, self.num_gnn_layers
-        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, self.edge_dim
+        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, (self.edge_dim or 0)
+        d.gnn_type = rt.GNN_TYPES[self.gnn_type]
         d.predict_correction = 1 if self.predict_correction else 0
         d.bn_eps = float(self.gnn.norms[0].module.eps)
         return d
@@ -168,9 +207,16 @@ class BathymetricGNN(nn.Module):
             parts += [sd[p + ".weight"], sd[p + ".bias"]]
         for l in range(self.num_gnn_layers):
             c, n = f"gnn.convs.{l}.", f"gnn.norms.{l}.module."
-            parts += [sd[c + "lin.weight"], sd[c + "att_src"], sd[c + "att_dst"], sd[c + "att_edge"],
-                      sd[c + "lin_edge.weight"], sd[c + "bias"],
-                      sd[n + "weight"], sd[n + "bias"], sd[n + "running_mean"], sd[n + "running_var"]]
+            if self.gnn_type == "GAT":
+                parts += [sd[c + "lin.weight"], sd[c + "att_src"], sd[c + "att_dst"], sd[c + "att_edge"],
+                          sd[c + "lin_edge.weight"], sd[c + "bias"]]
+            elif self.gnn_type == "GCN":
+                parts += [sd[c + "lin.weight"], sd[c + "bias"]]
+            elif self.gnn_type == "GraphSAGE":
+                parts += [sd[c + "lin_l.weight"], sd[c + "lin_l.bias"], sd[c + "lin_r.weight"]]
+            else:
+                parts += [sd[c + "nn.0.weight"], sd[c + "nn.0.bias"], sd[c + "nn.2.weight"], sd[c + "nn.2.bias"]]
+            parts += [sd[n + "weight"], sd[n + "bias"], sd[n + "running_mean"], sd[n + "running_var"]]
         heads = ["classification_head", "confidence_head"] + (["correction_head"] if self.predict_correction else [])
         for h in heads:
             parts += [sd[h + ".mlp.0.weight"], sd[h + ".mlp.0.bias"], sd[h + ".mlp.3.weight"], sd[h + ".mlp.3.bias"]]

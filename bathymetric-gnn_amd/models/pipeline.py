@@ -171,7 +171,8 @@ class HostTilePipeline:
     copied back on a D2H stream; ``depth`` slots (default 2) of pinned + device buffers let batch i+1 upload
     and batch i-1 download while batch i computes.  ``submit`` enqueues a batch and returns the result of the
     batch submitted ``depth`` calls earlier (or None); ``drain`` yields what is still in flight, in order.
-    Result arrays are views of the slot's pinned buffer: valid until that slot is submitted again."""
+    Result arrays are views of a pinned output buffer that stays untouched until the NEXT call of ``submit`` /
+    ``drain`` step (there is one output buffer more than there are slots): use or copy them before that."""
 
     def __init__(self, engine: TileBatchEngine, n_tiles: int, h: int, w: int, with_uncertainty: bool = False,
                  resolution=(1.0, 1.0), depth: int = 2):
@@ -189,24 +190,34 @@ class HostTilePipeline:
             self.slots.append({
                 "h_depth": pin(torch.float32), "h_mask": pin(torch.uint8), "h_unc": pin(torch.float32) if with_uncertainty else None,
                 "d_depth": mk(torch.float32), "d_mask": mk(torch.uint8), "d_unc": mk(torch.float32) if with_uncertainty else None,
-                "d_out": mk(torch.float32, (3, self.cells)), "h_out": pin(torch.float32, (3, self.cells)),
+                "d_out": mk(torch.float32, (3, self.cells)), "h_out": None,
                 "up": torch.cuda.Event(), "done": torch.cuda.Event(), "down": torch.cuda.Event(), "busy": False, "tag": None})
+        self._free_out = [pin(torch.float32, (3, self.cells)) for _ in range(depth + 1)]
+        self._lent = None            # the output buffer whose views the caller currently holds
         self.i = 0
+
+    def _recycle(self):
+        if self._lent is not None:
+            self._free_out.append(self._lent)
+            self._lent = None
 
     def _result(self, slot):
         slot["down"].synchronize()
         slot["busy"] = False
-        o = slot["h_out"].numpy().reshape(3, self.n, self.h, self.w)
+        self._lent, slot["h_out"] = slot["h_out"], None
+        o = self._lent.numpy().reshape(3, self.n, self.h, self.w)
         return slot["tag"], {"classification": o[0], "confidence": o[1], "correction": o[2]}
 
     def submit(self, depth: np.ndarray, mask: np.ndarray, unc: Optional[np.ndarray] = None, tag=None):
+        self._recycle()                                            # views handed out by the previous call expire now
         slot = self.slots[self.i % len(self.slots)]
         self.i += 1
-        ready = self._result(slot) if slot["busy"] else None       # also: its device/pinned buffers are free again
+        ready = self._result(slot) if slot["busy"] else None       # also: its device / pinned input buffers are free again
         slot["h_depth"].numpy()[:] = np.asarray(depth, np.float32).reshape(-1)
         slot["h_mask"].numpy()[:] = np.asarray(mask).reshape(-1).view(np.uint8)
         if slot["h_unc"] is not None:
             slot["h_unc"].numpy()[:] = np.asarray(unc, np.float32).reshape(-1)
+        slot["h_out"] = self._free_out.pop()                       # never the buffer just lent to the caller
         with torch.cuda.stream(self.h2d):
             slot["d_depth"].copy_(slot["h_depth"], non_blocking=True)
             slot["d_mask"].copy_(slot["h_mask"], non_blocking=True)
@@ -228,6 +239,7 @@ class HostTilePipeline:
         for k in range(len(self.slots)):
             slot = self.slots[(self.i + k) % len(self.slots)]
             if slot["busy"]:
+                self._recycle()
                 yield self._result(slot)
 
 

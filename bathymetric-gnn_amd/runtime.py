@@ -28,10 +28,13 @@ EF_ZERO = 3
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4
 
 
+GNN_TYPES = {"GAT": 0, "GCN": 1, "GraphSAGE": 2, "GIN": 3}      # BGNN_GNN_*
+
+
 class ModelDesc(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("hidden", C.c_int32), ("num_layers", C.c_int32),
                 ("heads", C.c_int32), ("num_classes", C.c_int32), ("edge_dim", C.c_int32),
-                ("predict_correction", C.c_int32), ("bn_eps", C.c_float)]
+                ("predict_correction", C.c_int32), ("bn_eps", C.c_float), ("gnn_type", C.c_int32)]
 
 
 class Tiles(C.Structure):
@@ -111,8 +114,8 @@ def load_library(path: Optional[str] = None):
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.bgnn_abi_version() != 1:
-            raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != 1")
+        if lib.bgnn_abi_version() != 2:
+            raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != 2")
         _lib = lib
         return lib
 

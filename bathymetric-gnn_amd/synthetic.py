@@ -118,7 +118,7 @@ def _glorot(rng, shape, fan_in, fan_out):
 def synthetic_state_dict(in_channels: int = 7, hidden: int = 64, num_layers: int = 4,
                          heads: int = 4, num_classes: int = 3, edge_dim: int = 3,
                          predict_correction: bool = True, seed: int = 1234,
-                         legacy_lin_src: bool = False) -> "OrderedDict[str, np.ndarray]":
+                         legacy_lin_src: bool = False, gnn_type: str = "GAT") -> "OrderedDict[str, np.ndarray]":
     """Random-init weights under the reference's state_dict key names
     (``training/trainer.py:809-829`` saves ``model.state_dict()``).
 
@@ -137,7 +137,29 @@ def synthetic_state_dict(in_channels: int = 7, hidden: int = 64, num_layers: int
 
     linear("feature_extractor.mlp.0", hidden, in_channels)
     linear("feature_extractor.mlp.3", hidden, hidden)
-    for l in range(num_layers):
+    def batch_norm(l, width):
+        q = f"gnn.norms.{l}.module."
+        sd[q + "weight"] = rng.uniform(0.8, 1.2, size=width).astype(np.float32)
+        sd[q + "bias"] = (0.05 * rng.standard_normal(width)).astype(np.float32)
+        sd[q + "running_mean"] = (0.1 * rng.standard_normal(width)).astype(np.float32)
+        sd[q + "running_var"] = rng.uniform(0.5, 1.5, size=width).astype(np.float32)
+        sd[q + "num_batches_tracked"] = np.array(100, dtype=np.int64)
+
+    for l in range(num_layers if gnn_type != "GAT" else 0):      # GCN / GraphSAGE / GIN: every layer hidden -> hidden
+        p = f"gnn.convs.{l}."
+        if gnn_type == "GCN":
+            sd[p + "lin.weight"] = _glorot(rng, (hidden, hidden), hidden, hidden)
+            sd[p + "bias"] = (0.05 * rng.standard_normal(hidden)).astype(np.float32)
+        elif gnn_type == "GraphSAGE":
+            linear(p + "lin_l", hidden, hidden)
+            sd[p + "lin_r.weight"] = _glorot(rng, (hidden, hidden), hidden, hidden)
+        elif gnn_type == "GIN":
+            linear(p + "nn.0", hidden, hidden)
+            linear(p + "nn.2", hidden, hidden)
+        else:
+            raise ValueError(f"Unknown GNN type: {gnn_type}")
+        batch_norm(l, hidden)
+    for l in range(num_layers if gnn_type == "GAT" else 0):
         last = l == num_layers - 1
         H = 1 if last else heads
         d_in = hidden if l == 0 else hidden * heads

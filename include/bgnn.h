@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BGNN_ABI_VERSION 1
+#define BGNN_ABI_VERSION 2
 
 #define BGNN_OK 0
 #define BGNN_ERR_INVALID (-1)     /* bad argument (-> ValueError in the Python mirror)   */
@@ -73,7 +73,10 @@ enum {
 int bgnn_ctx_profile(bgnn_ctx *ctx, uint32_t kernel_mask);
 int bgnn_ctx_profile_read(bgnn_ctx *ctx, double *ms, int64_t *launches);
 
-/* ---- model: BathymetricGNN (models/gnn.py:263-358), GAT backbone only --------------- */
+/* ---- model: BathymetricGNN (models/gnn.py:263-358) ------------------------------------ */
+enum { /* GNNBackbone gnn_type (models/gnn.py:120-143); GAT is the hot path, the others run on plain gather + GEMM kernels */
+  BGNN_GNN_GAT = 0, BGNN_GNN_GCN = 1, BGNN_GNN_SAGE = 2, BGNN_GNN_GIN = 3
+};
 typedef struct bgnn_model_desc {
   int32_t in_channels;        /* 7, or 8 with the uncertainty column                     */
   int32_t hidden;             /* 64 (must be a multiple of 32, <= 64)                    */
@@ -83,6 +86,7 @@ typedef struct bgnn_model_desc {
   int32_t edge_dim;           /* 3                                                       */
   int32_t predict_correction; /* correction head present                                 */
   float bn_eps;               /* torch BatchNorm1d eps, 1e-5                             */
+  int32_t gnn_type;           /* BGNN_GNN_*; 0 = GAT                                     */
 } bgnn_model_desc;
 
 /* Number of float32 values bgnn_model_create expects in `weights`, in this order
@@ -96,6 +100,10 @@ typedef struct bgnn_model_desc {
  *   classification_head.mlp.0.{weight[hid/2,hid],bias}, classification_head.mlp.3.{weight[classes,hid/2],bias}
  *   confidence_head.mlp.0.{..}, confidence_head.mlp.3.{weight[1,hid/2],bias[1]}
  *   correction_head.mlp.0.{..}, correction_head.mlp.3.{..}     (only if predict_correction)
+ * For the other backbones the per-layer block is (every layer hid -> hid, torch_geometric default arguments):
+ *   GCN : gnn.convs.l.lin.weight[hid,hid], gnn.convs.l.bias[hid], norms (4 x [hid])
+ *   SAGE: gnn.convs.l.lin_l.weight[hid,hid], lin_l.bias[hid], lin_r.weight[hid,hid], norms
+ *   GIN : gnn.convs.l.nn.0.weight[hid,hid], nn.0.bias[hid], nn.2.weight[hid,hid], nn.2.bias[hid], norms
  */
 size_t bgnn_model_weight_count(const bgnn_model_desc *desc);
 

@@ -48,7 +48,7 @@ def _lin_weight(sd: Mapping, prefix: str, dtype):
 
 def num_layers_of(sd: Mapping) -> int:
     n = 0
-    while (f"gnn.convs.{n}.att_src") in sd:
+    while (f"gnn.norms.{n}.module.weight") in sd:       # one BatchNorm per layer, whatever the convolution
         n += 1
     return n
 
@@ -106,13 +106,72 @@ def _mlp2(x, sd, p0, p1, dtype):
     return F.linear(h, _t(sd[p1 + ".weight"], dtype), _t(sd[p1 + ".bias"], dtype))
 
 
+def gnn_type_of(sd: Mapping) -> str:
+    """Backbone type from the state_dict key names (models/gnn.py:120-143)."""
+    if "gnn.convs.0.lin_l.weight" in sd:
+        return "GraphSAGE"
+    if "gnn.convs.0.nn.0.weight" in sd:
+        return "GIN"
+    if "gnn.convs.0.att_src" in sd:
+        return "GAT"
+    return "GCN"
+
+
+def gcn_conv(x, edge_index, sd: Mapping, prefix: str, dtype):
+    """torch_geometric ``GCNConv`` with default arguments (improved=False, add_self_loops=True, normalize=True,
+    bias=True; parity unpinned like GATConv): x = lin(x); gcn_norm (add_remaining_self_loops with unit weights: the
+    N loops go LAST; deg = scatter-add of the weights over the targets; norm = d^-1/2[src] * w * d^-1/2[dst]);
+    out = scatter-add(norm * x[src]) + bias."""
+    N = x.shape[0]
+    src, dst = edge_index[0], edge_index[1]
+    keep = src != dst
+    loops = torch.arange(N, dtype=torch.int64)
+    src = torch.cat([src[keep], loops]); dst = torch.cat([dst[keep], loops])
+    w = torch.ones(src.shape[0], dtype=dtype)
+    deg = torch.zeros(N, dtype=dtype).index_add_(0, dst, w)
+    dinv = deg.pow(-0.5)
+    dinv[torch.isinf(dinv)] = 0
+    norm = dinv[src] * w * dinv[dst]
+    xw = F.linear(x, _t(sd[prefix + "lin.weight"], dtype))
+    out = torch.zeros_like(xw).index_add_(0, dst, norm.unsqueeze(-1) * xw[src])
+    return out + _t(sd[prefix + "bias"], dtype)
+
+
+def sage_conv(x, edge_index, sd: Mapping, prefix: str, dtype):
+    """``SAGEConv`` defaults (aggr='mean', root_weight=True, normalize=False): lin_l(mean_j x_j) + lin_r(x_i); the
+    mean is scatter-sum / clamp(count, min=1); explicit self loops in edge_index are ordinary edges."""
+    N = x.shape[0]
+    src, dst = edge_index[0], edge_index[1]
+    s = torch.zeros_like(x).index_add_(0, dst, x[src])
+    cnt = torch.zeros(N, dtype=dtype).index_add_(0, dst, torch.ones(src.shape[0], dtype=dtype)).clamp(min=1)
+    mean = s / cnt.unsqueeze(-1)
+    return (F.linear(mean, _t(sd[prefix + "lin_l.weight"], dtype), _t(sd[prefix + "lin_l.bias"], dtype))
+            + F.linear(x, _t(sd[prefix + "lin_r.weight"], dtype)))
+
+
+def gin_conv(x, edge_index, sd: Mapping, prefix: str, dtype):
+    """``GINConv(nn)`` defaults (eps=0, train_eps=False): nn(sum_j x_j + (1 + eps) x_i), nn = Linear ReLU Linear."""
+    src, dst = edge_index[0], edge_index[1]
+    s = torch.zeros_like(x).index_add_(0, dst, x[src])
+    s = s + (1.0 + 0.0) * x
+    return _mlp2(s, sd, prefix + "nn.0", prefix + "nn.2", dtype)
+
+
 def backbone(x, edge_index, edge_attr, sd: Mapping, dtype):
     """feature extractor + GNN backbone -> [N, hidden]"""
     L = num_layers_of(sd)
+    kind = gnn_type_of(sd)
     h = _mlp2(x, sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", dtype)
     for l in range(L):
         last = l == L - 1
-        h = gat_conv(h, edge_index, edge_attr, sd, f"gnn.convs.{l}.", concat=not last, dtype=dtype)
+        if kind == "GAT":
+            h = gat_conv(h, edge_index, edge_attr, sd, f"gnn.convs.{l}.", concat=not last, dtype=dtype)
+        elif kind == "GCN":
+            h = gcn_conv(h, edge_index, sd, f"gnn.convs.{l}.", dtype)
+        elif kind == "GraphSAGE":
+            h = sage_conv(h, edge_index, sd, f"gnn.convs.{l}.", dtype)
+        else:
+            h = gin_conv(h, edge_index, sd, f"gnn.convs.{l}.", dtype)
         h = batch_norm_eval(h, sd, f"gnn.norms.{l}.module.", dtype)
         if not last:
             h = F.relu(h)

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_struct_layouts():
     from bathymetric_gnn_amd import runtime as rt
-    assert C.sizeof(rt.ModelDesc) == 32
+    assert C.sizeof(rt.ModelDesc) == 36
     assert C.sizeof(rt.GraphOpts) == 4 * (2 + 1 + 8 + 1 + 4)
     assert C.sizeof(rt.Outputs) == 9 * C.sizeof(C.c_void_p)
     assert C.sizeof(rt.Tiles) == 8 + 5 * C.sizeof(C.c_void_p)
@@ -69,3 +69,14 @@ def test_errors_without_gpu(lib):
         GraphBuilder().build_graph(np.zeros((4, 4), np.float32))
     with pytest.raises(ValueError):
         GraphBuilder(connectivity="6-connected")
+
+
+@pytest.mark.parametrize("kind,per_layer", [("GCN", 64 * 64 + 64), ("GraphSAGE", 2 * 64 * 64 + 64), ("GIN", 2 * (64 * 64 + 64))])
+def test_weight_count_other_backbones(kind, per_layer, lib):
+    """Blob sizes of the GCN / GraphSAGE / GIN backbones (include/bgnn.h lists the order)."""
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=3)
+    d = m._desc()
+    fe = 64 * 7 + 64 + 64 * 64 + 64
+    heads = (32 * 64 + 32 + 3 * 32 + 3) + 2 * (32 * 64 + 32 + 32 + 1)
+    assert lib.bgnn_model_weight_count(C.byref(d)) == fe + 3 * (per_layer + 4 * 64) + heads == m.pack_weights().size

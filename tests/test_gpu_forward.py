@@ -307,11 +307,22 @@ def test_host_tile_pipeline_matches_blocking_path(gpu_device):
             got.append((r[0], {k: v.copy() for k, v in r[1].items()}))
     got += [(t, {k: v.copy() for k, v in r.items()}) for t, r in hp.drain()]
     assert [t for t, _ in got] == list(range(5))
+    # (the blocking references are computed AFTER the pipeline has run cold: a result view that is overwritten by a
+    #  later batch's D2H -- the race this ordering once exposed -- would show up as another batch's grids)
     for (t, r), (d, m, u) in zip(got, batches):
         ref = eng.infer(list(d), list(m), list(u), [(0.5, 1.0)] * n)
         for k in range(n):
             for ch in ("classification", "confidence", "correction"):
                 assert np.array_equal(r[ch][k].view(np.uint32), ref[k][ch].view(np.uint32)), (t, k, ch)
+    # views stay valid until the next submit / drain step even when the GPU runs ahead
+    hp2 = HostTilePipeline(eng, n, h, w, with_uncertainty=True, resolution=(0.5, 1.0))
+    for i, (d, m, u) in enumerate(batches + batches):
+        r = hp2.submit(d, m, u, tag=i % 5)
+        torch.cuda.synchronize()                        # everything queued so far has completed, D2H included
+        if r is not None:
+            ref = got[r[0]][1]
+            assert all(np.array_equal(r[1][ch], ref[ch]) for ch in ref)
+    assert len(list(hp2.drain())) == 2
 
 
 @pytest.mark.parametrize("conn,loops", [("4-connected", False), ("4-connected", True), ("8-connected", True)])
@@ -335,6 +346,37 @@ def test_four_connected_and_self_loops(conn, loops, gpu_device):
     res = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 1.0)] * 3)
     for (d, m, _), r in zip(tiles, res):
         og = graph_cpu.build_graph(d, m, None, (0.5, 1.0), connectivity=conn, include_self_loops=loops)
+        ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
+        assert np.abs(r["confidence"] - ref["confidence"]).max() < TOL
+        assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("kind", ["GCN", "GraphSAGE", "GIN"])
+@pytest.mark.parametrize("loops", [False, True])
+def test_other_backbones_match_oracle(kind, loops, gpu_device):
+    """GCN / GraphSAGE / GIN backbones (reference models/gnn.py:120-143, torch_geometric default arguments) against the
+    CPU restatement (parity unpinned, like GAT): predict() on single graphs, and the per-batch tile entry."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    sd = synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=3, seed=77)
+    m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).eval()
+    gb = GraphBuilder(include_self_loops=loops)
+    tiles = [synthetic.synthetic_tile(h, w, 90 + i, "V1") for i, (h, w) in enumerate([(40, 56), (33, 21), (64, 64)])]
+    for d, mk, _ in tiles[:2]:
+        g = gb.build_graph(d, mk, None, (0.5, 0.5))
+        og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5), include_self_loops=loops)
+        ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+        out = m.predict(g)
+        _compare(out, ref)
+        assert (out["hidden"].cpu() - ref["hidden"]).abs().max().item() < TOL if "hidden" in out else True
+    eng = TileBatchEngine(m, gb, gpu_device)
+    res = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 3)
+    for (d, mk, _), r in zip(tiles, res):
+        og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5), include_self_loops=loops)
         ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
         assert np.abs(r["confidence"] - ref["confidence"]).max() < TOL
         assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4

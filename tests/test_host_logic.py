@@ -40,8 +40,19 @@ def test_state_dict_keys_match_reference_names():
     assert m.gnn.convs[3].bias.shape == (64,) and m.gnn.norms[0].module.weight.shape == (256,)
     # older torch_geometric checkpoints (lin_src / lin_dst) load too
     m.load_state_dict({k: torch.as_tensor(v) for k, v in synthetic.synthetic_state_dict(legacy_lin_src=True).items()})
+    # the other backbones carry torch_geometric's parameter names as well (models/gnn.py:120-143)
+    for kind, keys in (("GCN", ["gnn.convs.0.lin.weight", "gnn.convs.0.bias"]),
+                       ("GraphSAGE", ["gnn.convs.0.lin_l.weight", "gnn.convs.0.lin_l.bias", "gnn.convs.0.lin_r.weight"]),
+                       ("GIN", ["gnn.convs.0.nn.0.weight", "gnn.convs.0.nn.0.bias", "gnn.convs.0.nn.2.weight", "gnn.convs.0.nn.2.bias"])):
+        mk = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=2)
+        sk = set(mk.state_dict())
+        assert all(k in sk for k in keys) and "gnn.norms.1.module.running_var" in sk
+        assert "gnn.convs.0.lin_r.bias" not in sk
+        ref = synthetic.synthetic_state_dict(gnn_type=kind, num_layers=2)
+        assert sk == set(ref)
+        mk.load_state_dict({k: torch.as_tensor(v) for k, v in ref.items()})
     with pytest.raises(NotImplementedError):
-        BathymetricGNN(in_channels=7, gnn_type="GCN", edge_dim=3)
+        BathymetricGNN(in_channels=7, gnn_type="GAT", edge_dim=None)
     with pytest.raises(ValueError):
         BathymetricGNN(in_channels=7, gnn_type="Transformer", edge_dim=3)
 
