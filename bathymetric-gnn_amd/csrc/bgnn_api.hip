@@ -268,6 +268,34 @@ size_t bgnn_model_weight_count(const bgnn_model_desc *d) {
   return n;
 }
 
+// ---- bf16x3 operand split (opt-in matrix path) --------------------------------------------------------------
+// w = hi + lo + O(2^-16 |w|) with hi = bf16(w), lo = bf16(w - hi), round to nearest even.  The image replaces Wt
+// [D][NC] float32 byte for byte: per 16-row half-chunk, per 32-column tile t, per part p (hi, lo), one 1-KiB block in
+// the lane order of v_mfma_f32_32x32x16_bf16's A operand: [k-group 2][column m 32][k 8] bf16.
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+static void pack_split_bf16(const float *Wt, int D, int NC, float *dst_as_float) {
+  uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
+  const int NT = NC / 32;
+  for (int hc = 0; hc < D / 16; ++hc)
+    for (int t = 0; t < NT; ++t)
+      for (int part = 0; part < 2; ++part)
+        for (int kg = 0; kg < 2; ++kg)
+          for (int m = 0; m < 32; ++m)
+            for (int i = 0; i < 8; ++i) {
+              const float w = Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m];
+              const uint16_t hi = bf16_rne(w);
+              const uint16_t v = part == 0 ? hi : bf16_rne(w - bf16_to_f32(hi));
+              dst[((((size_t)hc * NT + t) * 2 + part) * 2 + kg) * 256 + m * 8 + i] = v;
+            }
+}
+
 int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
   BGNN_REQUIRE(ctx && d && w && out, "bgnn_model_create: NULL argument");
   BGNN_REQUIRE(d->hidden == 32 || d->hidden == 64, "hidden_channels=%d unsupported (32 or 64)", d->hidden);
@@ -406,6 +434,24 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     pk[o_l0f_b + o] = (float)s;
   }
 
+  // bf16 hi / lo images of the fused kernels' next-stage weights (layers 1.. and the heads' first layers)
+  std::vector<size_t> o_wsp(L, 0);
+  size_t o_hW0sp = 0;
+  if (gat) {
+    for (int l = 1; l < L; ++l) {
+      const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
+      o_wsp[l] = reserve((size_t)D * HC);
+    }
+    o_hW0sp = reserve((size_t)hid * HT);
+    for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
+      const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
+      std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
+      pack_split_bf16(src.data(), D, HC, pk.data() + o_wsp[l]);
+    }
+    std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
+    pack_split_bf16(src.data(), hid, HT, pk.data() + o_hW0sp);
+  }
+
   bgnn_model *m = new bgnn_model();
   m->ctx = ctx; m->desc = *d; m->blob_floats = pk.size();
   hipError_t e = hipMalloc((void **)&m->blob, pk.size() * sizeof(float));
@@ -431,8 +477,10 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.width = last ? hid : Ly.heads * hid; Ly.concat = !last;
     Ly.Wt = m->blob + lo[l].Wt; Ly.att_src = m->blob + lo[l].as; Ly.att_dst = m->blob + lo[l].ad;
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
+    Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
   }
   m->head_hidden_total = HT;
+  m->hd_W0sp = gat ? m->blob + o_hW0sp : nullptr;
   m->hd_W0t = m->blob + o_hW0t; m->hd_b0 = m->blob + o_hb0; m->hd_W1 = m->blob + o_hW1; m->hd_b1 = m->blob + o_hb1;
   *out = m;
   return BGNN_OK;

@@ -98,6 +98,7 @@ struct BgnnLayer {
   float *V;         // [heads][edge_dim]   folded lin_edge . att_edge
   float *scale;     // [width]  BN weight / sqrt(var + eps)
   float *shift;     // [width]  (conv bias - mean) * scale + BN bias
+  float *Wsp;       // Wt as a bf16 hi / lo split image for the bf16x3 matrix path (same byte geometry as Wt; see pack_split_bf16)
   // non-attention backbones (desc.gnn_type != BGNN_GNN_GAT): Wt = GCN lin^T [hid][hid] | SAGE [lin_l^T ; lin_r^T] [2 hid][hid]
   // with BatchNorm folded in | GIN nn.0^T [hid][hid]; then
   float *b1;        // GIN nn.0 bias [hid]
@@ -115,6 +116,7 @@ struct bgnn_model {
   std::vector<BgnnLayer> layers;
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
+  float *hd_W0sp = nullptr;   // hd_W0t as a bf16 hi / lo split image
   float *hd_W1, *hd_b1;       // second layers packed: cls [classes][hid/2], conf [hid/2], corr [hid/2]; biases
 };
 

@@ -125,6 +125,41 @@ struct MfmaGroups {
   }
 };
 
+// ---- bf16x3 matrix path (opt-in): x = xh + xl, W = Wh + Wl (bf16 each), x W ~= xh Wh + xl Wh + xh Wl with float32
+// accumulation on v_mfma_f32_32x32x16_bf16 -- 3 instructions of 32 cycles per 16 k instead of 8 x 64 cycles of
+// v_mfma_f32_32x32x2_f32, and on the matrix pipe proper: unlike the f32 MFMA (which runs at the VALU rate and blocks
+// its SIMD neighbour) it co-executes with the other workgroup's vector work.  Class logits move by ~6e-6
+// (tools/bf16_split_accuracy.py); the exact-f32 path stays the default.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(const f32x4 &ga, const f32x4 &gb, bf16x8 &hi, bf16x8 &lo) {
+  const float v[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hi[i] = (__bf16)v[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lo[i] = (__bf16)(v[i] - (float)hi[i]);
+}
+
+// one 16-k half-chunk: tile t's W fragments (hi, lo) sit at wh + (2t + part) KiB (+ lane * 16, folded into wh);
+// the fragments of tile t + 1 are requested before tile t's three MFMAs are issued
+template <int NT, int T>
+struct SplitTiles {
+  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const bf16x8 &xh, const bf16x8 &xl, uint32_t wh, f32x4 ah, f32x4 al) {
+    lds_reads_done();
+    f32x4 nh = ah, nl = al;
+    if constexpr (T + 1 < NT) { nh = lds_read4<(2 * (T + 1)) * 1024>(wh); nl = lds_read4<(2 * (T + 1) + 1) * 1024>(wh); }
+    const bf16x8 wh8 = __builtin_bit_cast(bf16x8, ah), wl8 = __builtin_bit_cast(bf16x8, al);
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl8, xh, acc[T], 0, 0, 0);
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh8, xl, acc[T], 0, 0, 0);
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh8, xh, acc[T], 0, 0, 0);
+    if constexpr (T + 1 < NT) SplitTiles<NT, T + 1>::step(acc, xh, xl, wh, nh, nl);
+  }
+  __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const bf16x8 &xh, const bf16x8 &xl, uint32_t wh) {
+    static_assert(T == 0, "entry point");
+    step(acc, xh, xl, wh, lds_read4<0>(wh), lds_read4<1024>(wh));
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
@@ -159,8 +194,9 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int FLOATS = FHR * 32 + 32 * NC + RSZ + FHR + 4 + 128 * APITCH;
 };
 
-template <int HC, int C, int K, int NT, int EPI, int NS>
+template <int HC, int C, int K, int NT, int EPI, int NS, bool SP = false>
 __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fused_kernel(FusedArgs a) {
+  static_assert(!SP || NS == 1, "the bf16x3 path is built for the 4-wave form");
   // (narrow next stages leave registers and LDS for a third workgroup per CU)
   // 4*NS waves, two workgroups per CU.  Wave w: node group ng = w & 3 (cells 32ng..32ng+31, two tile rows) and,
   // for NS = 2, column half nh = w >> 2 of the NC output channels.  Lane (r, hl): node r of the group, k-half hl.
@@ -340,7 +376,11 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 
   const uint32_t slab0 = lds_addr(slab);
   const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + nh * NTL * 32 + r);
-  const uint32_t scsh0 = lds_addr(scsh) + hl * 16;
+  // chunk (16 B = 4 channels) ownership of lane (r, hl) inside a 32-channel slab: exact-f32 path 2j + hl (k = 8j + 4hl + i
+  // of f32 k-step j); bf16x3 path {2hl, 2hl + 1} for k-step 0 and {4 + 2hl, 5 + 2hl} for k-step 1 (k = 16 step + 8hl + i)
+  constexpr uint32_t CX1 = SP ? 16 : 32, CX2 = 64, CX3 = SP ? 80 : 96;
+  const uint32_t scsh0 = lds_addr(scsh) + (SP ? hl * 32 : hl * 16);
+  const uint32_t wsp0 = lds_addr(wbuf) + lane * 16;      // bf16x3: A fragments are stored in lane order
   const uint32_t alx0 = lds_addr(alx + cell * APITCH);
 
   // ---- slabs.  Lane (r, hl) gathers exactly the 16 values it feeds to the MFMA as B operand: channel chunks
@@ -383,10 +423,10 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       for (int b = 0; b <= K; ++b) {
         const int nidx = b == K ? sidx : sidx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
         // slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5))
-        const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ hl) << 4);
+        const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
         f32x4 x[4];
         const float alpha = lds_read1<0>(ap + 4 * b);
-        x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ 32); x[2] = lds_read4<0>(rb ^ 64); x[3] = lds_read4<0>(rb ^ 96);
+        x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ CX1); x[2] = lds_read4<0>(rb ^ CX2); x[3] = lds_read4<0>(rb ^ CX3);
         lds_reads_done();
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
@@ -397,8 +437,8 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {                // two chunks at a time (register budget)
           f32x4 sc0, sc1, sh0, sh1;
-          if (jp == 0) { sc0 = lds_read4<0>(cp); sc1 = lds_read4<32>(cp); sh0 = lds_read4<HC * 4>(cp); sh1 = lds_read4<HC * 4 + 32>(cp); }
-          else { sc0 = lds_read4<64>(cp); sc1 = lds_read4<96>(cp); sh0 = lds_read4<HC * 4 + 64>(cp); sh1 = lds_read4<HC * 4 + 96>(cp); }
+          if (jp == 0) { sc0 = lds_read4<0>(cp); sc1 = lds_read4<CX1>(cp); sh0 = lds_read4<HC * 4>(cp); sh1 = lds_read4<HC * 4 + CX1>(cp); }
+          else { sc0 = lds_read4<CX2>(cp); sc1 = lds_read4<CX3>(cp); sh0 = lds_read4<HC * 4 + CX2>(cp); sh1 = lds_read4<HC * 4 + CX3>(cp); }
           lds_reads_done();
           g[2 * jp] = g[2 * jp] * sc0 + sh0;
           g[2 * jp + 1] = g[2 * jp + 1] * sc1 + sh1;
@@ -417,13 +457,21 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       BGNN_STAMP(5)   // wait for WA + barrier
       if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
       // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
-      if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
+      bf16x8 xh0, xl0, xh1, xl1;
+      if constexpr (SP) { split_bf16(g[0], g[1], xh0, xl0); split_bf16(g[2], g[3], xh1, xl1); }
+      if (!(a.dbg & 2)) {
+        if constexpr (SP) SplitTiles<NTL, 0>::run(acc, xh0, xl0, wsp0);
+        else MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
+      }
       // WB(s) landed; the npc pieces of slab s+1 issued above stay in flight
       if (s + 1 < NSLAB && !(a.dbg & 4)) { if (npc == NPIECE) wait_vm_lgkm<NPIECE>(); else wait_vm_lgkm<NPIECE - 1>(); }
       else wait_vm_lgkm<0>();
       __builtin_amdgcn_s_barrier();                     // every wave is done with W rows 0-15
       if (s + 1 < NSLAB && !(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
-      if (!(a.dbg & 2)) MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
+      if (!(a.dbg & 2)) {
+        if constexpr (SP) SplitTiles<NTL, 0>::run(acc, xh1, xl1, wsp0 + 16 * NC * 4);
+        else MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
+      }
       BGNN_STAMP(6)   // MFMA
       if (s + 1 < NSLAB) {
         wait_lgkm0();
@@ -590,12 +638,12 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   if (a.stamps && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
 }
 
-template <int HC, int C, int K, int NT, int EPI, int NS = 1>
+template <int HC, int C, int K, int NT, int EPI, int NS = 1, bool SP = false>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr int H = HC / C;
   constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI>::FLOATS * 4;
   static bool configured = false;     // per instantiation
-  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS>;
+  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS, SP>;
   size_t lds_launch = lds_bytes;
   if (const char *e = getenv("BGNN_FUSED_LDS_PAD")) lds_launch = std::max(lds_bytes, (size_t)atoi(e) * 1024);   // occupancy experiment
   if (!configured) {
@@ -630,9 +678,18 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   if (Ln.d_in != HC) return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  a.Wt = Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
+  const bool split = getenv("BGNN_SPLIT_BF16") != nullptr;             // opt-in bf16x3 matrix path (read per call)
+  a.Wt = split ? Ln.Wsp : Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
   ProfScope ps(ctx, BGNN_K_FUSED);
+  if (split) {
+#define BGNN_FUSED_SP(hc, nt)                                                                           \
+    if (HC == hc && NC == nt * 32)                                                                      \
+      return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, 1, true>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, 1, true>(ctx, a);
+    BGNN_FUSED_SP(256, 8) BGNN_FUSED_SP(256, 2)
+#undef BGNN_FUSED_SP
+    a.Wt = Ln.Wt;                                                     // other shapes: exact-f32 instances only
+  }
 #define BGNN_FUSED_CASE(hc, nt, ns)                                                                     \
   if (HC == hc && NC == nt * 32)                                                                        \
     return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, ns>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, ns>(ctx, a);
@@ -654,11 +711,14 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  a.Wt = m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1; a.local_std = g->d_local_std;
+  const bool split = getenv("BGNN_SPLIT_BF16") != nullptr;
+  a.Wt = split ? m->hd_W0sp : m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1; a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;
   a.thr_auto = thr_auto; a.thr_review = thr_review; a.norm_floor = norm_floor; a.o = *o;
   a.cls_grid = cls_grid; a.conf_grid = conf_grid; a.corr_grid = corr_grid;
   ProfScope ps(ctx, BGNN_K_FUSED);
+  if (split)
+    return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS, 1, true>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS, 1, true>(ctx, a);
   return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS>(ctx, a);
 }
 
