@@ -281,6 +281,29 @@ def main():
                                       "steps": n_pc, "bytes_per_cell": {"h2d": 5, "d2h": 12},
                                       "note": "host numpy tiles in, host grids out: pinned double-buffered staging, H2D / "
                                               "compute / D2H overlapped on three streams (HostTilePipeline)"}
+        if world == 1 and args.workload == "tiles" and not args.unfused:
+            # Opt-in matrix path, reported BESIDE the headline (never as it): bf16 hi/lo operand split (bf16x3) on the bf16
+            # matrix cores with float32 accumulation.  Same inputs, same timing protocol; the distance of its class logits
+            # to the exact-f32 path is measured on one tile of the batch.
+            from bathymetric_gnn_amd.data import GraphBuilder as _GB
+            g1 = _GB(device=dev).build_graph(depth[0], mask[0], None, (0.5, 0.5))
+            lg_exact = model.predict(g1)["class_logits"].clone()
+            os.environ["BGNN_SPLIT_BF16"] = "1"
+            try:
+                lg_split = model.predict(g1)["class_logits"]
+                for _ in range(2):
+                    step()
+                n_sp = max(4, min(args.steps, 10))
+                torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                for _ in range(n_sp):
+                    step()
+                torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
+            finally:
+                del os.environ["BGNN_SPLIT_BF16"]
+            line["split_bf16x3"] = {"value": nodes_per_step * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
+                                    "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
+                                    "note": "BGNN_SPLIT_BF16=1: fused-layer GEMMs as bf16 hi/lo operand splits on "
+                                            "v_mfma_f32_32x32x16_bf16, float32 accumulate; opt-in, not the headline"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
             line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
