@@ -436,13 +436,14 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
 
   // bf16 hi / lo images of the fused kernels' next-stage weights (layers 1.. and the heads' first layers)
   std::vector<size_t> o_wsp(L, 0);
-  size_t o_hW0sp = 0;
+  size_t o_hW0sp = 0, o_l0fsp = 0;
   if (gat) {
     for (int l = 1; l < L; ++l) {
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       o_wsp[l] = reserve((size_t)D * HC);
     }
     o_hW0sp = reserve((size_t)hid * HT);
+    o_l0fsp = reserve((size_t)hid * HC0);
     for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
@@ -450,6 +451,8 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
     pack_split_bf16(src.data(), hid, HT, pk.data() + o_hW0sp);
+    std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
+    pack_split_bf16(src0.data(), hid, HC0, pk.data() + o_l0fsp);
   }
 
   bgnn_model *m = new bgnn_model();
@@ -460,6 +463,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   if (e != hipSuccess) { (void)hipFree(m->blob); delete m; set_error("hipMemcpy(model) failed: %s", hipGetErrorString(e)); return BGNN_ERR_HIP; }
   m->fe_W0t = m->blob + o_fe_W0t; m->fe_b0 = m->blob + o_fe_b0; m->fe_W1t = m->blob + o_fe_W1t; m->fe_b1 = m->blob + o_fe_b1;
   m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
+  m->l0f_Wsp = gat ? m->blob + o_l0fsp : nullptr;
   m->layers.resize(L);
   for (int l = 0; l < L && !gat; ++l) {
     BgnnLayer &Ly = m->layers[l];
@@ -731,7 +735,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     if (getenv("BGNN_NO_FOLD") == nullptr) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
-                               L0.att_src, L0.att_dst, asdX, L0.heads, hid));
+                               L0.att_src, L0.att_dst, asdX, L0.heads, hid,
+                               getenv("BGNN_SPLIT_BF16") ? m->l0f_Wsp : nullptr));
     } else {
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));

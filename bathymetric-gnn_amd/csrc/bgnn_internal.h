@@ -113,6 +113,7 @@ struct bgnn_model {
   size_t blob_floats = 0;
   float *fe_W0t, *fe_b0, *fe_W1t, *fe_b1;     // [in8][hid], [hid], [hid][hid], [hid]
   float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
+  float *l0f_Wsp = nullptr;   // l0f_Wt as a bf16 hi / lo split image
   std::vector<BgnnLayer> layers;
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
@@ -188,7 +189,7 @@ int launch_generic_build(bgnn_ctx *ctx, bgnn_graph *g, int64_t n_nodes, int32_t 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y,
                     int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu,
                     const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
-                    int H = 0, int C = 0);
+                    int H = 0, int C = 0, const float *Wt_split = nullptr);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                          const float *asd, float *out, int relu);
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,

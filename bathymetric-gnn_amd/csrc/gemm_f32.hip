@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
 // Ablations (BGNN_GEMM_DBG, 8.4 M rows, NC = 256): 3.5 ms as is; 2.3 ms without the MFMAs (= 11 GB at 4.8 TB/s: the
 // memory side alone is HBM-bound); 1.75 ms is the MFMA floor; 4 instead of 8 waves per CU: 4.6 ms.  With two waves per
 // SIMD (128 accumulators each) the two phases overlap only partly; a start stagger of the second wave changes nothing.
-template <int NT, bool ATT>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// SP: bf16x3 matrix path (opt-in, see gat_layer_fused.hip): Wt is then the hi / lo split image of pack_split_bf16 and X
+// is split in registers; lane (r, h) owns k = 16 step + 8h + i of every 16-wide k-step.
+template <int NT, bool ATT, bool SP = false>
 __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   constexpr int NC = NT * 32, K = 64;
   extern __shared__ __attribute__((aligned(128))) float wres_lds[];
@@ -248,9 +252,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   float4 ax[K / 8];
   auto load_x = [&](int64_t rb) {
     const int64_t row = rb + r;
-    const float *xp = a.X + (row < M ? row : M - 1) * a.ldx + 4 * h;
+    const float *xp = a.X + (row < M ? row : M - 1) * a.ldx + (SP ? 8 * h : 4 * h);
 #pragma unroll
-    for (int s = 0; s < K / 8; ++s) ax[s] = *reinterpret_cast<const float4 *>(xp + s * 8);
+    for (int s = 0; s < K / 8; ++s)                  // exact: k = 8s + 4h + i; split: k = 16 (s/2) + 8h + 4 (s&1) + i
+      ax[s] = *reinterpret_cast<const float4 *>(xp + (SP ? (s >> 1) * 16 + (s & 1) * 4 : s * 8));
   };
   if (row0 < M) load_x(row0);
   for (; row0 < M; row0 += stride) {
@@ -259,7 +264,28 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    if (!(a.dbg & 2))
+    if constexpr (SP) {
+      if (!(a.dbg & 2)) {
+#pragma unroll
+        for (int st = 0; st < K / 16; ++st) {
+          const float v[8] = {ax[2 * st].x, ax[2 * st].y, ax[2 * st].z, ax[2 * st].w,
+                              ax[2 * st + 1].x, ax[2 * st + 1].y, ax[2 * st + 1].z, ax[2 * st + 1].w};
+          bf16x8 xh, xl;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xh[i] = (__bf16)v[i];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xl[i] = (__bf16)(v[i] - (float)xh[i]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {               // half-chunk st: tile t, part p at (st * NT * 2 + 2t + p) KiB
+            const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + ((st * NT + t) * 2) * 1024 + lane * 16);
+            const bf16x8 wlo = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + ((st * NT + t) * 2 + 1) * 1024 + lane * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    } else if (!(a.dbg & 2))
 #pragma unroll
     for (int s = 0; s < K / 8; ++s) {
       const float av[4] = {ax[s].x, ax[s].y, ax[s].z, ax[s].w};
@@ -345,11 +371,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   }
 }
 
-template <int NT, bool ATT>
+template <int NT, bool ATT, bool SP = false>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
   constexpr size_t lds_bytes = (size_t)(64 * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
   static bool configured = false;
-  auto kern = gemm_wres64_kernel<NT, ATT>;
+  auto kern = gemm_wres64_kernel<NT, ATT, SP>;
   if (!configured) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     configured = true;
@@ -363,7 +389,7 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
-                    const float *att_dst, float *asd, int H, int C) {
+                    const float *att_dst, float *asd, int H, int C, const float *Wt_split) {
   BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0 && ldy % 4 == 0,
                "gemm_f32: unsupported shape K=%d NC=%d ldx=%d ldy=%d", K, NC, ldx, ldy);
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
@@ -372,9 +398,11 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   static const int gemm_dbg = getenv("BGNN_GEMM_DBG") ? atoi(getenv("BGNN_GEMM_DBG")) : 0;
   GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg};
   static const bool no_wres = getenv("BGNN_NO_WRES") != nullptr;
+  if (!(K == 64 && !no_wres && max_rows >= 65536 && att_src)) Wt_split = nullptr;   // the split image is only read by the W-resident ATT form
   if (K == 64 && !no_wres && max_rows >= 65536) {    // W-resident persistent form
     switch (NC / 32) {
-#define BGNN_WRES_CASE(NT) case NT: return att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
+#define BGNN_WRES_CASE(NT) case NT: return Wt_split ? (a.Wt = Wt_split, launch_wres64<NT, true, true>(ctx, a))      \
+                                   : att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
       BGNN_WRES_CASE(2) BGNN_WRES_CASE(8)
 #undef BGNN_WRES_CASE
       default: break;

@@ -395,6 +395,7 @@ def test_bf16x3_matrix_path(gpu_device, monkeypatch):
     g = gb.build_graph(d, m, None, (0.5, 0.5))
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
     ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+    monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False)
     exact = model.predict(g)
     monkeypatch.setenv("BGNN_SPLIT_BF16", "1")
     split = model.predict(g)
