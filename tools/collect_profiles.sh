@@ -8,15 +8,18 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_fused.json
 python3 $R/bench.py --unfused --no-cpu-baseline > $O/bench_unfused.json
+python3 $R/bench.py --split-bf16 --no-cpu-baseline > $O/bench_split.json
 python3 $R/bench.py --workload vr --vr-budget 50000 --no-cpu-baseline > $O/bench_vr_50k.json
 python3 $R/bench.py --workload vr --vr-budget 1000000 --no-cpu-baseline > $O/bench_vr_1M.json
-for mode in fused unfused; do
+for mode in fused unfused split; do
   flag=""; [ $mode = unfused ] && flag="--unfused"
+  if [ $mode = split ]; then export BGNN_SPLIT_BF16=1; else unset BGNN_SPLIT_BF16; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${mode}_stats -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${mode}_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${mode}_write -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
   echo "$mode profiled"
 done
+unset BGNN_SPLIT_BF16
 # keep the merge small: drop the per-dispatch traces of the stats passes
 find $O -name "*kernel_trace.csv" -path "*_stats*" -delete
 ls $O
