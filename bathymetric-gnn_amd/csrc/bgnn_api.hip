@@ -705,6 +705,18 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   const int64_t *dm = g->d_counts;
   const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr;
   // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid); then lin of layer 0
+  if (!gat && g->kind != 0 && d.gnn_type != BGNN_GNN_GCN) {
+    // foreign graphs: the CSR build dropped explicit self loops (GATConv and GCNConv replace them anyway); SAGEConv and
+    // GINConv treat them as ordinary edges, which the CSR no longer holds
+    int64_t c[4];
+    BGNN_HIP_CHECK(hipMemcpyAsync(c, g->d_counts, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (c[2] != c[1]) {
+      set_error("GraphSAGE / GIN on a foreign graph with explicit self loops (or out-of-range edges: %lld of %lld edges kept) "
+                "is not supported", (long long)c[2], (long long)c[1]);
+      return BGNN_ERR_UNSUPPORTED;
+    }
+  }
   if (!gat) {
     // GCN / GraphSAGE / GIN backbones (gnn.py:120-143; torch_geometric default arguments): plain gathers + GEMMs.
     // Not the hot path: no fusion beyond BatchNorm / bias / ReLU folded into the neighbouring kernel.

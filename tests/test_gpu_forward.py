@@ -408,3 +408,36 @@ def test_bf16x3_matrix_path(gpu_device, monkeypatch):
     r_exact = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
     assert np.abs(r_split["confidence"] - r_exact["confidence"]).max() < 5e-5
     assert (r_split["classification"] == r_exact["classification"]).mean() > 0.999
+
+
+@pytest.mark.parametrize("kind", ["GCN", "GraphSAGE", "GIN"])
+def test_other_backbones_on_foreign_graphs(kind, gpu_device):
+    """A ``Data`` built elsewhere (generic CSR path) through the non-attention backbones: shuffled grid edges, a hub,
+    duplicate edges, isolated nodes.  Explicit self loops: fine for GCN (replaced by its own), refused for SAGE / GIN."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import Data
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    sd = synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=2, seed=5)
+    m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=2, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).eval()
+    rng = np.random.default_rng(3)
+    N, E = 400, 2500
+    ei = rng.integers(0, N - 10, size=(2, E)).astype(np.int64)
+    ei[1, :50] = 7                                                  # hub
+    ei[:, 60:70] = ei[:, 50:60]                                     # duplicate edges
+    keep = ei[0] != ei[1]
+    ei_noloop = ei[:, keep]
+    x = rng.standard_normal((N, 7)).astype(np.float32)
+    ea = rng.standard_normal((ei_noloop.shape[1], 3)).astype(np.float32)
+    out = m.predict(Data(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei_noloop).cuda(),
+                         edge_attr=torch.from_numpy(ea).cuda()))
+    _compare(out, gat_cpu.predict(sd, x, ei_noloop, ea))
+    ei_loop = np.concatenate([ei_noloop, np.stack([np.arange(20, 30), np.arange(20, 30)])], axis=1)
+    ea_loop = rng.standard_normal((ei_loop.shape[1], 3)).astype(np.float32)
+    data = Data(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei_loop).cuda(), edge_attr=torch.from_numpy(ea_loop).cuda())
+    if kind == "GCN":
+        _compare(m.predict(data), gat_cpu.predict(sd, x, ei_loop, ea_loop))
+    else:
+        with pytest.raises(NotImplementedError):
+            m.predict(data)
