@@ -30,8 +30,9 @@ struct StitchArgs {
 };
 
 __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;
+  const int nbx = (a.W + 255) / 256;                     // linear grid: surveys taller than 65 535 rows fit too
+  const int r = blockIdx.x / nbx;
+  const int c = (blockIdx.x - r * nbx) * blockDim.x + threadIdx.x;
   if (c >= a.W) return;
   const float NANF = __builtin_nanf("");
   float acc_conf = NANF, w_conf = 0.0f, acc_corr = NANF, w_corr = 0.0f;
@@ -182,7 +183,9 @@ extern "C" int bgnn_stitch_tiles(bgnn_ctx *ctx, int32_t height, int32_t width, i
                weight_pitch, tile_offsets, classification, confidence, correction, depth, valid_mask,
                auto_correct_threshold, out_classification, out_confidence, out_correction, out_cleaned_depth};
   ProfScope ps(ctx, BGNN_K_SCATTER);
-  hipLaunchKernelGGL(stitch_kernel, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, a);
+  const int64_t n_blocks = (int64_t)((width + 255) / 256) * height;
+  BGNN_REQUIRE(n_blocks < ((int64_t)1 << 31), "bgnn_stitch_tiles: survey too large for one launch (%lld workgroups)", (long long)n_blocks);
+  hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;
 }
