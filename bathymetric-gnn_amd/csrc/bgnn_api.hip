@@ -280,7 +280,35 @@ static inline uint16_t bf16_rne(float f) {
 }
 static inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-static void pack_split_bf16(const float *Wt, int D, int NC, float *dst_as_float) {
+static inline uint16_t f16_rne(float f) {               // float32 -> IEEE half, round to nearest even, overflow -> inf
+  uint32_t u; memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+  uint32_t m = u & 0x7fffffu;
+  if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (e <= 0) {                                            // subnormal half (or zero)
+    if (e < -10) return (uint16_t)sign;
+    m |= 0x800000u;
+    const int shift = 14 - e;                              // 24-bit significand -> 10 bits at exponent 2^-14
+    const uint32_t half = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    return (uint16_t)(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
+  }
+  const uint32_t half = ((uint32_t)e << 10) | (m >> 13), rem = m & 0x1fffu;
+  return (uint16_t)(sign | (half + ((rem > 0x1000u || (rem == 0x1000u && (half & 1))) ? 1 : 0)));
+}
+static inline float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) u = sign;
+    else { int k = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++k; } u = sign | ((uint32_t)(113 - k) << 23) | ((mm & 0x3ffu) << 13); }
+  } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+  else u = sign | ((e + 112) << 23) | (m << 13);
+  float f; memcpy(&f, &u, 4); return f;
+}
+
+static void pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool f16) {
   uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
   const int NT = NC / 32;
   for (int hc = 0; hc < D / 16; ++hc)
@@ -290,8 +318,8 @@ static void pack_split_bf16(const float *Wt, int D, int NC, float *dst_as_float)
           for (int m = 0; m < 32; ++m)
             for (int i = 0; i < 8; ++i) {
               const float w = Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m];
-              const uint16_t hi = bf16_rne(w);
-              const uint16_t v = part == 0 ? hi : bf16_rne(w - bf16_to_f32(hi));
+              const uint16_t hi = f16 ? f16_rne(w) : bf16_rne(w);
+              const uint16_t v = part == 0 ? hi : f16 ? f16_rne(w - f16_to_f32(hi)) : bf16_rne(w - bf16_to_f32(hi));
               dst[((((size_t)hc * NT + t) * 2 + part) * 2 + kg) * 256 + m * 8 + i] = v;
             }
 }
@@ -434,25 +462,29 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     pk[o_l0f_b + o] = (float)s;
   }
 
-  // bf16 hi / lo images of the fused kernels' next-stage weights (layers 1.. and the heads' first layers)
-  std::vector<size_t> o_wsp(L, 0);
-  size_t o_hW0sp = 0, o_l0fsp = 0;
+  // bf16 and float16 hi / lo images of the fused kernels' next-stage weights (layers 1.., the heads' first layers) and
+  // of the folded layer-0 weight
+  std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0);
+  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0;
   if (gat) {
     for (int l = 1; l < L; ++l) {
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
-      o_wsp[l] = reserve((size_t)D * HC);
+      o_wsp[l] = reserve((size_t)D * HC); o_wsp16[l] = reserve((size_t)D * HC);
     }
-    o_hW0sp = reserve((size_t)hid * HT);
-    o_l0fsp = reserve((size_t)hid * HC0);
+    o_hW0sp = reserve((size_t)hid * HT); o_hW0sp16 = reserve((size_t)hid * HT);
+    o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0);
     for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
-      pack_split_bf16(src.data(), D, HC, pk.data() + o_wsp[l]);
+      pack_split(src.data(), D, HC, pk.data() + o_wsp[l], false);
+      pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true);
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
-    pack_split_bf16(src.data(), hid, HT, pk.data() + o_hW0sp);
+    pack_split(src.data(), hid, HT, pk.data() + o_hW0sp, false);
+    pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true);
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
-    pack_split_bf16(src0.data(), hid, HC0, pk.data() + o_l0fsp);
+    pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
+    pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true);
   }
 
   bgnn_model *m = new bgnn_model();
@@ -464,6 +496,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->fe_W0t = m->blob + o_fe_W0t; m->fe_b0 = m->blob + o_fe_b0; m->fe_W1t = m->blob + o_fe_W1t; m->fe_b1 = m->blob + o_fe_b1;
   m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
   m->l0f_Wsp = gat ? m->blob + o_l0fsp : nullptr;
+  m->l0f_Wsp16 = gat ? m->blob + o_l0fsp16 : nullptr;
   m->layers.resize(L);
   for (int l = 0; l < L && !gat; ++l) {
     BgnnLayer &Ly = m->layers[l];
@@ -482,9 +515,11 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.Wt = m->blob + lo[l].Wt; Ly.att_src = m->blob + lo[l].as; Ly.att_dst = m->blob + lo[l].ad;
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
+    Ly.Wsp16 = l > 0 ? m->blob + o_wsp16[l] : nullptr;
   }
   m->head_hidden_total = HT;
   m->hd_W0sp = gat ? m->blob + o_hW0sp : nullptr;
+  m->hd_W0sp16 = gat ? m->blob + o_hW0sp16 : nullptr;
   m->hd_W0t = m->blob + o_hW0t; m->hd_b0 = m->blob + o_hb0; m->hd_W1 = m->blob + o_hW1; m->hd_b1 = m->blob + o_hb1;
   *out = m;
   return BGNN_OK;
@@ -748,7 +783,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
                                L0.att_src, L0.att_dst, asdX, L0.heads, hid,
-                               getenv("BGNN_SPLIT_BF16") ? m->l0f_Wsp : nullptr));
+                               bgnn_split_mode() == 2 ? m->l0f_Wsp16 : bgnn_split_mode() == 1 ? m->l0f_Wsp : nullptr,
+                               bgnn_split_mode()));
     } else {
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <cstdlib>
 #include <vector>
 #include <map>
 
@@ -98,7 +99,8 @@ struct BgnnLayer {
   float *V;         // [heads][edge_dim]   folded lin_edge . att_edge
   float *scale;     // [width]  BN weight / sqrt(var + eps)
   float *shift;     // [width]  (conv bias - mean) * scale + BN bias
-  float *Wsp;       // Wt as a bf16 hi / lo split image for the bf16x3 matrix path (same byte geometry as Wt; see pack_split_bf16)
+  float *Wsp;       // Wt as a bf16 hi / lo split image for the bf16x3 matrix path (same byte geometry as Wt; see pack_split)
+  float *Wsp16;     // the same with float16 parts (fp16x3)
   // non-attention backbones (desc.gnn_type != BGNN_GNN_GAT): Wt = GCN lin^T [hid][hid] | SAGE [lin_l^T ; lin_r^T] [2 hid][hid]
   // with BatchNorm folded in | GIN nn.0^T [hid][hid]; then
   float *b1;        // GIN nn.0 bias [hid]
@@ -113,11 +115,11 @@ struct bgnn_model {
   size_t blob_floats = 0;
   float *fe_W0t, *fe_b0, *fe_W1t, *fe_b1;     // [in8][hid], [hid], [hid][hid], [hid]
   float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
-  float *l0f_Wsp = nullptr;   // l0f_Wt as a bf16 hi / lo split image
+  float *l0f_Wsp = nullptr, *l0f_Wsp16 = nullptr;   // l0f_Wt as bf16 / float16 hi / lo split images
   std::vector<BgnnLayer> layers;
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
-  float *hd_W0sp = nullptr;   // hd_W0t as a bf16 hi / lo split image
+  float *hd_W0sp = nullptr, *hd_W0sp16 = nullptr;   // hd_W0t as bf16 / float16 hi / lo split images
   float *hd_W1, *hd_b1;       // second layers packed: cls [classes][hid/2], conf [hid/2], corr [hid/2]; biases
 };
 
@@ -189,7 +191,7 @@ int launch_generic_build(bgnn_ctx *ctx, bgnn_graph *g, int64_t n_nodes, int32_t 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y,
                     int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu,
                     const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
-                    int H = 0, int C = 0, const float *Wt_split = nullptr);
+                    int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                          const float *asd, float *out, int relu);
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
@@ -200,6 +202,8 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
                              const float *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);
+// opt-in matrix path, read per call: 0 exact f32, 1 bf16x3 (BGNN_SPLIT_BF16), 2 fp16x3 (BGNN_SPLIT_F16)
+static inline int bgnn_split_mode() { return getenv("BGNN_SPLIT_F16") ? 2 : getenv("BGNN_SPLIT_BF16") ? 1 : 0; }
 int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv);
 int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const float *x, int D, const float *dinv,
                            const float *scale, const float *shift, int relu, float *out, int ldo, float *copy_self);

@@ -21,6 +21,7 @@
 // :427-449 (predict), models/pipeline.py:278-307 (grids); GATConv per SURVEY Appendix B.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "gat_tile_common.h"
 
 namespace bgnn {
@@ -130,31 +131,42 @@ struct MfmaGroups {
 // v_mfma_f32_32x32x2_f32, and on the matrix pipe proper: unlike the f32 MFMA (which runs at the VALU rate and blocks
 // its SIMD neighbour) it co-executes with the other workgroup's vector work.  Class logits move by ~6e-6
 // (tools/bf16_split_accuracy.py); the exact-f32 path stays the default.
+// fp16x3 (BGNN_SPLIT_F16=1) is the same scheme with float16 parts on v_mfma_f32_32x32x16_f16: 11-bit parts instead of 8,
+// so hi + lo carries 22 bits and the logits land within ~5e-7 of the float64 forward (float32 itself: 2e-7) -- but only
+// while |x| stays below 65 504 (float16 range); larger activations would saturate.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split_bf16(const f32x4 &ga, const f32x4 &gb, bf16x8 &hi, bf16x8 &lo) {
+template <typename V8, typename E>
+__device__ __forceinline__ void split_lp(const f32x4 &ga, const f32x4 &gb, V8 &hi, V8 &lo) {
   const float v[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) hi[i] = (__bf16)v[i];
+  for (int i = 0; i < 8; ++i) hi[i] = (E)v[i];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  for (int i = 0; i < 8; ++i) lo[i] = (E)(v[i] - (float)hi[i]);
+}
+__device__ __forceinline__ f32x16 mfma_lp(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_lp(const f16x8 &a, const f16x8 &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 // one 16-k half-chunk: tile t's W fragments (hi, lo) sit at wh + (2t + part) KiB (+ lane * 16, folded into wh);
 // the fragments of tile t + 1 are requested before tile t's three MFMAs are issued
-template <int NT, int T>
+template <int NT, int T, typename V8>
 struct SplitTiles {
-  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const bf16x8 &xh, const bf16x8 &xl, uint32_t wh, f32x4 ah, f32x4 al) {
+  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const V8 &xh, const V8 &xl, uint32_t wh, f32x4 ah, f32x4 al) {
     lds_reads_done();
     f32x4 nh = ah, nl = al;
     if constexpr (T + 1 < NT) { nh = lds_read4<(2 * (T + 1)) * 1024>(wh); nl = lds_read4<(2 * (T + 1) + 1) * 1024>(wh); }
-    const bf16x8 wh8 = __builtin_bit_cast(bf16x8, ah), wl8 = __builtin_bit_cast(bf16x8, al);
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl8, xh, acc[T], 0, 0, 0);
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh8, xl, acc[T], 0, 0, 0);
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh8, xh, acc[T], 0, 0, 0);
-    if constexpr (T + 1 < NT) SplitTiles<NT, T + 1>::step(acc, xh, xl, wh, nh, nl);
+    const V8 wh8 = __builtin_bit_cast(V8, ah), wl8 = __builtin_bit_cast(V8, al);
+    acc[T] = mfma_lp(wl8, xh, acc[T]);
+    acc[T] = mfma_lp(wh8, xl, acc[T]);
+    acc[T] = mfma_lp(wh8, xh, acc[T]);
+    if constexpr (T + 1 < NT) SplitTiles<NT, T + 1, V8>::step(acc, xh, xl, wh, nh, nl);
   }
-  __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const bf16x8 &xh, const bf16x8 &xl, uint32_t wh) {
+  __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const V8 &xh, const V8 &xl, uint32_t wh) {
     static_assert(T == 0, "entry point");
     step(acc, xh, xl, wh, lds_read4<0>(wh), lds_read4<1024>(wh));
   }
@@ -194,7 +206,7 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int FLOATS = FHR * 32 + 32 * NC + RSZ + FHR + 4 + 128 * APITCH;
 };
 
-template <int HC, int C, int K, int NT, int EPI, int NS, bool SP = false>
+template <int HC, int C, int K, int NT, int EPI, int NS, int SP = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3
 __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fused_kernel(FusedArgs a) {
   static_assert(!SP || NS == 1, "the bf16x3 path is built for the 4-wave form");
   // (narrow next stages leave registers and LDS for a third workgroup per CU)
@@ -457,10 +469,12 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       BGNN_STAMP(5)   // wait for WA + barrier
       if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
       // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
-      bf16x8 xh0, xl0, xh1, xl1;
-      if constexpr (SP) { split_bf16(g[0], g[1], xh0, xl0); split_bf16(g[2], g[3], xh1, xl1); }
+      using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
+      using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
+      LP8 xh0, xl0, xh1, xl1;
+      if constexpr (SP != 0) { split_lp<LP8, LPE>(g[0], g[1], xh0, xl0); split_lp<LP8, LPE>(g[2], g[3], xh1, xl1); }
       if (!(a.dbg & 2)) {
-        if constexpr (SP) SplitTiles<NTL, 0>::run(acc, xh0, xl0, wsp0);
+        if constexpr (SP != 0) SplitTiles<NTL, 0, LP8>::run(acc, xh0, xl0, wsp0);
         else MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
       }
       // WB(s) landed; the npc pieces of slab s+1 issued above stay in flight
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       __builtin_amdgcn_s_barrier();                     // every wave is done with W rows 0-15
       if (s + 1 < NSLAB && !(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
       if (!(a.dbg & 2)) {
-        if constexpr (SP) SplitTiles<NTL, 0>::run(acc, xh1, xl1, wsp0 + 16 * NC * 4);
+        if constexpr (SP != 0) SplitTiles<NTL, 0, LP8>::run(acc, xh1, xl1, wsp0 + 16 * NC * 4);
         else MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
       }
       BGNN_STAMP(6)   // MFMA
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   if (a.stamps && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
 }
 
-template <int HC, int C, int K, int NT, int EPI, int NS = 1, bool SP = false>
+template <int HC, int C, int K, int NT, int EPI, int NS = 1, int SP = 0>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr int H = HC / C;
   constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI>::FLOATS * 4;
@@ -678,14 +692,18 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   if (Ln.d_in != HC) return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  const bool split = getenv("BGNN_SPLIT_BF16") != nullptr;             // opt-in bf16x3 matrix path (read per call)
-  a.Wt = split ? Ln.Wsp : Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
+  const int split = bgnn_split_mode();                                 // opt-in bf16x3 / fp16x3 matrix path (read per call)
+  a.Wt = split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next;
+  a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
   ProfScope ps(ctx, BGNN_K_FUSED);
   if (split) {
 #define BGNN_FUSED_SP(hc, nt)                                                                           \
-    if (HC == hc && NC == nt * 32)                                                                      \
-      return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, 1, true>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, 1, true>(ctx, a);
+    if (HC == hc && NC == nt * 32) {                                                                    \
+      if (split == 2)                                                                                   \
+        return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, 1, 2>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, 1, 2>(ctx, a); \
+      return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, 1, 1>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, 1, 1>(ctx, a);   \
+    }
     BGNN_FUSED_SP(256, 8) BGNN_FUSED_SP(256, 2)
 #undef BGNN_FUSED_SP
     a.Wt = Ln.Wt;                                                     // other shapes: exact-f32 instances only
@@ -711,14 +729,17 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  const bool split = getenv("BGNN_SPLIT_BF16") != nullptr;
-  a.Wt = split ? m->hd_W0sp : m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1; a.local_std = g->d_local_std;
+  const int split = bgnn_split_mode();
+  a.Wt = split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
+  a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;
   a.thr_auto = thr_auto; a.thr_review = thr_review; a.norm_floor = norm_floor; a.o = *o;
   a.cls_grid = cls_grid; a.conf_grid = conf_grid; a.corr_grid = corr_grid;
   ProfScope ps(ctx, BGNN_K_FUSED);
-  if (split)
-    return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS, 1, true>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS, 1, true>(ctx, a);
+  if (split == 2)
+    return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS, 1, 2>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS, 1, 2>(ctx, a);
+  if (split == 1)
+    return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS, 1, 1>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS, 1, 1>(ctx, a);
   return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS>(ctx, a);
 }
 

@@ -19,6 +19,7 @@
 //     then holds 16 output CHANNELS of ONE row (4 groups of 4 consecutive channels), so bias /
 //     ReLU / the attention dot products are in-lane work and stores are float4.
 #include <stdlib.h>
+#include <type_traits>
 #include "bgnn_internal.h"
 
 namespace bgnn {
@@ -217,10 +218,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
 // memory side alone is HBM-bound); 1.75 ms is the MFMA floor; 4 instead of 8 waves per CU: 4.6 ms.  With two waves per
 // SIMD (128 accumulators each) the two phases overlap only partly; a start stagger of the second wave changes nothing.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_lp(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_lp(const f16x8 &a, const f16x8 &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
-// SP: bf16x3 matrix path (opt-in, see gat_layer_fused.hip): Wt is then the hi / lo split image of pack_split_bf16 and X
+// SP (1 bf16x3, 2 fp16x3): operand-split matrix path (opt-in, see gat_layer_fused.hip): Wt is then the hi / lo split image of pack_split_bf16 and X
 // is split in registers; lane (r, h) owns k = 16 step + 8h + i of every 16-wide k-step.
-template <int NT, bool ATT, bool SP = false>
+template <int NT, bool ATT, int SP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   constexpr int NC = NT * 32, K = 64;
   extern __shared__ __attribute__((aligned(128))) float wres_lds[];
@@ -264,24 +272,26 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    if constexpr (SP) {
+    if constexpr (SP != 0) {
+      using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
+      using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
       if (!(a.dbg & 2)) {
 #pragma unroll
         for (int st = 0; st < K / 16; ++st) {
           const float v[8] = {ax[2 * st].x, ax[2 * st].y, ax[2 * st].z, ax[2 * st].w,
                               ax[2 * st + 1].x, ax[2 * st + 1].y, ax[2 * st + 1].z, ax[2 * st + 1].w};
-          bf16x8 xh, xl;
+          LP8 xh, xl;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) xh[i] = (__bf16)v[i];
+          for (int i = 0; i < 8; ++i) xh[i] = (LPE)v[i];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) xl[i] = (__bf16)(v[i] - (float)xh[i]);
+          for (int i = 0; i < 8; ++i) xl[i] = (LPE)(v[i] - (float)xh[i]);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {               // half-chunk st: tile t, part p at (st * NT * 2 + 2t + p) KiB
-            const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + ((st * NT + t) * 2) * 1024 + lane * 16);
-            const bf16x8 wlo = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + ((st * NT + t) * 2 + 1) * 1024 + lane * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[t], 0, 0, 0);
+            const LP8 wh = *reinterpret_cast<const LP8 *>(reinterpret_cast<const char *>(wl) + ((st * NT + t) * 2) * 1024 + lane * 16);
+            const LP8 wlo = *reinterpret_cast<const LP8 *>(reinterpret_cast<const char *>(wl) + ((st * NT + t) * 2 + 1) * 1024 + lane * 16);
+            acc[t] = mfma_lp(wlo, xh, acc[t]);
+            acc[t] = mfma_lp(wh, xl, acc[t]);
+            acc[t] = mfma_lp(wh, xh, acc[t]);
           }
         }
       }
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   }
 }
 
-template <int NT, bool ATT, bool SP = false>
+template <int NT, bool ATT, int SP = 0>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
   constexpr size_t lds_bytes = (size_t)(64 * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
   static bool configured = false;
@@ -389,7 +399,7 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
-                    const float *att_dst, float *asd, int H, int C, const float *Wt_split) {
+                    const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode) {
   BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0 && ldy % 4 == 0,
                "gemm_f32: unsupported shape K=%d NC=%d ldx=%d ldy=%d", K, NC, ldx, ldy);
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
@@ -401,8 +411,9 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (!(K == 64 && !no_wres && max_rows >= 65536 && att_src)) Wt_split = nullptr;   // the split image is only read by the W-resident ATT form
   if (K == 64 && !no_wres && max_rows >= 65536) {    // W-resident persistent form
     switch (NC / 32) {
-#define BGNN_WRES_CASE(NT) case NT: return Wt_split ? (a.Wt = Wt_split, launch_wres64<NT, true, true>(ctx, a))      \
-                                   : att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
+#define BGNN_WRES_CASE(NT) case NT:                                                                                 \
+        if (Wt_split) { a.Wt = Wt_split; return split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \
+        return att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
       BGNN_WRES_CASE(2) BGNN_WRES_CASE(8)
 #undef BGNN_WRES_CASE
       default: break;

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-f16", action="store_true",
+                    help="opt-in matrix path: float16 hi/lo operand split (fp16x3), float32 accumulation (|activations| < 65504)")
     ap.add_argument("--split-bf16", action="store_true",
                     help="opt-in matrix path: bf16 hi/lo operand split (bf16x3) with float32 accumulation instead of exact-f32 MFMAs")
     ap.add_argument("--unfused", action="store_true",
@@ -121,7 +123,9 @@ def main():
         os.environ["BGNN_NO_FUSED"] = "1"
     if args.split_bf16:
         os.environ["BGNN_SPLIT_BF16"] = "1"
-    split_main = "BGNN_SPLIT_BF16" in os.environ
+    if args.split_f16:
+        os.environ["BGNN_SPLIT_F16"] = "1"
+    split_main = "fp16x3" if "BGNN_SPLIT_F16" in os.environ else "bf16x3" if "BGNN_SPLIT_BF16" in os.environ else None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +240,7 @@ def main():
         if prof["fused"]["launches"]:
             if split_main:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", 3 * am["fused_flops"],
-                                           "bf16x3: executed flops = 3 x algorithmic, priced against the dense bf16 MFMA peak")
+                                           f"{split_main}: executed flops = 3 x algorithmic, priced against the dense bf16 / f16 MFMA peak")
             else:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma", am["fused_flops"],
                                            "K4 gather-softmax-aggregate fused with the next layer's exact-f32 MFMA GEMM (last: heads + scatter)")
@@ -265,14 +269,14 @@ def main():
             "metric": "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (bf16x3 split-operand MFMA, f32 accumulate)" if split_main else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": f"f32 ({split_main} split-operand MFMA, f32 accumulate)" if split_main else "f32", "data": "synthetic",
             "config": {"workload": workload_name,
                        "tiles_per_gpu": B if args.workload == "tiles" else args.vr_grids, "tile": S if args.workload == "tiles" else "3..50",
                        "nodes_per_step_per_gpu": nodes_per_step,
                        "parallelism": f"tile-sharded x{world}, no collective"},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")},
             "rooflines": roofs, "kernels": kernels, "path": "unfused" if args.unfused else "fused",
-            "matrix_path": "bf16x3 split (opt-in)" if split_main else "exact f32",
+            "matrix_path": f"{split_main} split (opt-in)" if split_main else "exact f32",
         }
         if world == 1 and args.workload == "tiles" and not args.unfused:
             # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
@@ -301,22 +305,24 @@ def main():
             from bathymetric_gnn_amd.data import GraphBuilder as _GB
             g1 = _GB(device=dev).build_graph(depth[0], mask[0], None, (0.5, 0.5))
             lg_exact = model.predict(g1)["class_logits"].clone()
-            os.environ["BGNN_SPLIT_BF16"] = "1"
-            try:
-                lg_split = model.predict(g1)["class_logits"]
-                for _ in range(2):
-                    step()
-                n_sp = max(4, min(args.steps, 10))
-                torch.cuda.synchronize(dev); t2 = time.perf_counter()
-                for _ in range(n_sp):
-                    step()
-                torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
-            finally:
-                del os.environ["BGNN_SPLIT_BF16"]
-            line["split_bf16x3"] = {"value": nodes_per_step * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
-                                    "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
-                                    "note": "BGNN_SPLIT_BF16=1: fused-layer GEMMs as bf16 hi/lo operand splits on "
-                                            "v_mfma_f32_32x32x16_bf16, float32 accumulate; opt-in, not the headline"}
+            for key, env, instr in (("split_bf16x3", "BGNN_SPLIT_BF16", "v_mfma_f32_32x32x16_bf16"),
+                                    ("split_fp16x3", "BGNN_SPLIT_F16", "v_mfma_f32_32x32x16_f16")):
+                os.environ[env] = "1"
+                try:
+                    lg_split = model.predict(g1)["class_logits"]
+                    for _ in range(2):
+                        step()
+                    n_sp = max(4, min(args.steps, 10))
+                    torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                    for _ in range(n_sp):
+                        step()
+                    torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
+                finally:
+                    del os.environ[env]
+                line[key] = {"value": nodes_per_step * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
+                             "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
+                             "note": f"{env}=1: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
+                                     "opt-in, not the headline"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
             line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

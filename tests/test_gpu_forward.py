@@ -382,9 +382,10 @@ def test_other_backbones_match_oracle(kind, loops, gpu_device):
         assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4
 
 
-def test_bf16x3_matrix_path(gpu_device, monkeypatch):
-    """Opt-in BGNN_SPLIT_BF16=1: the fused kernels' matrix products run as bf16 hi/lo operand splits with float32
-    accumulation.  Same 1e-4 bar against the float32 oracle; the distance to the exact-f32 path is reported and bounded."""
+@pytest.mark.parametrize("env,bound", [("BGNN_SPLIT_BF16", 5e-5), ("BGNN_SPLIT_F16", 5e-6)])
+def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
+    """Opt-in BGNN_SPLIT_BF16=1 / BGNN_SPLIT_F16=1: the layer matrix products run as bf16 / float16 hi/lo operand splits
+    with float32 accumulation.  Same 1e-4 bar against the float32 oracle; the distance to the exact-f32 path is reported and bounded."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
@@ -395,16 +396,16 @@ def test_bf16x3_matrix_path(gpu_device, monkeypatch):
     g = gb.build_graph(d, m, None, (0.5, 0.5))
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
     ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
-    monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False)
+    monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
     exact = model.predict(g)
-    monkeypatch.setenv("BGNN_SPLIT_BF16", "1")
+    monkeypatch.setenv(env, "1")
     split = model.predict(g)
     _compare(split, ref)
     diff = (split["class_logits"] - exact["class_logits"]).abs().max().item()
-    assert 0 < diff < 5e-5, diff                     # a different code path (not bit-equal), well inside the bar
+    assert 0 < diff < bound, diff                    # a different code path (not bit-equal), well inside the bar
     eng = TileBatchEngine(model, gb, gpu_device)
     r_split = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
-    monkeypatch.delenv("BGNN_SPLIT_BF16")
+    monkeypatch.delenv(env)
     r_exact = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
     assert np.abs(r_split["confidence"] - r_exact["confidence"]).max() < 5e-5
     assert (r_split["classification"] == r_exact["classification"]).mean() > 0.999
