@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_fused.json
 python3 $R/bench.py --unfused --no-cpu-baseline > $O/bench_unfused.json
 python3 $R/bench.py --split-bf16 --no-cpu-baseline > $O/bench_split.json
+python3 $R/bench.py --split-f16 --no-cpu-baseline > $O/bench_split_f16.json
 python3 $R/bench.py --workload vr --vr-budget 50000 --no-cpu-baseline > $O/bench_vr_50k.json
 python3 $R/bench.py --workload vr --vr-budget 1000000 --no-cpu-baseline > $O/bench_vr_1M.json
 for mode in fused unfused split; do
