@@ -80,3 +80,21 @@ def test_weight_count_other_backbones(kind, per_layer, lib):
     fe = 64 * 7 + 64 + 64 * 64 + 64
     heads = (32 * 64 + 32 + 3 * 32 + 3) + 2 * (32 * 64 + 32 + 32 + 1)
     assert lib.bgnn_model_weight_count(C.byref(d)) == fe + 3 * (per_layer + 4 * 64) + heads == m.pack_weights().size
+
+
+def test_header_is_plain_c_and_library_loads_from_c(tmp_path):
+    """include/bgnn.h compiles as C99 (-pedantic) and a C program resolves every declared entry point with dlsym."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi_smoke.c"), "-o", str(exe), "-ldl"], check=True)
+    r = subprocess.run([str(exe), os.path.join(root, "bathymetric-gnn_amd", "libbgnn_hip.so")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok")
+    declared = set(declared_symbols())
+    src = open(os.path.join(root, "tests", "c_abi_smoke.c")).read()
+    assert declared == set(re.findall(r"RESOLVE\((bgnn_[a-z_0-9]+)\)", src))
