@@ -308,7 +308,11 @@ static inline float f16_to_f32(uint16_t h) {
   float f; memcpy(&f, &u, 4); return f;
 }
 
-static void pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool f16) {
+// returns false when a float16 image would overflow (|w| >= 65504): the caller then leaves that image out
+static bool pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool f16) {
+  if (f16)
+    for (size_t i = 0; i < (size_t)D * NC; ++i)
+      if (!(std::fabs(Wt[i]) < 65504.0f)) return false;
   uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
   const int NT = NC / 32;
   for (int hc = 0; hc < D / 16; ++hc)
@@ -322,6 +326,7 @@ static void pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool
               const uint16_t v = part == 0 ? hi : f16 ? f16_rne(w - f16_to_f32(hi)) : bf16_rne(w - bf16_to_f32(hi));
               dst[((((size_t)hc * NT + t) * 2 + part) * 2 + kg) * 256 + m * 8 + i] = v;
             }
+  return true;
 }
 
 int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
@@ -466,6 +471,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   // of the folded layer-0 weight
   std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0);
   size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0;
+  bool f16_ok = true;                  // every weight fits float16: else BGNN_SPLIT_F16 falls back to the bf16 split
   if (gat) {
     for (int l = 1; l < L; ++l) {
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
@@ -477,14 +483,14 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
       pack_split(src.data(), D, HC, pk.data() + o_wsp[l], false);
-      pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true);
+      if (!pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true)) f16_ok = false;
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
     pack_split(src.data(), hid, HT, pk.data() + o_hW0sp, false);
-    pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true);
+    if (!pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true)) f16_ok = false;
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
-    pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true);
+    if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
   }
 
   bgnn_model *m = new bgnn_model();
@@ -496,7 +502,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->fe_W0t = m->blob + o_fe_W0t; m->fe_b0 = m->blob + o_fe_b0; m->fe_W1t = m->blob + o_fe_W1t; m->fe_b1 = m->blob + o_fe_b1;
   m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
   m->l0f_Wsp = gat ? m->blob + o_l0fsp : nullptr;
-  m->l0f_Wsp16 = gat ? m->blob + o_l0fsp16 : nullptr;
+  m->l0f_Wsp16 = gat && f16_ok ? m->blob + o_l0fsp16 : nullptr;
   m->layers.resize(L);
   for (int l = 0; l < L && !gat; ++l) {
     BgnnLayer &Ly = m->layers[l];
@@ -515,11 +521,11 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.Wt = m->blob + lo[l].Wt; Ly.att_src = m->blob + lo[l].as; Ly.att_dst = m->blob + lo[l].ad;
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
-    Ly.Wsp16 = l > 0 ? m->blob + o_wsp16[l] : nullptr;
+    Ly.Wsp16 = l > 0 && f16_ok ? m->blob + o_wsp16[l] : nullptr;
   }
   m->head_hidden_total = HT;
   m->hd_W0sp = gat ? m->blob + o_hW0sp : nullptr;
-  m->hd_W0sp16 = gat ? m->blob + o_hW0sp16 : nullptr;
+  m->hd_W0sp16 = gat && f16_ok ? m->blob + o_hW0sp16 : nullptr;
   m->hd_W0t = m->blob + o_hW0t; m->hd_b0 = m->blob + o_hb0; m->hd_W1 = m->blob + o_hW1; m->hd_b1 = m->blob + o_hb1;
   *out = m;
   return BGNN_OK;
@@ -783,8 +789,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
                                L0.att_src, L0.att_dst, asdX, L0.heads, hid,
-                               bgnn_split_mode() == 2 ? m->l0f_Wsp16 : bgnn_split_mode() == 1 ? m->l0f_Wsp : nullptr,
-                               bgnn_split_mode()));
+                               bgnn_split_mode() == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : bgnn_split_mode() ? m->l0f_Wsp : nullptr,
+                               bgnn_split_mode() == 2 && m->l0f_Wsp16 ? 2 : bgnn_split_mode() ? 1 : 0));
     } else {
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));

@@ -692,7 +692,8 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   if (Ln.d_in != HC) return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  const int split = bgnn_split_mode();                                 // opt-in bf16x3 / fp16x3 matrix path (read per call)
+  int split = bgnn_split_mode();                                       // opt-in bf16x3 / fp16x3 matrix path (read per call)
+  if (split == 2 && !Ln.Wsp16) split = 1;                              // a weight beyond float16's range: bf16 split instead
   a.Wt = split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next;
   a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
@@ -729,7 +730,8 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  const int split = bgnn_split_mode();
+  int split = bgnn_split_mode();
+  if (split == 2 && !m->hd_W0sp16) split = 1;
   a.Wt = split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
   a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;

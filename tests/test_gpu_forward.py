@@ -442,3 +442,23 @@ def test_other_backbones_on_foreign_graphs(kind, gpu_device):
     else:
         with pytest.raises(NotImplementedError):
             m.predict(data)
+
+
+def test_fp16_split_falls_back_when_a_weight_exceeds_float16(gpu_device, monkeypatch):
+    """BGNN_SPLIT_F16 with a weight beyond 65 504: the float16 image is left out at model load and the bf16 split runs."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    sd = dict(synthetic.synthetic_state_dict(in_channels=7, seed=1234))
+    w = np.array(sd["gnn.convs.1.lin.weight"], copy=True); w[3, 5] = 1.0e5
+    sd["gnn.convs.1.lin.weight"] = w
+    model = _model(sd)
+    d, m, _ = synthetic.synthetic_tile(48, 40, 6, "V1")
+    g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
+    monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
+    exact = model.predict(g)["class_logits"].clone()
+    monkeypatch.setenv("BGNN_SPLIT_F16", "1")
+    f16 = model.predict(g)["class_logits"].clone()
+    monkeypatch.delenv("BGNN_SPLIT_F16"); monkeypatch.setenv("BGNN_SPLIT_BF16", "1")
+    bf16 = model.predict(g)["class_logits"].clone()
+    assert torch.isfinite(f16).all() and torch.equal(f16, bf16)
+    assert (f16 - exact).abs().max().item() < 1e-2 * max(1.0, exact.abs().max().item())
