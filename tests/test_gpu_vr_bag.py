@@ -159,3 +159,22 @@ def test_process_refinements_non_contiguous_layout(gpu_device):
         j = int(md2[r, c]["index"])
         assert np.array_equal(w2.refinements[0, j:j + n], w.refinements[0, i:i + n])
     assert w2._corrections_applied == w._corrections_applied
+
+
+def test_config4_scale_stream_device_equals_loop(gpu_device):
+    """BASELINE config 4 at a quarter of its size (~1 000 refinement grids 3x3..50x50, ~0.7 M cells): the whole-BAG device
+    path and the reference-shaped 50 000-node loop write identical records and report identical counters."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import VRBagHandler
+    from bathymetric_gnn_amd.scripts.inference_native import run_refinements
+    proc = _processor(8)
+    md, ref = synthetic.synthetic_vr_bag(35, 35, seed=4000)
+    h = VRBagHandler.from_arrays(md, ref)
+    assert h.num_refinement_cells > 900
+    w_loop, w_dev = h.copy_and_open_for_writing(), h.copy_and_open_for_writing()
+    st_loop = run_refinements(proc, h, w_loop, 0.01)
+    st_dev = proc.process_refinements(h, w_dev, 0.01)
+    assert np.array_equal(w_dev.refinements.view(np.uint32), w_loop.refinements.view(np.uint32))
+    for k in ("grids_processed", "cells_processed", "cells_classified_noise", "cells_corrected"):
+        assert st_dev[k] == st_loop[k], k
+    assert st_dev["cells_corrected"] > 0
