@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
         }
         if (a.relu) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            g[j].x = g[j].x > 0.f ? g[j].x : 0.f; g[j].y = g[j].y > 0.f ? g[j].y : 0.f;
-            g[j].z = g[j].z > 0.f ? g[j].z : 0.f; g[j].w = g[j].w > 0.f ? g[j].w : 0.f;
+          for (int j = 0; j < 4; ++j) {               // one v_max_f32 each (the C select / fmax forms add a canonicalising one)
+            asm("v_max_f32 %0, 0, %0" : "+v"(g[j].x)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].y));
+            asm("v_max_f32 %0, 0, %0" : "+v"(g[j].z)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].w));
           }
         }
       }
@@ -508,9 +508,10 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       // att_src / att_dst were staged into LDS (wbuf is free now): no global-load latency chain here.
       constexpr int TPH = C / 32, H2 = NT / TPH, H2L = NTL / TPH > 0 ? NTL / TPH : 1;
       static_assert(EPI != EPI_NEXT || NTL % TPH == 0, "a wave column share must hold whole heads");
-      float ps[H2L], pd[H2L];
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 ps[H2L], pd[H2L];                            // two-lane partial sums: the products go out as v_pk_fma_f32
 #pragma unroll
-      for (int hd = 0; hd < H2L; ++hd) { ps[hd] = 0.0f; pd[hd] = 0.0f; }
+      for (int hd = 0; hd < H2L; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
       const uint32_t asl = lds_addr(attl + nh * NTL * 32 + 4 * hl);
       // Row-per-lane stores (32 rows x 32 B per instruction) are store-issue bound; instead each 32x32 tile
       // is transposed through a wave-private LDS patch (the slab region is free now) and written out as whole
@@ -538,8 +539,9 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-          ps[t / TPH] += v.x * s4[g].x + v.y * s4[g].y + v.z * s4[g].z + v.w * s4[g].w;
-          pd[t / TPH] += v.x * d4[g].x + v.y * d4[g].y + v.z * d4[g].z + v.w * d4[g].w;
+          const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+          ps[t / TPH] += vlo * (f32x2){s4[g].x, s4[g].y}; ps[t / TPH] += vhi * (f32x2){s4[g].z, s4[g].w};
+          pd[t / TPH] += vlo * (f32x2){d4[g].x, d4[g].y}; pd[t / TPH] += vhi * (f32x2){d4[g].z, d4[g].w};
           *reinterpret_cast<float4 *>(patch + r * TILED_PITCH + 8 * g + 4 * hl) = v;
         }
         asm volatile("" : "+v"(ps[t / TPH]), "+v"(pd[t / TPH]));   // the dots are due HERE (not sunk below the stores)
@@ -552,8 +554,9 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       }
 #pragma unroll
       for (int hd = 0; hd < H2L; ++hd) {
-        const float s_ = ps[hd] + __shfl_xor(ps[hd], 32);
-        const float d_ = pd[hd] + __shfl_xor(pd[hd], 32);
+        const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
+        const float s_ = sl + __shfl_xor(sl, 32);
+        const float d_ = dl + __shfl_xor(dl, 32);
         if (id >= 0 && hl == 0) {
           a.asd_out[(int64_t)id * 2 * H2 + nh * H2L + hd] = s_;
           a.asd_out[(int64_t)id * 2 * H2 + H2 + nh * H2L + hd] = d_;

@@ -171,12 +171,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        float ps = 0.0f, pd = 0.0f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 ps2 = {0.f, 0.f}, pd2 = {0.f, 0.f};       // two-lane partial sums: v_pk_fma_f32
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          ps += v[g].x * s4[g].x + v[g].y * s4[g].y + v[g].z * s4[g].z + v[g].w * s4[g].w;
-          pd += v[g].x * d4[g].x + v[g].y * d4[g].y + v[g].z * d4[g].z + v[g].w * d4[g].w;
+          const f32x2 vlo = {v[g].x, v[g].y}, vhi = {v[g].z, v[g].w};
+          ps2 += vlo * (f32x2){s4[g].x, s4[g].y}; ps2 += vhi * (f32x2){s4[g].z, s4[g].w};
+          pd2 += vlo * (f32x2){d4[g].x, d4[g].y}; pd2 += vhi * (f32x2){d4[g].z, d4[g].w};
         }
+        float ps = ps2.x + ps2.y, pd = pd2.x + pd2.y;
         asm volatile("" : "+v"(ps), "+v"(pd));      // due here, not sunk below the stores
         pts[t] = ps; ptd[t] = pd;
       }
@@ -342,12 +345,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        float ps = 0.0f, pd = 0.0f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 ps2 = {0.f, 0.f}, pd2 = {0.f, 0.f};       // two-lane partial sums: v_pk_fma_f32
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          ps += v[g].x * s4[g].x + v[g].y * s4[g].y + v[g].z * s4[g].z + v[g].w * s4[g].w;
-          pd += v[g].x * d4[g].x + v[g].y * d4[g].y + v[g].z * d4[g].z + v[g].w * d4[g].w;
+          const f32x2 vlo = {v[g].x, v[g].y}, vhi = {v[g].z, v[g].w};
+          ps2 += vlo * (f32x2){s4[g].x, s4[g].y}; ps2 += vhi * (f32x2){s4[g].z, s4[g].w};
+          pd2 += vlo * (f32x2){d4[g].x, d4[g].y}; pd2 += vhi * (f32x2){d4[g].z, d4[g].w};
         }
+        float ps = ps2.x + ps2.y, pd = pd2.x + pd2.y;
         asm volatile("" : "+v"(ps), "+v"(pd));
         pts[t] = ps; ptd[t] = pd;
       }
