@@ -254,11 +254,13 @@ def main():
         roofs = {k: v for k, v in roofs.items() if v}
         # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach if present
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # (the counters were collected on the default workload only: 128 tiles of 256 x 256, 4 layers)
+        if os.path.exists(pmc) and args.workload == "tiles" and (B, S, args.layers) == (128, 256, 4):
             try:
                 t = json.load(open(pmc))
                 for v in roofs.values():
-                    v["traffic"] = t.get(v["kernel"], {}).get("hbm_bytes_per_launch")
+                    e = t.get(v["kernel"] + ":split") if split_main else None
+                    v["traffic"] = (e or t.get(v["kernel"], {})).get("hbm_bytes_per_launch")
             except Exception:
                 pass
         if "fused_mfma" in roofs:

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Turn the raw output of tools/collect_profiles.sh (gpurun_out/prof_final/) into the committed files under profiles/:
+
+  r<NN>_bench_*.json            the bench lines of the evidence run
+  r<NN>_{mode}_kernel_stats.csv rocprofv3 --kernel-trace --stats summaries (copied unchanged)
+  r<NN>_pmc_traffic_all.json    per kernel instance: FETCH_SIZE / WRITE_SIZE per launch
+  pmc_traffic.json              per kernel CLASS (what bench.py attaches as roofline.traffic)
+
+Counter handling is the one /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes, both are in KiB, and FETCH_SIZE is doubled on gfx950.  Only full-batch launches are averaged
+(the launches whose grid is the largest one seen for that kernel): the bench also runs single-tile forwards.
+
+usage: python tools/summarise_profiles.py [--round 1] [--src gpurun_out/prof_final]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("bgnn::", "")
+    return re.sub(r"\(.*\)$", "", name)
+
+
+def per_launch(counter_dir, counter):
+    """kernel -> [(grid, KiB)] from one --pmc pass (one row per dispatch and counter; rows of one dispatch are summed)"""
+    files = glob.glob(os.path.join(counter_dir, "**", "*counter_collection.csv"), recursive=True)
+    by_dispatch = defaultdict(float)
+    meta = {}
+    for f in files:
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                key = (f, r["Dispatch_Id"])
+                by_dispatch[key] += float(r["Counter_Value"])
+                meta[key] = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+    out = defaultdict(list)
+    for key, v in by_dispatch.items():
+        k, g = meta[key]
+        out[k].append((g, v))
+    return out
+
+
+def full_batch_mean(samples):
+    gmax = max(g for g, _ in samples)
+    vals = [v for g, v in samples if g == gmax]
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", type=int, default=1)
+    ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof_final"))
+    a = ap.parse_args()
+    tag = f"r{a.round:02d}"
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+
+    for src_name, dst_name in (("bench_fused", "bench_fused"), ("bench_unfused", "bench_unfused"), ("bench_split", "bench_split"),
+                               ("bench_split_f16", "bench_split_f16"), ("bench_vr_50k", "bench_vr_budget50k"),
+                               ("bench_vr_1M", "bench_vr_budget1M")):
+        p = os.path.join(a.src, src_name + ".json")
+        if os.path.exists(p):
+            line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
+            json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{dst_name}.json"), "w"), indent=1)
+
+    all_k, classes = {}, {}
+    for mode, label in (("fused", "fused, exact f32"), ("unfused", "unfused"), ("split", "fused, bf16x3")):
+        st = glob.glob(os.path.join(a.src, f"{mode}_stats", "**", "*kernel_stats.csv"), recursive=True)
+        if st:
+            shutil.copy(st[0], os.path.join(dst, f"{tag}_{mode}_kernel_stats.csv"))
+        fetch = per_launch(os.path.join(a.src, f"{mode}_fetch"), "FETCH_SIZE")
+        write = per_launch(os.path.join(a.src, f"{mode}_write"), "WRITE_SIZE")
+        cls_acc = defaultdict(lambda: [0.0, 0])
+        for k in sorted(set(fetch) & set(write)):
+            f_kib, n = full_batch_mean(fetch[k])
+            w_kib, _ = full_batch_mean(write[k])
+            fb, wb = f_kib * 1024.0, w_kib * 1024.0
+            all_k[f"{mode}:{k}"] = {"launches_sampled": n, "fetch_bytes_per_launch_raw": fb,
+                                    "fetch_bytes_per_launch_x2_corrected": 2.0 * fb, "write_bytes_per_launch": wb,
+                                    "hbm_bytes_per_launch": 2.0 * fb + wb}
+            cls = re.sub(r"<.*$", "", k)
+            if cls == "gemm_wres64_kernel":
+                cls = "gemm_f32_kernel"          # the W-resident form of the same kernel class (bench key "gemm")
+            cls_acc[cls][0] += (2.0 * fb + wb) * n
+            cls_acc[cls][1] += n
+        for cls, (tot, n) in cls_acc.items():
+            if cls in ("gat_layer_fused_kernel", "gat_aggregate_tiled_kernel", "gemm_f32_kernel", "features_kernel"):
+                key = cls if mode != "split" else cls + ":split"
+                if mode == "unfused" and cls != "gat_aggregate_tiled_kernel":
+                    continue
+                classes[key] = {"hbm_bytes_per_launch": tot / n, "launches_sampled": n, "path": label}
+    classes["_note"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
+                        "(tools/collect_profiles.sh: bench.py, 128 tiles of 256x256; full-batch launches only), KiB -> bytes, "
+                        "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; launch-weighted mean over the "
+                        f"instances of a kernel class; per instance and raw values: profiles/{tag}_pmc_traffic_all.json "
+                        "(written by tools/summarise_profiles.py)")
+    json.dump(all_k, open(os.path.join(dst, f"{tag}_pmc_traffic_all.json"), "w"), indent=1)
+    json.dump(classes, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    for k, v in classes.items():
+        if k != "_note":
+            print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e9:8.2f} GB/launch  ({v['launches_sampled']} launches, {v['path']})")
+
+
+if __name__ == "__main__":
+    main()
