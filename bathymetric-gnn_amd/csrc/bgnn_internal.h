@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <map>
+#include <atomic>
 
 #include "../../include/bgnn.h"
 

@@ -659,14 +659,14 @@ template <int HC, int C, int K, int NT, int EPI, int NS = 1, int SP = 0>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr int H = HC / C;
   constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI>::FLOATS * 4;
-  static bool configured = false;     // per instantiation
+  static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
   auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS, SP>;
   size_t lds_launch = lds_bytes;
   if (const char *e = getenv("BGNN_FUSED_LDS_PAD")) lds_launch = std::max(lds_bytes, (size_t)atoi(e) * 1024);   // occupancy experiment
-  if (!configured) {
+  if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)std::max(lds_launch, lds_bytes)));
-    configured = true;
+    configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(kern, dim3(a.tb.n_blocks), dim3(256 * NS), lds_launch, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());

@@ -390,11 +390,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 template <int NT, bool ATT, int SP = 0>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
   constexpr size_t lds_bytes = (size_t)(64 * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
-  static bool configured = false;
+  static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
   auto kern = gemm_wres64_kernel<NT, ATT, SP>;
-  if (!configured) {
+  if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    configured = true;
+    configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   static const int nw = getenv("BGNN_GEMM_WAVES") ? atoi(getenv("BGNN_GEMM_WAVES")) : 8;

@@ -4,11 +4,15 @@ CPU oracle (oracle/gat_cpu.py -- parity unpinned, see oracle/__init__.py).
 Tolerance (north_star): class logits within 1e-4 absolute, float32.  Probabilities / confidence /
 correction get the same absolute bar; predicted_class / action must agree wherever the oracle's
 top-2 probability gap (or distance to a threshold) exceeds 1e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import gat_cpu, graph_cpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -409,6 +413,47 @@ def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
     r_exact = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
     assert np.abs(r_split["confidence"] - r_exact["confidence"]).max() < 5e-5
     assert (r_split["classification"] == r_exact["classification"]).mean() > 0.999
+
+
+def test_matrix_paths_distance_to_float64(gpu_device, monkeypatch):
+    """How far each matrix path is from the TRUE result (the float64 forward of the oracle), on BASELINE config 2 and on
+    a fully valid tile: exact-f32 MFMA, fp16x3 and bf16x3 next to the float32 CPU forward.  The split paths must stay within the
+    same order of rounding noise as float32 arithmetic itself (bounds below); the numbers are written to
+    gpurun_out/split_accuracy.json when that directory exists (evidence for DESIGN.md section 3)."""
+    import json
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    sd = synthetic.synthetic_state_dict(seed=1234)
+    model = _model(sd)
+    report = {}
+    for name, (h, w, seed, variant) in {"config2_256x256_V1": (256, 256, 1, "V1"), "full_160x144_V0": (160, 144, 9, "V0")}.items():
+        d, m, _ = synthetic.synthetic_tile(h, w, seed, variant)
+        g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
+        og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+        ref64 = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr, dtype=torch.float64)
+        ref32 = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr)
+        row = {"nodes": int(og.x.shape[0]), "logit_abs_max": float(ref64["class_logits"].abs().max())}
+        def dist(lg):
+            e = (lg.double().cpu() - ref64["class_logits"]).abs()
+            return {"max": float(e.max()), "rms": float((e ** 2).mean().sqrt())}
+        row["cpu_float32"] = dist(ref32["class_logits"])
+        for key, env in (("exact_f32_mfma", None), ("fp16x3", "BGNN_SPLIT_F16"), ("bf16x3", "BGNN_SPLIT_BF16")):
+            monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
+            if env:
+                monkeypatch.setenv(env, "1")
+            out = model.predict(g)
+            row[key] = dist(out["class_logits"])
+            row[key]["class_agreement_with_float64"] = float(
+                (out["class_logits"].argmax(1).cpu() == ref64["class_logits"].argmax(1)).double().mean())
+        monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
+        report[name] = row
+        print(name, json.dumps(row))
+        assert row["exact_f32_mfma"]["max"] < TOL and row["fp16x3"]["max"] < TOL and row["bf16x3"]["max"] < TOL
+        assert row["fp16x3"]["max"] < 4 * max(row["exact_f32_mfma"]["max"], row["cpu_float32"]["max"])   # float32-grade
+        assert row["bf16x3"]["max"] < 5e-5
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):
+        json.dump(report, open(os.path.join(out_dir, "split_accuracy.json"), "w"), indent=1)
 
 
 @pytest.mark.parametrize("kind", ["GCN", "GraphSAGE", "GIN"])
