@@ -359,7 +359,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   for (int o = 0; o < hid; ++o) for (int i = 0; i < hid; ++i) pk[o_fe_W1t + (size_t)i * hid + o] = p[(size_t)o * hid + i];
   p += (size_t)hid * hid;
   std::copy(p, p + hid, pk.begin() + o_fe_b1); p += hid;
-  struct LOff { size_t Wt, as, ad, V, sc, sh, b1, Wt2, b2; };
+  struct LOff { size_t Wt, as, ad, V, sc, sh, b1, Wt2, b2, tr_bias, tr_bw, tr_bb, tr_Wt; };   // tr_*: unfolded, for bgnn_forward_train
   std::vector<LOff> lo(L);
   // BatchNorm (eval) as y = x * s + t
   auto bn_fold = [&](const float *bw, const float *bb, const float *rm, const float *rv, int c, double &sc, double &sh) {
@@ -375,6 +375,23 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     else if (d->gnn_type == BGNN_GNN_SAGE) { b0 = p; p += hid; W1 = p; p += (size_t)hid * hid; }
     else { b0 = p; p += hid; W1 = p; p += (size_t)hid * hid; b1 = p; p += hid; }
     const float *bw = p; p += hid; const float *bb = p; p += hid; const float *rm = p; p += hid; const float *rv = p; p += hid;
+    {   // the unfolded last map of the layer (training-mode forward: BatchNorm statistics come from the batch)
+      const float *rb = d->gnn_type == BGNN_GNN_GIN ? b1 : b0;
+      lo[l].tr_bias = reserve(hid); lo[l].tr_bw = reserve(hid); lo[l].tr_bb = reserve(hid);
+      std::copy(rb, rb + hid, pk.begin() + lo[l].tr_bias);
+      std::copy(bw, bw + hid, pk.begin() + lo[l].tr_bw); std::copy(bb, bb + hid, pk.begin() + lo[l].tr_bb);
+      lo[l].tr_Wt = 0;
+      if (d->gnn_type == BGNN_GNN_SAGE) {
+        lo[l].tr_Wt = reserve((size_t)2 * hid * hid);
+        for (int o = 0; o < hid; ++o) for (int i = 0; i < hid; ++i) {
+          pk[lo[l].tr_Wt + (size_t)i * hid + o] = W0[(size_t)o * hid + i];
+          pk[lo[l].tr_Wt + (size_t)(hid + i) * hid + o] = W1[(size_t)o * hid + i];
+        }
+      } else if (d->gnn_type == BGNN_GNN_GIN) {
+        lo[l].tr_Wt = reserve((size_t)hid * hid);
+        for (int o = 0; o < hid; ++o) for (int i = 0; i < hid; ++i) pk[lo[l].tr_Wt + (size_t)i * hid + o] = W1[(size_t)o * hid + i];
+      }
+    }
     if (d->gnn_type == BGNN_GNN_GCN) {
       lo[l].Wt = reserve((size_t)hid * hid); lo[l].sc = reserve(hid); lo[l].sh = reserve(hid);
       for (int o = 0; o < hid; ++o) {
@@ -433,7 +450,12 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
       pk[lo[l].sc + c] = (float)s;
       pk[lo[l].sh + c] = (float)(((double)bias[c] - (double)rm[c]) * s + (double)bb[c]);
     }
+    lo[l].tr_bias = reserve(W); lo[l].tr_bw = reserve(W); lo[l].tr_bb = reserve(W); lo[l].tr_Wt = 0;
+    std::copy(bias, bias + W, pk.begin() + lo[l].tr_bias);
+    std::copy(bw, bw + W, pk.begin() + lo[l].tr_bw); std::copy(bb, bb + W, pk.begin() + lo[l].tr_bb);
   }
+  const size_t o_ones = reserve(256);
+  std::fill(pk.begin() + o_ones, pk.begin() + o_ones + 256, 1.0f);
   // heads: first layers concatenated column-wise, second layers packed
   size_t o_hW0t = reserve((size_t)hid * HT), o_hb0 = reserve(HT);
   size_t o_hW1 = reserve((size_t)d->num_classes * hh + 2 * hh), o_hb1 = reserve(d->num_classes + 2);
@@ -512,7 +534,10 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     if (d->gnn_type == BGNN_GNN_GCN) { Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh; }
     if (d->gnn_type == BGNN_GNN_SAGE) Ly.b2 = m->blob + lo[l].b2;
     if (d->gnn_type == BGNN_GNN_GIN) { Ly.b1 = m->blob + lo[l].b1; Ly.Wt2 = m->blob + lo[l].Wt2; Ly.b2 = m->blob + lo[l].b2; }
+    Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
+    Ly.tr_Wt = lo[l].tr_Wt ? m->blob + lo[l].tr_Wt : nullptr;
   }
+  m->ones = m->blob + o_ones;
   for (int l = 0; l < L && gat; ++l) {
     const bool last = l == L - 1;
     BgnnLayer &Ly = m->layers[l];
@@ -522,6 +547,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
     Ly.Wsp16 = l > 0 && f16_ok ? m->blob + o_wsp16[l] : nullptr;
+    Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
   }
   m->head_hidden_total = HT;
   m->hd_W0sp = gat ? m->blob + o_hW0sp : nullptr;
@@ -725,8 +751,13 @@ struct GridOut {             // optional fused node -> grid outputs (bgnn_infer_
   bool done = false;         // set when the fused tail wrote the grids
 };
 
+// training-mode forward: BatchNorm statistics of this batch, written layer by layer ([sum of layer widths] each)
+struct TrainOut {
+  float *mean, *var_unbiased;
+};
+
 static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, float thr_review,
-                        const bgnn_outputs *o, GridOut *grids) {
+                        const bgnn_outputs *o, GridOut *grids, TrainOut *tr = nullptr) {
   const bgnn_model_desc &d = m->desc;
   BGNN_REQUIRE(g->F == d.in_channels, "mat1 and mat2 shapes cannot be multiplied (graph has %d node features, model expects %d)",
                g->F, d.in_channels);
@@ -744,7 +775,16 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   float *X = (float *)pa, *Y = (float *)pb, *hidb = (float *)phid;
   float *asdX = (float *)pasd, *asdY = asdX + rows * 2 * d.heads;
   const int64_t *dm = g->d_counts;
-  const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr;
+  const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr && !tr;   // the fused layers carry the folded eval statistics
+  void *bnws = nullptr;
+  if (tr) BGNN_TRY(ctx_workspace(ctx, 5, bn_train_workspace_bytes(maxw >= 256 ? 256 : maxw), &bnws));
+  size_t tr_off = 0;
+  auto batch_norm = [&](float *z, const BgnnLayer &L, int relu) {          // z [rows][L.width], in place
+    const int rc = launch_bn_train(ctx, z, L.width, L.width, rows, dm, L.bn_w, L.bn_b, d.bn_eps, relu, bnws,
+                                   tr->mean ? tr->mean + tr_off : nullptr, tr->var_unbiased ? tr->var_unbiased + tr_off : nullptr);
+    tr_off += (size_t)L.width;
+    return rc;
+  };
   // feature extractor (gnn.py:386): Linear(in,hid) ReLU [Dropout] Linear(hid,hid); then lin of layer 0
   if (!gat && g->kind != 0 && d.gnn_type != BGNN_GNN_GCN) {
     // foreign graphs: the CSR build dropped explicit self loops (GATConv and GCNConv replace them anyway); SAGEConv and
@@ -771,14 +811,29 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       const int relu = l + 1 < nl ? 1 : 0;
       if (d.gnn_type == BGNN_GNN_GCN) {               // lin, normalised aggregate, + bias, BatchNorm, ReLU
         BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt, nullptr, Y, hid, dm, rows, hid, hid, 0));
-        BGNN_TRY(launch_neighbor_reduce(ctx, g, 1, Y, hid, dinv, L.scale, L.shift, relu, X, hid, nullptr));
+        if (tr) {
+          BGNN_TRY(launch_neighbor_reduce(ctx, g, 1, Y, hid, dinv, m->ones, L.tr_bias, 0, X, hid, nullptr));
+          BGNN_TRY(batch_norm(X, L, relu));
+        } else {
+          BGNN_TRY(launch_neighbor_reduce(ctx, g, 1, Y, hid, dinv, L.scale, L.shift, relu, X, hid, nullptr));
+        }
       } else if (d.gnn_type == BGNN_GNN_SAGE) {       // [mean_j x_j | x_i] @ [lin_l ; lin_r]^T (BatchNorm folded) + bias, ReLU
         BGNN_TRY(launch_neighbor_reduce(ctx, g, 2, X, hid, nullptr, nullptr, nullptr, 0, Y, 2 * hid, Y + hid));
-        BGNN_TRY(launch_gemm_f32(ctx, Y, 2 * hid, L.Wt, L.b2, X, hid, dm, rows, 2 * hid, hid, relu));
+        if (tr) {
+          BGNN_TRY(launch_gemm_f32(ctx, Y, 2 * hid, L.tr_Wt, L.tr_bias, X, hid, dm, rows, 2 * hid, hid, 0));
+          BGNN_TRY(batch_norm(X, L, relu));
+        } else {
+          BGNN_TRY(launch_gemm_f32(ctx, Y, 2 * hid, L.Wt, L.b2, X, hid, dm, rows, 2 * hid, hid, relu));
+        }
       } else {                                        // GIN: nn(sum_j x_j + x_i), nn = Linear ReLU Linear; BatchNorm; ReLU
         BGNN_TRY(launch_neighbor_reduce(ctx, g, 3, X, hid, nullptr, nullptr, nullptr, 0, Y, hid, nullptr));
         BGNN_TRY(launch_gemm_f32(ctx, Y, hid, L.Wt, L.b1, X, hid, dm, rows, hid, hid, 1));
-        BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt2, L.b2, Y, hid, dm, rows, hid, hid, relu));
+        if (tr) {
+          BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.tr_Wt, L.tr_bias, Y, hid, dm, rows, hid, hid, 0));
+          BGNN_TRY(batch_norm(Y, L, relu));
+        } else {
+          BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt2, L.b2, Y, hid, dm, rows, hid, hid, relu));
+        }
         std::swap(X, Y);
       }
     }
@@ -801,16 +856,20 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   // GNN backbone (gnn.py:173-188).  Invariant at the top of each iteration: X = lin_l(h_l), asdX = its dots.
   const size_t nl = gat ? m->layers.size() : 0;
   for (size_t l = 0; l < nl; ++l) {
-    const BgnnLayer &L = m->layers[l];
+    const BgnnLayer &Leval = m->layers[l];
+    BgnnLayer Ltrain = Leval;                          // training mode: out = aggregate + bias, BatchNorm afterwards
+    Ltrain.scale = m->ones; Ltrain.shift = Leval.tr_bias;
+    const BgnnLayer &L = tr ? Ltrain : Leval;
     const int relu = L.concat ? 1 : 0;
     if (l + 1 < nl) {
       const BgnnLayer &Ln = m->layers[l + 1];
       int rc = use_fused ? launch_fused_layer_next(ctx, g, L, Ln, hid, d.edge_dim, X, asdX, Y, asdY) : BGNN_ERR_UNSUPPORTED;
       if (rc == BGNN_OK) { std::swap(X, Y); std::swap(asdX, asdY); continue; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
-      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
-      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
+      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
+      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
       BGNN_TRY(rc);
+      if (tr) BGNN_TRY(batch_norm(Y, L, relu));
       BGNN_TRY(launch_gemm_f32(ctx, Y, Ln.d_in, Ln.Wt, nullptr, X, Ln.heads * hid, dm, rows, Ln.d_in, Ln.heads * hid, 0,
                                Ln.att_src, Ln.att_dst, asdX, Ln.heads, hid));
     } else {
@@ -820,9 +879,10 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
                          : BGNN_ERR_UNSUPPORTED;
       if (rc == BGNN_OK) { if (grids) grids->done = true; return BGNN_OK; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
-      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
-      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, relu);
+      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
+      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
       BGNN_TRY(rc);
+      if (tr) BGNN_TRY(batch_norm(Y, L, relu));
     }
   }
   if (o->hidden) {
@@ -841,6 +901,21 @@ int bgnn_forward(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, fl
   BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward: model/graph belong to another context");
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
   return forward_impl(ctx, m, g, thr_auto, thr_review, o, nullptr);
+}
+
+int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float *bn_batch_mean, float *bn_batch_var,
+                       const bgnn_outputs *o) {
+  BGNN_REQUIRE(ctx && m && g && o, "bgnn_forward_train: NULL argument");
+  BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward_train: model/graph belong to another context");
+  BGNN_REQUIRE(!o->action && !o->needs_review && !o->auto_correct, "bgnn_forward_train: the deployment flags belong to predict()");
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  int64_t c[4];
+  BGNN_HIP_CHECK(hipMemcpyAsync(c, g->d_counts, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  // torch.nn.functional.batch_norm in training mode refuses a single row the same way
+  BGNN_REQUIRE(c[0] != 1, "Expected more than 1 value per channel when training, got input size [1, %d]", m->layers[0].width);
+  TrainOut tr{bn_batch_mean, bn_batch_var};
+  return forward_impl(ctx, m, g, 0.85f, 0.6f, o, nullptr, &tr);
 }
 
 int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, float thr_auto,

@@ -107,6 +107,10 @@ struct BgnnLayer {
   float *b1;        // GIN nn.0 bias [hid]
   float *Wt2;       // GIN nn.2^T [hid][hid] with BatchNorm folded in
   float *b2;        // SAGE / GIN: bias with BatchNorm folded in [hid]
+  // unfolded pieces for the training-mode forward (BatchNorm statistics taken from the batch, bn_train.hip)
+  float *tr_bias;   // the convolution's own bias [width] (GAT bias, GCN bias, SAGE lin_l bias, GIN nn.2 bias)
+  float *bn_w, *bn_b;   // BatchNorm weight / bias [width]
+  float *tr_Wt;     // SAGE [lin_l^T ; lin_r^T], GIN nn.2^T without the BatchNorm fold (else nullptr)
 };
 
 struct bgnn_model {
@@ -118,6 +122,7 @@ struct bgnn_model {
   float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
   float *l0f_Wsp = nullptr, *l0f_Wsp16 = nullptr;   // l0f_Wt as bf16 / float16 hi / lo split images
   std::vector<BgnnLayer> layers;
+  float *ones = nullptr;      // [256] of 1.0f: the identity scale of an unfolded epilogue
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
   float *hd_W0sp = nullptr, *hd_W0sp16 = nullptr;   // hd_W0t as bf16 / float16 hi / lo split images
@@ -208,6 +213,9 @@ static inline int bgnn_split_mode() { return getenv("BGNN_SPLIT_F16") ? 2 : gete
 int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv);
 int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const float *x, int D, const float *dinv,
                            const float *scale, const float *shift, int relu, float *out, int ldo, float *copy_self);
+size_t bn_train_workspace_bytes(int W);
+int launch_bn_train(bgnn_ctx *ctx, float *z, int ld, int W, int64_t max_rows, const int64_t *d_m, const float *bn_w,
+                    const float *bn_b, float eps, int relu, void *workspace, float *batch_mean, float *batch_var_unbiased);
 int launch_heads_final(bgnn_ctx *ctx, const bgnn_model *m, const float *hid, int ldh, const int64_t *d_m,
                        int64_t max_rows, float thr_auto, float thr_review, const bgnn_outputs *o);
 

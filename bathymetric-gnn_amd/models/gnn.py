@@ -5,7 +5,7 @@ The module tree and parameter names equal the reference's (and torch_geometric's
 ``model.feature_extractor.mlp[0].in_features`` (read at ``scripts/inference_native.py:147``) works.
 The torch parameters are only the weight container: ``forward`` packs them once into the library's
 blob (``bgnn_model_create``) and runs the hand-written HIP kernels (``bgnn_forward``).  Inference
-(eval) semantics only -- dropout is the identity and BatchNorm uses running statistics.
+(eval) semantics, plus the training-mode FORWARD with batch-statistics BatchNorm when every dropout probability is 0.
 """
 from __future__ import annotations
 
@@ -283,7 +283,8 @@ class BathymetricGNN(nn.Module):
         g._sizes = (x.shape[0], ei.shape[1], np.array([0, x.shape[0]]), np.array([0, ei.shape[1]]))
         return g, (x, ei, ea)
 
-    def _run(self, data, thr_auto: float, thr_review: float, with_flags: bool, want_hidden: bool = False):
+    def _run(self, data, thr_auto: float, thr_review: float, with_flags: bool, want_hidden: bool = False,
+             train: bool = False):
         ctx = rt.get_context(self._device_of(data))
         g, keep = self._graph_of(data, ctx)
         if g.num_features != self.in_channels:
@@ -314,7 +315,27 @@ class BathymetricGNN(nn.Module):
         if hidden is not None:
             o.hidden = hidden.data_ptr()
         model_h = self.native(ctx)
-        if N > 0:
+        if N > 0 and train:
+            if N == 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                                 f"torch.Size([1, {self.gnn.norms[0].module.num_features}])")
+            widths = [n.module.num_features for n in self.gnn.norms]
+            mean = torch.empty(sum(widths), dtype=torch.float32, device=dev)
+            var = torch.empty_like(mean)
+            ctx.begin()
+            rt.check(ctx.lib.bgnn_forward_train(ctx.handle, model_h, g._handle, rt.ptr(mean), rt.ptr(var), C.byref(o)))
+            ctx.end()
+            with torch.no_grad():                       # torch.nn.BatchNorm1d's bookkeeping (momentum None = cumulative average)
+                off = 0
+                for n, w in zip(self.gnn.norms, widths):
+                    bn = n.module
+                    if bn.track_running_stats and bn.running_mean is not None:
+                        bn.num_batches_tracked += 1
+                        f = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+                        bn.running_mean.mul_(1.0 - f).add_(mean[off:off + w].to(bn.running_mean.device), alpha=f)
+                        bn.running_var.mul_(1.0 - f).add_(var[off:off + w].to(bn.running_var.device), alpha=f)
+                    off += w
+        elif N > 0:
             ctx.begin()
             rt.check(ctx.lib.bgnn_forward(ctx.handle, model_h, g._handle, C.c_float(thr_auto), C.c_float(thr_review),
                                           C.byref(o)))
@@ -324,13 +345,26 @@ class BathymetricGNN(nn.Module):
             out["hidden"] = hidden
         return out
 
+    def _dropout_probabilities(self):
+        ps = [m.p for m in self.modules() if isinstance(m, nn.Dropout)]
+        ps += [c.dropout for c in self.gnn.convs if isinstance(c, GATConv)]      # attention dropout (gnn.py:125-132)
+        ps.append(self.gnn.dropout)                                              # F.dropout between the layers (:186)
+        return ps
+
     def forward(self, data) -> Dict[str, torch.Tensor]:
         """class_logits [N,C], class_probs [N,C], predicted_class [N] i64, confidence [N],
-        correction [N] (reference :360-408).  Always eval semantics."""
-        if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
-            logger.warning("BathymetricGNN.forward in training mode: the MI355X path implements inference "
-                           "(eval) semantics only; dropout / batch statistics are not applied")
-        return self._run(data, 0.85, 0.6, with_flags=False)
+        correction [N] (reference :360-408).
+
+        ``eval()``: running statistics, dropout the identity.  ``train()`` (forward only, there is no backward pass
+        here): every BatchNorm layer normalises with the statistics of this batch and moves its running statistics
+        (``bgnn_forward_train``); that needs every dropout probability to be 0 -- active dropout draws from torch's
+        generator and is refused rather than silently skipped."""
+        if not self.training:
+            return self._run(data, 0.85, 0.6, with_flags=False)
+        if any(p > 0 for p in self._dropout_probabilities()):
+            raise NotImplementedError("BathymetricGNN.forward in training mode with dropout > 0: the MI355X path has no "
+                                      "random dropout (construct the model with dropout=0.0, or call .eval())")
+        return self._run(data, 0.85, 0.6, with_flags=False, train=True)
 
     def predict(self, data, auto_correct_threshold: float = 0.85, review_threshold: float = 0.6):
         """forward + deployment flags (reference :410-451)."""

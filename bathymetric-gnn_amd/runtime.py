@@ -77,6 +77,7 @@ _SIGNATURES = {
     "bgnn_graph_export": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "bgnn_graph_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bgnn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(Outputs)]),
+    "bgnn_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Outputs)]),
     "bgnn_stitch_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
                           [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4),
     "bgnn_cut_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
@@ -114,8 +115,8 @@ def load_library(path: Optional[str] = None):
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.bgnn_abi_version() != 2:
-            raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != 2")
+        if lib.bgnn_abi_version() != 3:
+            raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != 3")
         _lib = lib
         return lib
 

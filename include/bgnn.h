@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BGNN_ABI_VERSION 2
+#define BGNN_ABI_VERSION 3
 
 #define BGNN_OK 0
 #define BGNN_ERR_INVALID (-1)     /* bad argument (-> ValueError in the Python mirror)   */
@@ -189,6 +189,20 @@ typedef struct bgnn_outputs { /* all DEVICE, any may be NULL */
 
 int bgnn_forward(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, float auto_correct_threshold,
                  float review_threshold, const bgnn_outputs *out);
+
+/* BathymetricGNN.forward with the module in train() mode and every dropout probability 0 (models/gnn.py:360-408 with
+ * :151-154, :179-186 in training mode): each BatchNorm layer normalises with the mean and the biased variance of THIS
+ * batch of nodes instead of its running statistics (torch.nn.BatchNorm1d, which torch_geometric's BatchNorm wraps).
+ * Forward only -- there is no backward pass in this library.  Dropout with p > 0 draws from torch's generator and is
+ * not reproduced: the host layer refuses that case.
+ *   bn_batch_mean, bn_batch_var  DEVICE f32 [sum over layers of the layer width], layer after layer; either may be
+ *       NULL.  bn_batch_var is the UNBIASED variance: what the caller blends into running_var
+ *       (running = (1 - momentum) * running + momentum * batch), as running_mean with bn_batch_mean.
+ *   out: as for bgnn_forward; action / needs_review / auto_correct must be NULL (they belong to predict()).
+ * A batch of exactly one node is refused like torch does ("Expected more than 1 value per channel when training").
+ * Synchronises the stream once (reads the node count). */
+int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, float *bn_batch_mean, float *bn_batch_var,
+                       const bgnn_outputs *out);
 
 /* BathymetricPipeline._process_tile (models/pipeline.py:243-314) and
  * NativeVRProcessor._extract_results_from_outputs (scripts/inference_native.py:181-204)

@@ -101,6 +101,17 @@ def batch_norm_eval(x, sd: Mapping, prefix: str, dtype, eps: float = 1e-5):
     return F.batch_norm(x, rm, rv, w, b, False, 0.1, eps)
 
 
+def batch_norm_train(x, sd: Mapping, prefix: str, dtype, stats: dict, eps: float = 1e-5, momentum: float = 0.1):
+    """torch.nn.BatchNorm1d in training mode (what torch_geometric's BatchNorm wraps; reference models/gnn.py:151-154
+    with the module in train()): normalise with the batch mean / biased variance; the updated running statistics
+    (momentum 0.1, unbiased variance) are returned in ``stats[prefix + 'running_mean' / 'running_var']``."""
+    w = _t(sd[prefix + "weight"], dtype); b = _t(sd[prefix + "bias"], dtype)
+    rm = _t(sd[prefix + "running_mean"], dtype).clone(); rv = _t(sd[prefix + "running_var"], dtype).clone()
+    out = F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
+    stats[prefix + "running_mean"], stats[prefix + "running_var"] = rm, rv
+    return out
+
+
 def _mlp2(x, sd, p0, p1, dtype):
     h = F.relu(F.linear(x, _t(sd[p0 + ".weight"], dtype), _t(sd[p0 + ".bias"], dtype)))
     return F.linear(h, _t(sd[p1 + ".weight"], dtype), _t(sd[p1 + ".bias"], dtype))
@@ -157,8 +168,9 @@ def gin_conv(x, edge_index, sd: Mapping, prefix: str, dtype):
     return _mlp2(s, sd, prefix + "nn.0", prefix + "nn.2", dtype)
 
 
-def backbone(x, edge_index, edge_attr, sd: Mapping, dtype):
-    """feature extractor + GNN backbone -> [N, hidden]"""
+def backbone(x, edge_index, edge_attr, sd: Mapping, dtype, train_stats: dict = None):
+    """feature extractor + GNN backbone -> [N, hidden].  ``train_stats`` (a dict): training-mode BatchNorm (dropout 0),
+    the updated running statistics are left in it."""
     L = num_layers_of(sd)
     kind = gnn_type_of(sd)
     h = _mlp2(x, sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", dtype)
@@ -172,18 +184,22 @@ def backbone(x, edge_index, edge_attr, sd: Mapping, dtype):
             h = sage_conv(h, edge_index, sd, f"gnn.convs.{l}.", dtype)
         else:
             h = gin_conv(h, edge_index, sd, f"gnn.convs.{l}.", dtype)
-        h = batch_norm_eval(h, sd, f"gnn.norms.{l}.module.", dtype)
+        if train_stats is None:
+            h = batch_norm_eval(h, sd, f"gnn.norms.{l}.module.", dtype)
+        else:
+            h = batch_norm_train(h, sd, f"gnn.norms.{l}.module.", dtype, train_stats)
         if not last:
             h = F.relu(h)
     return h
 
 
-def forward(sd: Mapping, x, edge_index, edge_attr, dtype=torch.float32) -> Dict[str, torch.Tensor]:
-    """BathymetricGNN.forward (models/gnn.py:360-408), eval mode."""
+def forward(sd: Mapping, x, edge_index, edge_attr, dtype=torch.float32, train_stats: dict = None) -> Dict[str, torch.Tensor]:
+    """BathymetricGNN.forward (models/gnn.py:360-408): eval mode, or -- with ``train_stats`` a dict -- training mode with
+    every dropout probability 0 (batch-statistics BatchNorm)."""
     x = _t(x, dtype); edge_attr = _t(edge_attr, dtype)
     edge_index = _t(edge_index, torch.int64)
     with torch.no_grad():
-        h = backbone(x, edge_index, edge_attr, sd, dtype)
+        h = backbone(x, edge_index, edge_attr, sd, dtype, train_stats)
         logits = _mlp2(h, sd, "classification_head.mlp.0", "classification_head.mlp.3", dtype)
         probs = F.softmax(logits, dim=-1)
         out = {

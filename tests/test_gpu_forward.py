@@ -507,3 +507,62 @@ def test_fp16_split_falls_back_when_a_weight_exceeds_float16(gpu_device, monkeyp
     bf16 = model.predict(g)["class_logits"].clone()
     assert torch.isfinite(f16).all() and torch.equal(f16, bf16)
     assert (f16 - exact).abs().max().item() < 1e-2 * max(1.0, exact.abs().max().item())
+
+
+@pytest.mark.parametrize("kind,layers", [("GAT", 4), ("GAT", 1), ("GCN", 2), ("GraphSAGE", 2), ("GIN", 2)])
+def test_training_mode_forward_batch_statistics(kind, layers, gpu_device):
+    """BathymetricGNN.forward with the module in train() and dropout 0 (reference models/gnn.py:151-154,
+    :179-186 in training mode): every BatchNorm layer uses the statistics of the batch and moves its running statistics.
+    Oracle: the same forward with torch's batch_norm(training=True) on the CPU.  Same 1e-4 bar on the logits."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    sd = synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=layers, seed=31)
+    m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=layers, edge_dim=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device)
+    gb = GraphBuilder()
+    tiles = [synthetic.synthetic_tile(37, 45, 3, "V1"), synthetic.synthetic_tile(20, 64, 4, "V0")]
+    g = gb.build_graphs([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 2)
+    ogs = [graph_cpu.build_graph(t[0], t[1], None, (0.5, 0.5)) for t in tiles]
+    n0 = ogs[0].x.shape[0]
+    x = np.concatenate([o.x for o in ogs]); ea = np.concatenate([o.edge_attr for o in ogs])
+    ei = np.concatenate([ogs[0].edge_index, ogs[1].edge_index + n0], axis=1)
+
+    m.eval()
+    out_eval = m(g)["class_logits"].clone()
+    m.train()
+    out = m(g)
+    stats = {}
+    ref = gat_cpu.forward(sd, x, ei, ea, train_stats=stats)
+    assert (out["class_logits"].cpu() - ref["class_logits"]).abs().max().item() < TOL
+    assert (out["confidence"].cpu() - ref["confidence"]).abs().max().item() < TOL
+    assert (out["correction"].cpu() - ref["correction"]).abs().max().item() < TOL
+    assert (out["class_logits"] - out_eval).abs().max().item() > 1e-3          # a different normalisation, visibly
+    for l, n in enumerate(m.gnn.norms):                                          # running statistics moved as torch moves them
+        pre = f"gnn.norms.{l}.module."
+        assert (n.module.running_mean.cpu() - stats[pre + "running_mean"]).abs().max().item() < 1e-5
+        assert (n.module.running_var.cpu() - stats[pre + "running_var"]).abs().max().item() < 1e-5
+        assert int(n.module.num_batches_tracked) == int(np.asarray(sd[pre + "num_batches_tracked"])) + 1
+    # a second step starts from the moved statistics; eval afterwards uses them (the packed model is rebuilt)
+    sd2 = dict(sd); sd2.update({k: v.numpy() for k, v in stats.items()})
+    m.eval()
+    ref_eval2 = gat_cpu.forward(sd2, x, ei, ea)
+    assert (m(g)["class_logits"].cpu() - ref_eval2["class_logits"]).abs().max().item() < TOL
+
+
+def test_training_mode_refusals(gpu_device):
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    sd = synthetic.synthetic_state_dict(in_channels=7, seed=2)
+    m = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).train()
+    d = np.full((3, 3), 1.0e6, np.float32); d[1, 1] = -20.0
+    g1 = GraphBuilder().build_graph(d, d != 1.0e6, None, (1.0, 1.0))             # one node
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m(g1)
+    g0 = GraphBuilder().build_graph(np.full((4, 4), 1.0e6, np.float32), np.zeros((4, 4), bool), None, (1.0, 1.0))
+    assert m(g0)["class_logits"].shape == (0, 3)                                 # an empty batch passes through
+    assert int(m.gnn.norms[0].module.num_batches_tracked) == int(np.asarray(sd["gnn.norms.0.module.num_batches_tracked"]))

@@ -103,3 +103,14 @@ def test_apply_results_arithmetic():
     assert applied.tolist() == [[True, False], [False, False]]      # >= threshold, noise, valid (:480-503)
     assert depth[0, 0] == np.float32(9.75) and unc[0, 0] == np.float32(0.5 * (2 - 0.85))
     assert depth[1, 1] == np.float32(1.0e6)
+
+
+def test_training_mode_with_dropout_is_refused_loudly():
+    """forward() in train() mode with an active dropout would need torch's random stream: refused, never silently eval."""
+    import pytest
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    m = BathymetricGNN(in_channels=7, edge_dim=3)            # reference default dropout 0.1, module starts in train()
+    assert m.training
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m(object())
+    assert all(p == 0 for p in BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)._dropout_probabilities())

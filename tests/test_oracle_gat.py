@@ -163,3 +163,24 @@ def test_other_backbones_forward_shapes_and_fp64_distance(kind):
     o64 = gat_cpu.forward(sd, g.x, g.edge_index, g.edge_attr, dtype=torch.float64)
     assert o32["class_logits"].shape == (g.x.shape[0], 3) and o32["hidden"].shape[1] == 64
     assert (o32["class_logits"].double() - o64["class_logits"]).abs().max() < 1e-5
+
+
+def test_training_mode_batch_norm_matches_the_formula():
+    """oracle.batch_norm_train = (x - mean) / sqrt(biased var + eps) * w + b, running statistics moved with momentum 0.1
+    and the unbiased variance (torch.nn.BatchNorm1d in training mode)."""
+    import numpy as np
+    import torch
+    from oracle import gat_cpu
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((50, 8)).astype(np.float32) * 3 + 1)
+    sd = {"p.weight": rng.uniform(0.5, 1.5, 8).astype(np.float32), "p.bias": rng.standard_normal(8).astype(np.float32),
+          "p.running_mean": rng.standard_normal(8).astype(np.float32), "p.running_var": rng.uniform(0.5, 1.5, 8).astype(np.float32)}
+    stats = {}
+    y = gat_cpu.batch_norm_train(x, sd, "p.", torch.float32, stats)
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    want = (xd - mean) / torch.sqrt(var + 1e-5) * torch.from_numpy(sd["p.weight"]).double() + torch.from_numpy(sd["p.bias"]).double()
+    assert (y.double() - want).abs().max().item() < 1e-5
+    assert (stats["p.running_mean"].double() - (0.9 * torch.from_numpy(sd["p.running_mean"]).double() + 0.1 * mean)).abs().max() < 1e-6
+    assert (stats["p.running_var"].double() - (0.9 * torch.from_numpy(sd["p.running_var"]).double() + 0.1 * xd.var(0, unbiased=True))).abs().max() < 1e-6
+    assert np.array_equal(sd["p.running_mean"], sd["p.running_mean"].copy())       # the state dict itself is not touched
