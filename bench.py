@@ -325,6 +325,20 @@ def main():
                              "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
                              "note": f"{env}=1: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
                                      "opt-in, not the headline"}
+        if world == 1 and args.workload == "tiles" and not args.unfused and B > 1:
+            # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
+            d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
+            hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)
+            out1 = torch.empty((3, S * S), dtype=torch.float32, device=dev)
+            for _ in range(5):
+                eng.infer_device(hw1, res1, d1, m1, None, out=out1)
+            torch.cuda.synchronize(dev); t3 = time.perf_counter()
+            n_one = 50
+            for _ in range(n_one):
+                eng.infer_device(hw1, res1, d1, m1, None, out=out1)
+            torch.cuda.synchronize(dev); t_one = (time.perf_counter() - t3) / n_one
+            line["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
+                                   "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
             line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
