@@ -841,11 +841,12 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   } else {
     const BgnnLayer &L0 = m->layers[0];
     if (getenv("BGNN_NO_FOLD") == nullptr) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
+      const int sm = tr ? 0 : bgnn_split_mode();   // training mode: exact float32 only (batch statistics amplify the split's error)
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
                                L0.att_src, L0.att_dst, asdX, L0.heads, hid,
-                               bgnn_split_mode() == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : bgnn_split_mode() ? m->l0f_Wsp : nullptr,
-                               bgnn_split_mode() == 2 && m->l0f_Wsp16 ? 2 : bgnn_split_mode() ? 1 : 0));
+                               sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr,
+                               sm == 2 && m->l0f_Wsp16 ? 2 : sm ? 1 : 0));
     } else {
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));

@@ -414,8 +414,10 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   static const int gemm_dbg = getenv("BGNN_GEMM_DBG") ? atoi(getenv("BGNN_GEMM_DBG")) : 0;
   GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg};
   static const bool no_wres = getenv("BGNN_NO_WRES") != nullptr;
-  if (!(K == 64 && !no_wres && max_rows >= 65536 && att_src)) Wt_split = nullptr;   // the split image is only read by the W-resident ATT form
-  if (K == 64 && !no_wres && max_rows >= 65536) {    // W-resident persistent form
+  // the split image is only read by the W-resident ATT form (NC 64 or 256); with a split path switched on that form runs
+  // at EVERY batch size, so that a node's result does not depend on how many other nodes share its batch
+  if (!(K == 64 && !no_wres && att_src && (NC == 64 || NC == 256))) Wt_split = nullptr;
+  if (K == 64 && !no_wres && (max_rows >= 65536 || Wt_split)) {    // W-resident persistent form
     switch (NC / 32) {
 #define BGNN_WRES_CASE(NT) case NT:                                                                                 \
         if (Wt_split) { a.Wt = Wt_split; return split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \

@@ -401,6 +401,8 @@ def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
     ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
     monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
+    if os.environ.get("BGNN_NO_FUSED"):
+        pytest.skip("the split matrix paths live in the fused layer kernels")
     exact = model.predict(g)
     monkeypatch.setenv(env, "1")
     split = model.predict(g)
@@ -413,6 +415,13 @@ def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
     r_exact = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
     assert np.abs(r_split["confidence"] - r_exact["confidence"]).max() < 5e-5
     assert (r_split["classification"] == r_exact["classification"]).mean() > 0.999
+    # batch independence holds on the split paths too: a node's logits do not depend on what else is in the batch
+    # (small and large batches must take the same matrix path)
+    monkeypatch.setenv(env, "1")
+    d2, m2, _ = synthetic.synthetic_tile(300, 280, 6, "V0")          # > 65 536 nodes: the large-batch GEMM form
+    g_big = gb.build_graphs([d, d2], [m, m2], None, [(0.5, 0.5)] * 2)
+    n = int(m.sum())
+    assert torch.equal(model.predict(g_big)["class_logits"][:n], split["class_logits"])
 
 
 def test_matrix_paths_distance_to_float64(gpu_device, monkeypatch):
