@@ -102,3 +102,42 @@ def test_fuzz_forward_and_ragged_batches(gpu_device):
     batch = gb.build_graphs([t[0] for t in tiles], [t[1] for t in tiles], None, [t[2] for t in tiles])
     lg = model.predict(batch)["class_logits"]
     assert torch.equal(lg, torch.cat(singles))                     # block-diagonal batching changes nothing, bit for bit
+
+
+def test_fuzz_survey_geometry_device_stitch_equals_host_merge(gpu_device):
+    """Random survey extents / tile sizes / overlaps / min_valid_ratio, including surveys smaller than one tile, zero
+    overlap, extents that trigger the shift-back rule of the last tile row / column, and large nodata regions: the
+    device path (cut -> infer -> bgnn_stitch_tiles) equals the host TileMerger on the same per-tile grids bit for bit."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.config import Config
+    from bathymetric_gnn_amd.data import BathymetricGrid
+    from bathymetric_gnn_amd.models import BathymetricGNN, BathymetricPipeline
+    rng = np.random.default_rng(4242)
+    sd = synthetic.synthetic_state_dict(in_channels=7, seed=1234)
+    model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model.to(gpu_device).eval()
+    cases = [(40, 300, 64, 16, 0.1), (64, 64, 64, 0, 0.0), (65, 129, 64, 32, 0.5), (33, 47, 64, 16, 0.0)]
+    for _ in range(8):
+        tile = int(rng.choice([32, 48, 64, 96]))
+        cases.append((int(rng.integers(20, 260)), int(rng.integers(20, 260)), tile,
+                      int(rng.choice([0, 8, tile // 4, tile // 2])), float(rng.choice([0.0, 0.1, 0.5, 0.9]))))
+    for H, W, tile, overlap, ratio in cases:
+        d, _, _ = synthetic.synthetic_tile(H, W, int(rng.integers(1 << 30)), "V0")
+        holes = rng.random((H, W)) < rng.choice([0.0, 0.05, 0.4])
+        d[holes] = 1.0e6
+        if rng.random() < 0.5:                                   # a block of nodata: whole tiles skipped
+            r0, c0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            d[r0:r0 + H // 2, c0:c0 + W // 2] = 1.0e6
+        cfg = Config()
+        cfg.tile.tile_size, cfg.tile.overlap, cfg.tile.min_valid_ratio = tile, overlap, ratio
+        grid = BathymetricGrid(depth=d, nodata_value=1.0e6, resolution=(0.5, 0.5))
+        pipe = BathymetricPipeline(cfg, tile_batch=int(rng.integers(1, 9)))
+        pipe.set_model(model)
+        res = pipe.process_grid(grid)
+        pipe.host_stitch = True
+        res_host = pipe.process_grid(grid)
+        for k in res_host:
+            ctx = f"{k}: survey {H}x{W}, tile {tile}, overlap {overlap}, min_valid_ratio {ratio}"
+            assert np.array_equal(np.isnan(res[k]), np.isnan(res_host[k])), ctx
+            assert np.array_equal(np.nan_to_num(res[k]).view(np.uint32), np.nan_to_num(res_host[k]).view(np.uint32)), ctx
