@@ -271,18 +271,26 @@ class BathymetricPipeline:
                                        self.config.inference.auto_correct_threshold,
                                        self.config.inference.review_threshold)
 
-    def load_model(self, model_path: Union[str, Path]):
+    def load_model(self, model_path: Union[str, Path], trust_pickle: bool = False):
         """Checkpoint -> model (reference :92-132).  Accepts the trainer's dict
         (``model_state_dict`` + ``in_channels`` / ``edge_dim`` / optional ``model_config`` or
         pickled ``config``) and a plain ``{state_dict, meta}`` form.  Loaded with
-        ``weights_only=True`` first; a checkpoint that pickles the reference's ``Config`` object needs
-        the reference's ``config`` package importable and is then loaded the reference's way."""
+        ``weights_only=True``.  A checkpoint that pickles the reference's ``Config`` object
+        (``training/trainer.py:809-829``) cannot be read that way: unpickling executes code from the file, so it
+        is an explicit opt-in (``trust_pickle=True``; the reference does it unconditionally, :105) and needs the
+        reference's ``config`` package importable."""
         model_path = Path(model_path)
         if not model_path.exists():
             raise FileNotFoundError(f"Model not found: {model_path}")
         try:
             ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
-        except Exception:
+        except Exception as e:
+            if not trust_pickle:
+                raise RuntimeError(
+                    f"{model_path} cannot be loaded with weights_only=True ({type(e).__name__}: it holds pickled Python "
+                    "objects, e.g. the trainer's Config). Unpickling executes code from the file: pass "
+                    "load_model(path, trust_pickle=True) only for a checkpoint you trust, or re-save it as "
+                    "{'model_state_dict', 'in_channels', 'edge_dim', 'model_config': dict}") from e
             ckpt = torch.load(model_path, map_location="cpu", weights_only=False)
         mc = ckpt.get("model_config", None)
         if mc is None and ckpt.get("config", None) is not None:

@@ -17,6 +17,8 @@ oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -95,6 +97,50 @@ def cpu_baseline(n_tiles, tile, sd, seed0):
                       f"+ scatter, {dt:.1f} s wall ({tg:.1f} s of it graph build); os.cpu_count()={os.cpu_count()}"}
 
 
+def launch_plan(gpus, env, n_devices):
+    """What `bench.py --gpus N` does with its process: ("worker", None) when a launcher (torch.distributed.run, or this
+    file's own spawn) already set WORLD_SIZE; ("single", None) for N = 1; ("spawn", None) when N > 1 ranks must be
+    started from here; ("error", reason) when that cannot work.  Pure function (unit-tested on CPU)."""
+    if gpus < 1:
+        return "error", f"--gpus {gpus}: need at least one GPU"
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            return "error", f"--gpus {gpus} but WORLD_SIZE={world}"
+        return ("worker" if world > 1 else "single"), None
+    if gpus == 1:
+        return "single", None
+    if n_devices < gpus:
+        return "error", f"--gpus {gpus} but only {n_devices} GPU(s) visible on this node"
+    return "spawn", None
+
+
+def spawn_ranks(n, argv, env=None, python=None):
+    """Start `n` child processes of `argv` (one per GPU: RANK = LOCAL_RANK = i, WORLD_SIZE = n, rendezvous on
+    127.0.0.1 at a free port), wait for all of them and return the worst exit status.  The parent never touches the
+    GPU, so nothing is exec'd or forked from a process that has initialised HIP."""
+    env = dict(os.environ if env is None else env)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for i in range(n):
+        e = dict(env, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([python or sys.executable] + list(argv), env=e))
+    rc = 0
+    for p in procs:
+        r = p.wait()
+        if r != 0 and rc == 0:
+            rc = r if r > 0 else 1
+    if rc != 0:                                            # one rank failed: do not leave the others waiting in a barrier
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,11 +172,16 @@ def main():
     if args.split_f16:
         os.environ["BGNN_SPLIT_F16"] = "1"
     split_main = "fp16x3" if "BGNN_SPLIT_F16" in os.environ else "bf16x3" if "BGNN_SPLIT_BF16" in os.environ else None
+    # N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (device_count() does not
+    # initialise HIP on this image), wait for them and leave with their status.
+    mode, why = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
+    if mode == "error":
+        raise SystemExit(f"bench.py: {why}")
+    if mode == "spawn":
+        raise SystemExit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -261,6 +312,9 @@ def main():
                 for v in roofs.values():
                     e = t.get(v["kernel"] + ":split") if split_main else None
                     v["traffic"] = (e or t.get(v["kernel"], {})).get("hbm_bytes_per_launch")
+                    if v["traffic"] is not None:
+                        v["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                               "command, collected separately (not measured by this run)")
             except Exception:
                 pass
         if "fused_mfma" in roofs:
@@ -276,7 +330,8 @@ def main():
                        "tiles_per_gpu": B if args.workload == "tiles" else args.vr_grids, "tile": S if args.workload == "tiles" else "3..50",
                        "nodes_per_step_per_gpu": nodes_per_step,
                        "parallelism": f"tile-sharded x{world}, no collective"},
-            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")},
+            "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                       "kernel", "avg_launch_ms")},
             "rooflines": roofs, "kernels": kernels, "path": "unfused" if args.unfused else "fused",
             "matrix_path": f"{split_main} split (opt-in)" if split_main else "exact f32",
         }

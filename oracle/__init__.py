@@ -14,7 +14,10 @@ Pinning status
   reference's own ``GraphBuilder`` in the build container
   (``tests/golden/make_golden.py``), plus the known answers in SURVEY.md
   Appendix A.
-* ``tiling_cpu`` (reference ``data/tiling.py``): PINNED the same way.
+* tiling (reference ``data/tiling.py``) has no module here: the product's host mirror
+  ``bathymetric_gnn_amd/data/tiling.py`` is itself checked bit-for-bit against
+  ``tests/golden/tiling_reference.npz``, generated from the reference's ``TileManager`` /
+  ``TileMerger`` (``tests/golden/make_golden_tiling.py``).
 * ``gat_cpu`` (model forward, reference ``models/gnn.py``): **parity unpinned**.
   The arithmetic of GATConv / BatchNorm lives in ``torch_geometric``
   (un-vendored, version unpinned in the reference: ``environment.yml:50-52``,
@@ -23,5 +26,11 @@ Pinning status
   (``scripts/test_pipeline.py:333-345`` prints shapes only).  ``gat_cpu``
   restates the published upstream semantics and is
   anchored on the reference's call sites (``models/gnn.py:125-132,176,181``)
-  and on a hand-computed known-answer case in ``tests/test_oracle_gat.py``.
+  and on a hand-computed known-answer case in ``tests/test_oracle_gat.py``.  What the
+  reference CAN pin of the model is pinned: ``LocalFeatureExtractor``, the three heads, the
+  ``forward`` wiring / softmax / argmax and the ``predict`` flag logic are plain torch in
+  ``models/gnn.py`` and were executed in the build container
+  (``tests/golden/make_golden_model.py`` -> ``tests/golden/model_*.npz``); ``gat_cpu``
+  reproduces those fixtures (``tests/test_oracle_model_golden.py``).  Only the GATConv
+  arithmetic itself (a12) stays unpinned.
 """

@@ -89,6 +89,17 @@ def test_checkpoint_loading_paths(tmp_path, monkeypatch):
     assert captured["m"].in_channels == 8 and captured["m"].num_gnn_layers == 3
     with pytest.raises(FileNotFoundError):
         p.load_model(tmp_path / "missing.pt")
+    # a checkpoint that pickles a Python object (the trainer's Config): refused unless unpickling is opted into
+    import argparse
+    pickled = tmp_path / "with_config_object.pt"
+    torch.save({"model_state_dict": sd, "in_channels": 8, "edge_dim": 3,
+                "config": argparse.Namespace(model=argparse.Namespace(gnn_num_layers=3))}, pickled)
+    captured.clear()
+    with pytest.raises(RuntimeError, match="trust_pickle=True"):
+        p.load_model(pickled)
+    assert "m" not in captured
+    p.load_model(pickled, trust_pickle=True)
+    assert captured["m"].num_gnn_layers == 3
 
 
 def test_apply_results_arithmetic():
