@@ -140,6 +140,12 @@ __global__ void copy_rows_kernel(const float *src, float *dst, int width, const 
   if (i < *d_m * width) dst[i] = src[i];
 }
 
+// x [n][in] -> x8 [n][8], zero padded (the node-feature layout of the graph build)
+__global__ void pad_rows8_kernel(const float *x, int in, float *x8, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 8) x8[i] = (i & 7) < in ? x[(i >> 3) * in + (i & 7)] : 0.0f;
+}
+
 }  // namespace bgnn
 
 using namespace bgnn;
@@ -902,6 +908,54 @@ int bgnn_forward(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, fl
   BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward: model/graph belong to another context");
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
   return forward_impl(ctx, m, g, thr_auto, thr_review, o, nullptr);
+}
+
+// ---- sub-modules of the model on their own (parity tests against reference-generated fixtures) ----------------
+static int row_count_on_device(bgnn_ctx *ctx, int64_t n, int64_t **d_n) {
+  void *p;
+  BGNN_TRY(ctx_workspace(ctx, 5, 64, &p));
+  BGNN_TRY(ctx_upload(ctx, &n, sizeof(n), p));
+  *d_n = (int64_t *)p;
+  return BGNN_OK;
+}
+
+int bgnn_feature_extractor(bgnn_ctx *ctx, bgnn_model *m, const float *x, int64_t n_nodes, float *out) {
+  BGNN_REQUIRE(ctx && m && out && (x || n_nodes == 0), "bgnn_feature_extractor: NULL argument");
+  BGNN_REQUIRE(m->ctx == ctx, "bgnn_feature_extractor: model belongs to another context");
+  BGNN_REQUIRE(n_nodes >= 0 && n_nodes < ((int64_t)1 << 30), "bgnn_feature_extractor: n_nodes=%lld out of range", (long long)n_nodes);
+  if (n_nodes == 0) return BGNN_OK;
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  const int hid = m->desc.hidden, in = m->desc.in_channels;
+  void *px8, *ph;
+  BGNN_TRY(ctx_workspace(ctx, 0, (size_t)n_nodes * 8 * sizeof(float), &px8));
+  BGNN_TRY(ctx_workspace(ctx, 1, (size_t)n_nodes * hid * sizeof(float), &ph));
+  int64_t *dn;
+  BGNN_TRY(row_count_on_device(ctx, n_nodes, &dn));
+  hipLaunchKernelGGL(pad_rows8_kernel, dim3((unsigned)((n_nodes * 8 + 255) / 256)), dim3(256), 0, ctx->stream, x, in,
+                     (float *)px8, n_nodes);
+  BGNN_HIP_CHECK(hipGetLastError());
+  BGNN_TRY(launch_gemm_f32(ctx, (const float *)px8, 8, m->fe_W0t, m->fe_b0, (float *)ph, hid, dn, n_nodes, 8, hid, 1));
+  BGNN_TRY(launch_gemm_f32(ctx, (const float *)ph, hid, m->fe_W1t, m->fe_b1, out, hid, dn, n_nodes, hid, hid, 0));
+  return BGNN_OK;
+}
+
+int bgnn_heads(bgnn_ctx *ctx, bgnn_model *m, const float *hidden, int64_t n_nodes, float thr_auto, float thr_review,
+               const bgnn_outputs *o) {
+  BGNN_REQUIRE(ctx && m && o && (hidden || n_nodes == 0), "bgnn_heads: NULL argument");
+  BGNN_REQUIRE(m->ctx == ctx, "bgnn_heads: model belongs to another context");
+  BGNN_REQUIRE(n_nodes >= 0 && n_nodes < ((int64_t)1 << 30), "bgnn_heads: n_nodes=%lld out of range", (long long)n_nodes);
+  BGNN_REQUIRE(!o->hidden, "bgnn_heads: `hidden` is this call's input");
+  if (n_nodes == 0) return BGNN_OK;
+  BGNN_HIP_CHECK(hipSetDevice(ctx->device));
+  const int hid = m->desc.hidden;
+  void *phid;
+  BGNN_TRY(ctx_workspace(ctx, 3, (size_t)n_nodes * m->head_hidden_total * sizeof(float), &phid));
+  int64_t *dn;
+  BGNN_TRY(row_count_on_device(ctx, n_nodes, &dn));
+  BGNN_TRY(launch_gemm_f32(ctx, hidden, hid, m->hd_W0t, m->hd_b0, (float *)phid, m->head_hidden_total, dn, n_nodes, hid,
+                           m->head_hidden_total, 1));
+  BGNN_TRY(launch_heads_final(ctx, m, (const float *)phid, m->head_hidden_total, dn, n_nodes, thr_auto, thr_review, o));
+  return BGNN_OK;
 }
 
 int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float *bn_batch_mean, float *bn_batch_var,

@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import logging
 import math
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -34,6 +35,11 @@ class LocalFeatureExtractor(nn.Module):
             seq += [nn.Linear(hidden_channels, hidden_channels), nn.ReLU(), nn.Dropout(dropout)]
         seq.append(nn.Linear(hidden_channels, out_channels))
         self.mlp = nn.Sequential(*seq)
+        self._owner = None           # weakref to the BathymetricGNN whose packed weights the kernels read
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[N, in] -> [N, out] on the HIP kernels (``bgnn_feature_extractor``): eval semantics (dropout = identity)."""
+        return _owner_of(self)._run_submodule("feature_extractor", x)
 
 
 def _glorot_(t: torch.Tensor):
@@ -137,7 +143,17 @@ class GNNBackbone(nn.Module):
             self.norms.append(BatchNorm(hidden_channels))
 
 
+def _owner_of(sub):
+    owner = sub._owner() if sub._owner is not None else None
+    if owner is None:
+        raise RuntimeError(f"{type(sub).__name__} runs through its BathymetricGNN's packed weights on the GPU; "
+                           "a detached sub-module has no compute path (there is no CPU fallback)")
+    return owner
+
+
 class _Head(nn.Module):
+    _which = None
+
     def __init__(self, in_channels, hidden_channels, out_features, dropout, sigmoid=False):
         super().__init__()
         seq = [nn.Linear(in_channels, hidden_channels), nn.ReLU(), nn.Dropout(dropout),
@@ -145,19 +161,30 @@ class _Head(nn.Module):
         if sigmoid:
             seq.append(nn.Sigmoid())
         self.mlp = nn.Sequential(*seq)
+        self._owner = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Backbone output [N, hidden] -> this head's output (reference :191-260) on the HIP kernels (``bgnn_heads``)."""
+        return _owner_of(self)._run_submodule(self._which, x)
 
 
 class ClassificationHead(_Head):
+    _which = "class_logits"
+
     def __init__(self, in_channels, hidden_channels, num_classes, dropout=0.1):
         super().__init__(in_channels, hidden_channels, num_classes, dropout)
 
 
 class ConfidenceHead(_Head):
+    _which = "confidence"
+
     def __init__(self, in_channels, hidden_channels, dropout=0.1):
         super().__init__(in_channels, hidden_channels, 1, dropout, sigmoid=True)
 
 
 class CorrectionHead(_Head):
+    _which = "correction"
+
     def __init__(self, in_channels, hidden_channels, dropout=0.1):
         super().__init__(in_channels, hidden_channels, 1, dropout)
 
@@ -186,6 +213,9 @@ class BathymetricGNN(nn.Module):
         self.correction_head = CorrectionHead(hidden_channels, hidden_channels // 2, dropout) if predict_correction else None
         self._native = None          # (ctx, handle)
         self._native_key = None
+        for sub in (self.feature_extractor, self.classification_head, self.confidence_head, self.correction_head):
+            if sub is not None:
+                object.__setattr__(sub, "_owner", weakref.ref(self))
         logger.info(f"Created BathymetricGNN: {gnn_type} with {num_gnn_layers} layers, {hidden_channels} hidden channels")
 
     # ---- weights -> library ------------------------------------------------------------------
@@ -343,6 +373,29 @@ class BathymetricGNN(nn.Module):
         out.update(extra)
         if hidden is not None:
             out["hidden"] = hidden
+        return out
+
+    def _run_submodule(self, which: str, x: torch.Tensor) -> torch.Tensor:
+        """``model.feature_extractor(x)`` / ``model.classification_head(h)`` / ``confidence_head(h)`` /
+        ``correction_head(h)`` (reference :386, :392-406) through the C ABI, eval semantics."""
+        p = next(self.parameters())
+        ctx = rt.get_context(x.device if x.device.type == "cuda" else (p.device if p.device.type == "cuda" else None))
+        x = x.detach().to(ctx.device, torch.float32).contiguous()
+        width = self.in_channels if which == "feature_extractor" else self.hidden_channels
+        if x.dim() != 2 or x.shape[1] != width:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} and {width}x...)")
+        N, model_h = x.shape[0], self.native(ctx)
+        ctx.begin()
+        if which == "feature_extractor":
+            out = torch.empty((N, self.hidden_channels), dtype=torch.float32, device=ctx.device)
+            rt.check(ctx.lib.bgnn_feature_extractor(ctx.handle, model_h, rt.ptr(x), N, rt.ptr(out)))
+        else:
+            shape = (N, self.num_classes) if which == "class_logits" else (N,)
+            out = torch.empty(shape, dtype=torch.float32, device=ctx.device)
+            o = rt.Outputs()
+            setattr(o, which, out.data_ptr())
+            rt.check(ctx.lib.bgnn_heads(ctx.handle, model_h, rt.ptr(x), N, C.c_float(0.85), C.c_float(0.6), C.byref(o)))
+        ctx.end()
         return out
 
     def _dropout_probabilities(self):

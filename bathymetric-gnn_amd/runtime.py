@@ -26,6 +26,7 @@ EDGE_FEATURE_IDS = {"distance": 0, "depth_difference": 1, "slope": 2}
 EF_ZERO = 3
 
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4
+ABI_VERSION = 4
 
 
 GNN_TYPES = {"GAT": 0, "GCN": 1, "GraphSAGE": 2, "GIN": 3}      # BGNN_GNN_*
@@ -77,6 +78,8 @@ _SIGNATURES = {
     "bgnn_graph_export": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "bgnn_graph_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bgnn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(Outputs)]),
+    "bgnn_feature_extractor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgnn_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.POINTER(Outputs)]),
     "bgnn_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Outputs)]),
     "bgnn_stitch_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
                           [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4),
@@ -115,8 +118,8 @@ def load_library(path: Optional[str] = None):
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.bgnn_abi_version() != 3:
-            raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != 3")
+        if lib.bgnn_abi_version() != ABI_VERSION:
+            raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != {ABI_VERSION}")
         _lib = lib
         return lib
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BGNN_ABI_VERSION 3
+#define BGNN_ABI_VERSION 4
 
 #define BGNN_OK 0
 #define BGNN_ERR_INVALID (-1)     /* bad argument (-> ValueError in the Python mirror)   */
@@ -189,6 +189,15 @@ typedef struct bgnn_outputs { /* all DEVICE, any may be NULL */
 
 int bgnn_forward(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, float auto_correct_threshold,
                  float review_threshold, const bgnn_outputs *out);
+
+/* The model's plain-torch sub-modules on their own, so that they can be held to vectors the reference itself produced
+ * (tests/golden/model_*.npz): LocalFeatureExtractor.forward (models/gnn.py:34-71; called at :386) on x [n_nodes][in_channels]
+ * -> out [n_nodes][hidden] (the unfolded two-Linear chain), and the three heads + softmax / argmax / sigmoid + predict's
+ * flags (models/gnn.py:191-260, :392-406, :427-449) on a backbone output hidden [n_nodes][hidden].  All DEVICE, row-major
+ * float32; `out->hidden` must be NULL for bgnn_heads.  Asynchronous. */
+int bgnn_feature_extractor(bgnn_ctx *ctx, bgnn_model *model, const float *x, int64_t n_nodes, float *out);
+int bgnn_heads(bgnn_ctx *ctx, bgnn_model *model, const float *hidden, int64_t n_nodes, float auto_correct_threshold,
+               float review_threshold, const bgnn_outputs *out);
 
 /* BathymetricGNN.forward with the module in train() mode and every dropout probability 0 (models/gnn.py:360-408 with
  * :151-154, :179-186 in training mode): each BatchNorm layer normalises with the mean and the biased variance of THIS

@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 def golden_names(full_only=False):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    names = [n for n in names if not n.startswith("tiling_")]
+    names = [n for n in names if not n.startswith(("tiling_", "model_"))]
     if full_only:
         names = [n for n in names if not n.startswith("C2_")]
     return names

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+from _calibration import assert_mixed, calibrate_heads
 from oracle import gat_cpu, graph_cpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +27,12 @@ def _model(sd, in_channels=7, num_layers=4, heads=4, hidden=64, predict_correcti
     return m.to(torch.device("cuda:0")).eval()
 
 
-def _compare(out, ref, check_flags=True):
+def _compare(out, ref, check_flags=True, require_mixed=None):
+    """require_mixed: the oracle's classes / actions must not be constant (None: whenever the graph has >= 400 nodes --
+    pass False where the model's heads were not calibrated on this graph)."""
+    if require_mixed or require_mixed is None:
+        mixed = assert_mixed(ref)
+        assert mixed or not require_mixed
     err = (out["class_logits"].cpu() - ref["class_logits"]).abs().max().item()
     assert err < TOL, f"logits differ by {err}"
     assert (out["class_probs"].cpu() - ref["class_probs"]).abs().max().item() < TOL
@@ -57,11 +63,12 @@ def test_predict_matches_oracle(shape, variant, layers, unc, seed, gpu_device):
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     d, m, u = synthetic.synthetic_tile(shape[0], shape[1], seed, variant if min(shape) >= 16 else "V0", unc)
-    sd = synthetic.synthetic_state_dict(in_channels=8 if unc else 7, num_layers=layers, seed=1234)
+    og = graph_cpu.build_graph(d, m, u, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=8 if unc else 7, num_layers=layers, seed=1234),
+                         og.x, og.edge_index, og.edge_attr)
     model = _model(sd, in_channels=8 if unc else 7, num_layers=layers)
     g = GraphBuilder().build_graph(d, m, u, (0.5, 0.5))
     out = model.predict(g)
-    og = graph_cpu.build_graph(d, m, u, (0.5, 0.5))
     ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
     _compare(out, ref)
 
@@ -71,13 +78,14 @@ def test_config2_256_tile_logits_and_fp64_distance(gpu_device):
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     d, m, _ = synthetic.synthetic_tile(256, 256, 1, "V1")
-    sd = synthetic.synthetic_state_dict(seed=1234)
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
     model = _model(sd)
     g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
     out = model.predict(g)
-    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
     ref32 = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
-    _compare(out, ref32)
+    _compare(out, ref32, require_mixed=True)
+    assert torch.unique(ref32["predicted_class"]).numel() == 3
     ref64 = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr, dtype=torch.float64)
     e_gpu = (out["class_logits"].cpu().double() - ref64["class_logits"]).abs().max().item()
     e_cpu = (ref32["class_logits"].double() - ref64["class_logits"]).abs().max().item()
@@ -108,7 +116,8 @@ def test_variants_heads_hidden_nocorr_legacy_keys(gpu_device):
                dict(predict_correction=False), dict(legacy=True)):
         legacy = kw.pop("legacy", False)
         heads, hidden, pc = kw.get("heads", 4), kw.get("hidden", 64), kw.get("predict_correction", True)
-        sd = synthetic.synthetic_state_dict(hidden=hidden, heads=heads, predict_correction=pc, seed=5, legacy_lin_src=legacy)
+        sd = calibrate_heads(synthetic.synthetic_state_dict(hidden=hidden, heads=heads, predict_correction=pc, seed=5, legacy_lin_src=legacy),
+                             og.x, og.edge_index, og.edge_attr)
         model = _model(sd, heads=heads, hidden=hidden, predict_correction=pc)
         out = model.predict(g)
         ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
@@ -256,11 +265,11 @@ def test_foreign_data_generic_graph(gpu_device):
     arbitrary edge order, variable in-degree (0 .. >16), explicit self loops (GATConv removes them)."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import Data
-    sd = synthetic.synthetic_state_dict(seed=1234)
-    model = _model(sd)
     # (a) a grid graph from the oracle, edges shuffled
     d, m, _ = synthetic.synthetic_tile(40, 33, 3, "V1")
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
+    model = _model(sd)
     perm = np.random.default_rng(1).permutation(og.num_edges)
     data = Data(x=torch.from_numpy(og.x), edge_index=torch.from_numpy(og.edge_index[:, perm]),
                 edge_attr=torch.from_numpy(og.edge_attr[perm]))
@@ -278,7 +287,7 @@ def test_foreign_data_generic_graph(gpu_device):
     out = model.predict(Data(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei).cuda(),
                              edge_attr=torch.from_numpy(ea).cuda()))
     ref = gat_cpu.predict(sd, x, ei, ea)
-    _compare(out, ref)
+    _compare(out, ref, require_mixed=False)
 
 
 def test_k16_dilated_extension(gpu_device):
@@ -290,7 +299,7 @@ def test_k16_dilated_extension(gpu_device):
     g = GraphBuilder(connectivity="16-dilated").build_graph(d, m, None, (0.5, 0.5))
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5), connectivity="16-dilated")
     assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
-    sd = synthetic.synthetic_state_dict(seed=1234)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
     _compare(_model(sd).predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
 
 
@@ -336,15 +345,16 @@ def test_four_connected_and_self_loops(conn, loops, gpu_device):
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
-    sd = synthetic.synthetic_state_dict(in_channels=7, seed=1234)
-    model = _model(sd)
     gb = GraphBuilder(connectivity=conn, include_self_loops=loops)
     tiles = [synthetic.synthetic_tile(h, w, 70 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (64, 64)])]
-    for d, m, _ in tiles[:2]:
+    og0 = graph_cpu.build_graph(tiles[0][0], tiles[0][1], None, (0.5, 1.0), connectivity=conn, include_self_loops=loops)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=7, seed=1234), og0.x, og0.edge_index, og0.edge_attr)
+    model = _model(sd)
+    for i, (d, m, _) in enumerate(tiles[:2]):
         g = gb.build_graph(d, m, None, (0.5, 1.0))
         og = graph_cpu.build_graph(d, m, None, (0.5, 1.0), connectivity=conn, include_self_loops=loops)
         assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
-        _compare(model.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
+        _compare(model.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr), require_mixed=(i == 0))
     # and through the fused per-batch entry (ragged batch)
     eng = TileBatchEngine(model, gb, gpu_device)
     res = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 1.0)] * 3)
@@ -364,18 +374,20 @@ def test_other_backbones_match_oracle(kind, loops, gpu_device):
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.models import BathymetricGNN
     from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
-    sd = synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=3, seed=77)
+    tiles = [synthetic.synthetic_tile(h, w, 90 + i, "V1") for i, (h, w) in enumerate([(40, 56), (33, 21), (64, 64)])]
+    og0 = graph_cpu.build_graph(tiles[0][0], tiles[0][1], None, (0.5, 0.5), include_self_loops=loops)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=3, seed=77),
+                         og0.x, og0.edge_index, og0.edge_attr)
     m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=3, dropout=0.0)
     m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     m.to(gpu_device).eval()
     gb = GraphBuilder(include_self_loops=loops)
-    tiles = [synthetic.synthetic_tile(h, w, 90 + i, "V1") for i, (h, w) in enumerate([(40, 56), (33, 21), (64, 64)])]
-    for d, mk, _ in tiles[:2]:
+    for i, (d, mk, _) in enumerate(tiles[:2]):
         g = gb.build_graph(d, mk, None, (0.5, 0.5))
         og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5), include_self_loops=loops)
         ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
         out = m.predict(g)
-        _compare(out, ref)
+        _compare(out, ref, require_mixed=(i == 0))
         assert (out["hidden"].cpu() - ref["hidden"]).abs().max().item() < TOL if "hidden" in out else True
     eng = TileBatchEngine(m, gb, gpu_device)
     res = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 3)
@@ -406,7 +418,7 @@ def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
     exact = model.predict(g)
     monkeypatch.setenv(env, "1")
     split = model.predict(g)
-    _compare(split, ref)
+    _compare(split, ref, require_mixed=False)        # (uncalibrated weights: this test compares matrix paths, not classes)
     diff = (split["class_logits"] - exact["class_logits"]).abs().max().item()
     assert 0 < diff < bound, diff                    # a different code path (not bit-equal), well inside the bar
     eng = TileBatchEngine(model, gb, gpu_device)
@@ -487,12 +499,12 @@ def test_other_backbones_on_foreign_graphs(kind, gpu_device):
     ea = rng.standard_normal((ei_noloop.shape[1], 3)).astype(np.float32)
     out = m.predict(Data(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei_noloop).cuda(),
                          edge_attr=torch.from_numpy(ea).cuda()))
-    _compare(out, gat_cpu.predict(sd, x, ei_noloop, ea))
+    _compare(out, gat_cpu.predict(sd, x, ei_noloop, ea), require_mixed=False)
     ei_loop = np.concatenate([ei_noloop, np.stack([np.arange(20, 30), np.arange(20, 30)])], axis=1)
     ea_loop = rng.standard_normal((ei_loop.shape[1], 3)).astype(np.float32)
     data = Data(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei_loop).cuda(), edge_attr=torch.from_numpy(ea_loop).cuda())
     if kind == "GCN":
-        _compare(m.predict(data), gat_cpu.predict(sd, x, ei_loop, ea_loop))
+        _compare(m.predict(data), gat_cpu.predict(sd, x, ei_loop, ea_loop), require_mixed=False)
     else:
         with pytest.raises(NotImplementedError):
             m.predict(data)
