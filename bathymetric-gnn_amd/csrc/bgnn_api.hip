@@ -190,7 +190,51 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     return BGNN_ERR_NOMEM;
   }
   c->stamps = reinterpret_cast<unsigned long long *>(c->zero_page + 1024);
+  {   // defaults from the environment, read once per context
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    BgnnOpts &o = c->opts;
+    o.matrix_path = getenv("BGNN_SPLIT_F16") ? 2 : getenv("BGNN_SPLIT_BF16") ? 1 : 0;
+    o.fused = getenv("BGNN_NO_FUSED") ? 0 : 1;
+    o.fold_extractor = getenv("BGNN_NO_FOLD") ? 0 : 1;
+    o.fused_column_split = getenv("BGNN_FUSED_SPLIT") ? 1 : 0;
+    o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
+    o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
+    o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
+    o.gemm_waves = env_int("BGNN_GEMM_WAVES", 8);
+    o.gemm_diag = env_int("BGNN_GEMM_DBG", 0);
+    o.gemm_no_wres = getenv("BGNN_NO_WRES") ? 1 : 0;
+  }
   *out = c;
+  return BGNN_OK;
+}
+
+static int *option_slot(bgnn_ctx *ctx, const char *name) {
+  BgnnOpts &o = ctx->opts;
+  struct { const char *n; int *p; } tab[] = {
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor},
+      {"fused_column_split", &o.fused_column_split}, {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
+      {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
+      {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
+  for (auto &t : tab) if (strcmp(t.n, name) == 0) return t.p;
+  return nullptr;
+}
+
+int bgnn_ctx_set_option(bgnn_ctx *ctx, const char *name, int value) {
+  BGNN_REQUIRE(ctx && name, "bgnn_ctx_set_option: NULL argument");
+  int *p = option_slot(ctx, name);
+  BGNN_REQUIRE(p, "bgnn_ctx_set_option: unknown option '%s'", name);
+  if (p == &ctx->opts.matrix_path) BGNN_REQUIRE(value >= 0 && value <= 2, "matrix_path=%d (0 exact f32, 1 bf16x3, 2 fp16x3)", value);
+  if ((p == &ctx->opts.diag_mask || p == &ctx->opts.diag_stamps || p == &ctx->opts.gemm_diag) && value != 0)
+    BGNN_REQUIRE(BGNN_DIAG, "option '%s' needs the diagnostic build of the library (python __graft_entry__.py --diag)", name);
+  *p = value;
+  return BGNN_OK;
+}
+
+int bgnn_ctx_get_option(bgnn_ctx *ctx, const char *name, int *value) {
+  BGNN_REQUIRE(ctx && name && value, "bgnn_ctx_get_option: NULL argument");
+  int *p = option_slot(ctx, name);
+  BGNN_REQUIRE(p, "bgnn_ctx_get_option: unknown option '%s'", name);
+  *value = *p;
   return BGNN_OK;
 }
 
@@ -781,7 +825,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   float *X = (float *)pa, *Y = (float *)pb, *hidb = (float *)phid;
   float *asdX = (float *)pasd, *asdY = asdX + rows * 2 * d.heads;
   const int64_t *dm = g->d_counts;
-  const bool use_fused = getenv("BGNN_NO_FUSED") == nullptr && !tr;   // the fused layers carry the folded eval statistics
+  const bool use_fused = ctx->opts.fused && !tr;   // the fused layers carry the folded eval statistics
   void *bnws = nullptr;
   if (tr) BGNN_TRY(ctx_workspace(ctx, 5, bn_train_workspace_bytes(maxw >= 256 ? 256 : maxw), &bnws));
   size_t tr_off = 0;
@@ -846,8 +890,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     std::swap(X, Y);                                  // the tail below expects the backbone output in Y
   } else {
     const BgnnLayer &L0 = m->layers[0];
-    if (getenv("BGNN_NO_FOLD") == nullptr) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
-      const int sm = tr ? 0 : bgnn_split_mode();   // training mode: exact float32 only (batch statistics amplify the split's error)
+    if (ctx->opts.fold_extractor) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
+      const int sm = tr ? 0 : ctx->opts.matrix_path;   // training mode: exact float32 only (batch statistics amplify the split's error)
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
                                L0.att_src, L0.att_dst, asdX, L0.heads, hid,
@@ -991,7 +1035,7 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
     o.predicted_class = (int64_t *)p;
     o.confidence = (float *)(o.predicted_class + rows);
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
-    const bool try_fused = getenv("BGNN_NO_FUSED") == nullptr && g->kind == 0 && (g->K == 4 || g->K == 8) &&
+    const bool try_fused = ctx->opts.fused && g->kind == 0 && (g->K == 4 || g->K == 8) &&
                            m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
     rc = forward_impl(ctx, m, g, thr_auto, thr_review, try_fused ? &none : &o, &go);
     if (rc == BGNN_OK && !go.done) {

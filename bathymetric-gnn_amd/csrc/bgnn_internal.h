@@ -69,8 +69,29 @@ struct BgnnWorkItem {
   int32_t tile, r0, nr, pad;
 };
 
+// Run-time switches of a context.  Defaults come from the environment ONCE, at bgnn_ctx_create (BGNN_SPLIT_F16 /
+// BGNN_SPLIT_BF16, BGNN_NO_FUSED, BGNN_NO_FOLD, ...); afterwards only bgnn_ctx_set_option changes them -- no getenv on
+// the launch path.
+struct BgnnOpts {
+  int matrix_path = 0;       // 0 exact f32, 1 bf16x3, 2 fp16x3 (opt-in operand-split matrix paths)
+  int fused = 1;             // 0: K3 / K4 / K5 / K6 as separate kernels
+  int fold_extractor = 1;    // 0: run the extractor's second Linear and lin of layer 0 unfolded
+  int fused_column_split = 0;  // experiment: 8-wave workgroups with the accumulator split by columns
+  int fused_lds_pad_kb = 0;    // experiment: pad the fused kernel's LDS request (occupancy)
+  int diag_mask = 0;         // BGNN_DIAG builds only: phase ablation bits of the fused kernel
+  int diag_stamps = 0;       // BGNN_DIAG builds only: per-phase s_memtime sums
+  int gemm_waves = 8, gemm_diag = 0, gemm_no_wres = 0;
+};
+
+// Diagnostics (phase ablations, cycle stamps) are compiled in only with -DBGNN_DIAG=1 (python __graft_entry__.py --diag
+// builds libbgnn_hip_diag.so); the production kernels carry none of it.
+#ifndef BGNN_DIAG
+#define BGNN_DIAG 0
+#endif
+
 struct bgnn_ctx {
   int device = 0;
+  BgnnOpts opts;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
   bgnn::DevPool pool;
@@ -208,8 +229,6 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
                              const float *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);
-// opt-in matrix path, read per call: 0 exact f32, 1 bf16x3 (BGNN_SPLIT_BF16), 2 fp16x3 (BGNN_SPLIT_F16)
-static inline int bgnn_split_mode() { return getenv("BGNN_SPLIT_F16") ? 2 : getenv("BGNN_SPLIT_BF16") ? 1 : 0; }
 int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv);
 int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const float *x, int D, const float *dinv,
                            const float *scale, const float *shift, int relu, float *out, int ldo, float *copy_self);

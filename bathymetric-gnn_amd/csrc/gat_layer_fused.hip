@@ -30,12 +30,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_NEXT = 0, EPI_HEADS = 1 };
 
+// Diagnostics exist only in the -DBGNN_DIAG=1 build (libbgnn_hip_diag.so): phase ablation bits (a.dbg) and per-phase
+// s_memtime sums (a.stamps).  In the production build DBG(bit) is the constant false and BGNN_STAMP expands to nothing,
+// so neither the tests inside the slab loop nor the live t_prev register pair exist.
+#if BGNN_DIAG
+#define DBG(bit) (a.dbg & (bit))
 #define BGNN_STAMP(slot)                                                                   \
   if (a.stamps && threadIdx.x == 0) {                                                      \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                            \
     atomicAdd(a.stamps + (slot), _t - t_prev);                                             \
     t_prev = _t;                                                                           \
   }
+#else
+#define DBG(bit) false
+#define BGNN_STAMP(slot)
+#endif
 
 struct FusedArgs {
   TileBlocks tb;
@@ -235,7 +244,9 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   int *minid = hid + HR;                               // [4]
   float *alx = reinterpret_cast<float *>(minid + 4);   // [128][APITCH]  alpha[cell][head][K+1]
 
+#if BGNN_DIAG
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+#endif
   const BlockPos pos = decode_block<FT_H>(a.tb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ng = wave & 3, nh = wave >> 2;
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   constexpr int NHL = (H + 2 * NS - 1) / (2 * NS);      // heads per lane
   constexpr int NPIECE = (HR * 8 + NTH - 1) / NTH;
   static_assert((NPIECE - 2) * NTH + NTH - 64 < HR * 8, "every wave moves NPIECE or NPIECE - 1 pieces");
-  const bool pre = a.ED == 3 && !(a.dbg & 32);
+  const bool pre = a.ED == 3 && !DBG(32);
   int my_pre = -1, hid_v = -1;
   {
     const int gr = pos.r0 + tid / HW_ - 1, gc = pos.c0 + tid % HW_ - 1;
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   // ---- phase A: attention coefficients -> LDS.  The 2*NS lanes that share a cell (lane halves x column halves)
   // take the heads round-robin.
   {
-    const int my = (a.dbg & 32) ? -1 : hid[self_idx];
+    const int my = DBG(32) ? -1 : hid[self_idx];
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
       const int hh = nh * 2 + hl + i * 2 * NS;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       f32x4 g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!(a.dbg & 1))
+      if (!DBG(1))
 #pragma unroll
       for (int b = 0; b <= K; ++b) {
         const int nidx = b == K ? sidx : sidx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
@@ -467,22 +478,22 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       wait_vm_lgkm<WH>();                               // WA(s) landed (WB(s) may still fly)
       __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
       BGNN_STAMP(5)   // wait for WA + barrier
-      if (s + 1 < NSLAB && !(a.dbg & 4)) issue_slab(s + 1);
+      if (s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
       // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
       using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
       using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
       LP8 xh0, xl0, xh1, xl1;
       if constexpr (SP != 0) { split_lp<LP8, LPE>(g[0], g[1], xh0, xl0); split_lp<LP8, LPE>(g[2], g[3], xh1, xl1); }
-      if (!(a.dbg & 2)) {
+      if (!DBG(2)) {
         if constexpr (SP != 0) SplitTiles<NTL, 0, LP8>::run(acc, xh0, xl0, wsp0);
         else MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
       }
       // WB(s) landed; the npc pieces of slab s+1 issued above stay in flight
-      if (s + 1 < NSLAB && !(a.dbg & 4)) { if (npc == NPIECE) wait_vm_lgkm<NPIECE>(); else wait_vm_lgkm<NPIECE - 1>(); }
+      if (s + 1 < NSLAB && !DBG(4)) { if (npc == NPIECE) wait_vm_lgkm<NPIECE>(); else wait_vm_lgkm<NPIECE - 1>(); }
       else wait_vm_lgkm<0>();
       __builtin_amdgcn_s_barrier();                     // every wave is done with W rows 0-15
-      if (s + 1 < NSLAB && !(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
-      if (!(a.dbg & 2)) {
+      if (s + 1 < NSLAB && !DBG(8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
+      if (!DBG(2)) {
         if constexpr (SP != 0) SplitTiles<NTL, 0, LP8>::run(acc, xh1, xl1, wsp0 + 16 * NC * 4);
         else MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
       }
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       if (s + 1 < NSLAB) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                   // every wave is done with W rows 16-31
-        if (!(a.dbg & 8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, (s + 1) * 32 + 16, wave, lane);
+        if (!DBG(8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, (s + 1) * 32 + 16, wave, lane);
         BGNN_STAMP(7)   // barrier + WB DMA issue
       }
     }
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   // NS == 1: the store patches below stay inside the slab region, which every wave left at the last slab's second
   // barrier -- a wave goes straight from its last MFMA into its own epilogue.  NS == 2: the patches reach into wbuf.
   if (EPI == EPI_NEXT && NS > 1) __syncthreads();
-  if (!(a.dbg & 64)) {
+  if (!DBG(64)) {
     const int mr = tr, mc = tc;
     const int id = hid[self_idx];
     if (EPI == EPI_NEXT) {
@@ -652,7 +663,9 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
     }
   }
   BGNN_STAMP(8)   // final epilogue
+#if BGNN_DIAG
   if (a.stamps && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
+#endif
 }
 
 template <int HC, int C, int K, int NT, int EPI, int NS = 1, int SP = 0>
@@ -661,8 +674,7 @@ static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI>::FLOATS * 4;
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
   auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS, SP>;
-  size_t lds_launch = lds_bytes;
-  if (const char *e = getenv("BGNN_FUSED_LDS_PAD")) lds_launch = std::max(lds_bytes, (size_t)atoi(e) * 1024);   // occupancy experiment
+  const size_t lds_launch = std::max(lds_bytes, (size_t)ctx->opts.fused_lds_pad_kb * 1024);   // (pad: occupancy experiment)
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)std::max(lds_launch, lds_bytes)));
@@ -683,8 +695,8 @@ static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, i
   a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
   a.node_id = g->d_node_id; a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
   a.ED = ED; a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
-  { const char *e = getenv("BGNN_FUSED_DBG"); a.dbg = e ? atoi(e) : 0; }
-  a.stamps = getenv("BGNN_FUSED_STAMPS") ? g->ctx->stamps : nullptr;
+  a.dbg = BGNN_DIAG ? g->ctx->opts.diag_mask : 0;
+  a.stamps = BGNN_DIAG && g->ctx->opts.diag_stamps ? g->ctx->stamps : nullptr;
 }
 
 // aggregate of layer L (width HC = L.heads*C) fused with the GEMM of the next layer `Ln`
@@ -695,7 +707,7 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   if (Ln.d_in != HC) return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  int split = bgnn_split_mode();                                       // opt-in bf16x3 / fp16x3 matrix path (read per call)
+  int split = ctx->opts.matrix_path;                                   // opt-in bf16x3 / fp16x3 matrix path
   if (split == 2 && !Ln.Wsp16) split = 1;                              // a weight beyond float16's range: bf16 split instead
   a.Wt = split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next;
   a.asd_out = asd_next;
@@ -717,7 +729,7 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
     return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, ns>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, ns>(ctx, a);
   // Column split (16 waves per CU at 128 registers): correct, but hipcc spills inside the gather loop at that
   // budget and every spill reload waits on the in-flight DMAs -- 1.5x slower than NS = 1 today.  Opt-in only.
-  static const int ns_big = getenv("BGNN_FUSED_SPLIT") ? 2 : 1;
+  const int ns_big = ctx->opts.fused_column_split ? 2 : 1;
   if (ns_big == 2) { BGNN_FUSED_CASE(256, 8, 2) }
   BGNN_FUSED_CASE(256, 8, 1) BGNN_FUSED_CASE(256, 2, 1) BGNN_FUSED_CASE(128, 4, 1) BGNN_FUSED_CASE(128, 2, 1) BGNN_FUSED_CASE(64, 2, 1)
 #undef BGNN_FUSED_CASE
@@ -733,7 +745,7 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
   fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  int split = bgnn_split_mode();
+  int split = ctx->opts.matrix_path;
   if (split == 2 && !m->hd_W0sp16) split = 1;
   a.Wt = split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
   a.local_std = g->d_local_std;

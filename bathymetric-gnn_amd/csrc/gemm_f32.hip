@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     if constexpr (SP != 0) {
       using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
       using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
-      if (!(a.dbg & 2)) {
+      if (!(BGNN_DIAG && (a.dbg & 2))) {
 #pragma unroll
         for (int st = 0; st < K / 16; ++st) {
           const float v[8] = {ax[2 * st].x, ax[2 * st].y, ax[2 * st].z, ax[2 * st].w,
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
           }
         }
       }
-    } else if (!(a.dbg & 2))
+    } else if (!(BGNN_DIAG && (a.dbg & 2)))
 #pragma unroll
     for (int s = 0; s < K / 8; ++s) {
       const float av[4] = {ax[s].x, ax[s].y, ax[s].z, ax[s].w};
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 32], av[i], acc[t], 0, 0, 0);
       }
     }
-    if (row0 + stride < M && !(a.dbg & 4)) load_x(row0 + stride);    // next block's X flies under this block's epilogue
+    if (row0 + stride < M && !(BGNN_DIAG && (a.dbg & 4))) load_x(row0 + stride);    // next block's X flies under this block's epilogue
     // stores leave as 256-byte row segments (two tiles side by side in the patch): 16 lanes x 16 B per row, 4 rows per
     // instruction -- half as many separate DRAM bursts per 1-KiB output row as 128-byte segments
     static_assert(NT % 2 == 0, "tiles are stored in pairs");
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(patch + r * PP + (t & 1) * 32 + 8 * g + 4 * h) = v[g];
       __builtin_amdgcn_sched_barrier(0);
-      if ((t & 1) && !(a.dbg & 1)) {
+      if ((t & 1) && !(BGNN_DIAG && (a.dbg & 1))) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           *reinterpret_cast<float4 *>(dst[k] + (t - 1) * 32) =
@@ -397,7 +397,7 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
     configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  static const int nw = getenv("BGNN_GEMM_WAVES") ? atoi(getenv("BGNN_GEMM_WAVES")) : 8;
+  const int nw = ctx->opts.gemm_waves;
   hipLaunchKernelGGL(kern, dim3(ctx->num_cus * per_cu), dim3(64 * nw), lds_bytes, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;
@@ -411,9 +411,9 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
-  static const int gemm_dbg = getenv("BGNN_GEMM_DBG") ? atoi(getenv("BGNN_GEMM_DBG")) : 0;
+  const int gemm_dbg = BGNN_DIAG ? ctx->opts.gemm_diag : 0;
   GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg};
-  static const bool no_wres = getenv("BGNN_NO_WRES") != nullptr;
+  const bool no_wres = ctx->opts.gemm_no_wres != 0;
   // the split image is only read by the W-resident ATT form (NC 64 or 256); with a split path switched on that form runs
   // at EVERY batch size, so that a node's result does not depend on how many other nodes share its batch
   if (!(K == 64 && !no_wres && att_src && (NC == 64 || NC == 256))) Wt_split = nullptr;

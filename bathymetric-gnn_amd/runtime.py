@@ -27,6 +27,7 @@ EF_ZERO = 3
 
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4
 ABI_VERSION = 4
+MATRIX_PATHS = {"exact_f32": 0, "bf16x3": 1, "fp16x3": 2}
 
 
 GNN_TYPES = {"GAT": 0, "GCN": 1, "GraphSAGE": 2, "GIN": 3}      # BGNN_GNN_*
@@ -63,6 +64,8 @@ _SIGNATURES = {
     "bgnn_ctx_destroy": (C.c_int, [C.c_void_p]),
     "bgnn_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "bgnn_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "bgnn_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "bgnn_ctx_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "bgnn_ctx_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bgnn_ctx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bgnn_model_weight_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
@@ -166,6 +169,35 @@ class Context:
 
     def synchronize(self):
         check(self.lib.bgnn_ctx_synchronize(self.handle))
+
+    # -- run-time switches (include/bgnn.h: bgnn_ctx_set_option).  The environment is read once, when the
+    #    context is created; afterwards only these calls change a switch.
+    def set_option(self, name: str, value):
+        if name == "matrix_path" and isinstance(value, str):
+            value = MATRIX_PATHS[value]
+        check(self.lib.bgnn_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        check(self.lib.bgnn_ctx_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """``with ctx.options(matrix_path="bf16x3"): ...`` -- set, run, restore."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_, *exc):
+                for k, v in self_.old.items():
+                    ctx.set_option(k, v)
+                return False
+        return _Scope()
 
     def profile(self, kernels):
         mask = 0

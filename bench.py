@@ -165,13 +165,6 @@ def main():
     ap.add_argument("--vr-budget", type=int, default=50000)
     args = ap.parse_args()
 
-    if args.unfused:
-        os.environ["BGNN_NO_FUSED"] = "1"
-    if args.split_bf16:
-        os.environ["BGNN_SPLIT_BF16"] = "1"
-    if args.split_f16:
-        os.environ["BGNN_SPLIT_F16"] = "1"
-    split_main = "fp16x3" if "BGNN_SPLIT_F16" in os.environ else "bf16x3" if "BGNN_SPLIT_BF16" in os.environ else None
     # N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (device_count() does not
     # initialise HIP on this image), wait for them and leave with their status.
     mode, why = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
@@ -203,6 +196,13 @@ def main():
     gb = GraphBuilder(device=dev)
     eng = TileBatchEngine(model, gb, dev)
     ctx = eng.ctx
+    # run-time switches of the library context (the environment is only read when a context is created)
+    if args.unfused:
+        ctx.set_option("fused", 0)
+    if args.split_f16 or args.split_bf16:
+        ctx.set_option("matrix_path", "fp16x3" if args.split_f16 else "bf16x3")
+    split_main = {0: None, 1: "bf16x3", 2: "fp16x3"}[ctx.get_option("matrix_path")]
+    unfused = not ctx.get_option("fused")
     nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
 
     if args.workload == "tiles":
@@ -332,10 +332,10 @@ def main():
                        "parallelism": f"tile-sharded x{world}, no collective"},
             "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                        "kernel", "avg_launch_ms")},
-            "rooflines": roofs, "kernels": kernels, "path": "unfused" if args.unfused else "fused",
+            "rooflines": roofs, "kernels": kernels, "path": "unfused" if unfused else "fused",
             "matrix_path": f"{split_main} split (opt-in)" if split_main else "exact f32",
         }
-        if world == 1 and args.workload == "tiles" and not args.unfused:
+        if world == 1 and args.workload == "tiles" and not unfused:
             # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
             # D2H on three streams, two slots in flight.  Reported beside `value`, never as it.
             from bathymetric_gnn_amd.models.pipeline import HostTilePipeline
@@ -355,16 +355,16 @@ def main():
                                       "steps": n_pc, "bytes_per_cell": {"h2d": 5, "d2h": 12},
                                       "note": "host numpy tiles in, host grids out: pinned double-buffered staging, H2D / "
                                               "compute / D2H overlapped on three streams (HostTilePipeline)"}
-        if world == 1 and args.workload == "tiles" and not args.unfused and not split_main:
+        if world == 1 and args.workload == "tiles" and not unfused and not split_main:
             # Opt-in matrix path, reported BESIDE the headline (never as it): bf16 hi/lo operand split (bf16x3) on the bf16
             # matrix cores with float32 accumulation.  Same inputs, same timing protocol; the distance of its class logits
             # to the exact-f32 path is measured on one tile of the batch.
             from bathymetric_gnn_amd.data import GraphBuilder as _GB
             g1 = _GB(device=dev).build_graph(depth[0], mask[0], None, (0.5, 0.5))
             lg_exact = model.predict(g1)["class_logits"].clone()
-            for key, env, instr in (("split_bf16x3", "BGNN_SPLIT_BF16", "v_mfma_f32_32x32x16_bf16"),
-                                    ("split_fp16x3", "BGNN_SPLIT_F16", "v_mfma_f32_32x32x16_f16")):
-                os.environ[env] = "1"
+            for key, env, instr in (("split_bf16x3", "bf16x3", "v_mfma_f32_32x32x16_bf16"),
+                                    ("split_fp16x3", "fp16x3", "v_mfma_f32_32x32x16_f16")):
+                ctx.set_option("matrix_path", env)
                 try:
                     lg_split = model.predict(g1)["class_logits"]
                     for _ in range(2):
@@ -375,12 +375,12 @@ def main():
                         step()
                     torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
                 finally:
-                    del os.environ[env]
+                    ctx.set_option("matrix_path", "exact_f32")
                 line[key] = {"value": nodes_per_step * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
                              "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
-                             "note": f"{env}=1: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
+                             "note": f"matrix_path={env}: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
                                      "opt-in, not the headline"}
-        if world == 1 and args.workload == "tiles" and not args.unfused and B > 1:
+        if world == 1 and args.workload == "tiles" and not unfused and B > 1:
             # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
             d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
             hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)

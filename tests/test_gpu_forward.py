@@ -19,6 +19,20 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def _set_matrix_path(name):
+    """'exact_f32' | 'bf16x3' | 'fp16x3' on the cuda:0 context (bgnn_ctx_set_option; the environment is only read when a
+    context is created)."""
+    from bathymetric_gnn_amd import runtime as rt
+    rt.get_context(torch.device("cuda:0")).set_option("matrix_path", name)
+
+
+@pytest.fixture(autouse=True)
+def _restore_matrix_path():
+    yield
+    if torch.cuda.is_available():
+        _set_matrix_path("exact_f32")
+
+
 def _model(sd, in_channels=7, num_layers=4, heads=4, hidden=64, predict_correction=True):
     from bathymetric_gnn_amd.models import BathymetricGNN
     m = BathymetricGNN(in_channels=in_channels, hidden_channels=hidden, num_gnn_layers=num_layers, heads=heads,
@@ -398,9 +412,10 @@ def test_other_backbones_match_oracle(kind, loops, gpu_device):
         assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4
 
 
-@pytest.mark.parametrize("env,bound", [("BGNN_SPLIT_BF16", 5e-5), ("BGNN_SPLIT_F16", 5e-6)])
-def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
-    """Opt-in BGNN_SPLIT_BF16=1 / BGNN_SPLIT_F16=1: the layer matrix products run as bf16 / float16 hi/lo operand splits
+@pytest.mark.parametrize("path,bound", [("bf16x3", 5e-5), ("fp16x3", 5e-6)])
+def test_split_matrix_paths(path, bound, gpu_device):
+    """Opt-in matrix_path = bf16x3 / fp16x3 (context option; BGNN_SPLIT_BF16=1 / BGNN_SPLIT_F16=1 set the default of a new
+    context): the layer matrix products run as bf16 / float16 hi/lo operand splits
     with float32 accumulation.  Same 1e-4 bar against the float32 oracle; the distance to the exact-f32 path is reported and bounded."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
@@ -412,31 +427,32 @@ def test_split_matrix_paths(env, bound, gpu_device, monkeypatch):
     g = gb.build_graph(d, m, None, (0.5, 0.5))
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
     ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
-    monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
-    if os.environ.get("BGNN_NO_FUSED"):
+    from bathymetric_gnn_amd import runtime as rt
+    _set_matrix_path("exact_f32")
+    if not rt.get_context(gpu_device).get_option("fused"):
         pytest.skip("the split matrix paths live in the fused layer kernels")
     exact = model.predict(g)
-    monkeypatch.setenv(env, "1")
+    _set_matrix_path(path)
     split = model.predict(g)
     _compare(split, ref, require_mixed=False)        # (uncalibrated weights: this test compares matrix paths, not classes)
     diff = (split["class_logits"] - exact["class_logits"]).abs().max().item()
     assert 0 < diff < bound, diff                    # a different code path (not bit-equal), well inside the bar
     eng = TileBatchEngine(model, gb, gpu_device)
     r_split = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
-    monkeypatch.delenv(env)
+    _set_matrix_path("exact_f32")
     r_exact = eng.infer([d], [m], None, [(0.5, 0.5)])[0]
     assert np.abs(r_split["confidence"] - r_exact["confidence"]).max() < 5e-5
     assert (r_split["classification"] == r_exact["classification"]).mean() > 0.999
     # batch independence holds on the split paths too: a node's logits do not depend on what else is in the batch
     # (small and large batches must take the same matrix path)
-    monkeypatch.setenv(env, "1")
+    _set_matrix_path(path)
     d2, m2, _ = synthetic.synthetic_tile(300, 280, 6, "V0")          # > 65 536 nodes: the large-batch GEMM form
     g_big = gb.build_graphs([d, d2], [m, m2], None, [(0.5, 0.5)] * 2)
     n = int(m.sum())
     assert torch.equal(model.predict(g_big)["class_logits"][:n], split["class_logits"])
 
 
-def test_matrix_paths_distance_to_float64(gpu_device, monkeypatch):
+def test_matrix_paths_distance_to_float64(gpu_device):
     """How far each matrix path is from the TRUE result (the float64 forward of the oracle), on BASELINE config 2 and on
     a fully valid tile: exact-f32 MFMA, fp16x3 and bf16x3 next to the float32 CPU forward.  The split paths must stay within the
     same order of rounding noise as float32 arithmetic itself (bounds below); the numbers are written to
@@ -458,15 +474,13 @@ def test_matrix_paths_distance_to_float64(gpu_device, monkeypatch):
             e = (lg.double().cpu() - ref64["class_logits"]).abs()
             return {"max": float(e.max()), "rms": float((e ** 2).mean().sqrt())}
         row["cpu_float32"] = dist(ref32["class_logits"])
-        for key, env in (("exact_f32_mfma", None), ("fp16x3", "BGNN_SPLIT_F16"), ("bf16x3", "BGNN_SPLIT_BF16")):
-            monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
-            if env:
-                monkeypatch.setenv(env, "1")
+        for key, path in (("exact_f32_mfma", "exact_f32"), ("fp16x3", "fp16x3"), ("bf16x3", "bf16x3")):
+            _set_matrix_path(path)
             out = model.predict(g)
             row[key] = dist(out["class_logits"])
             row[key]["class_agreement_with_float64"] = float(
                 (out["class_logits"].argmax(1).cpu() == ref64["class_logits"].argmax(1)).double().mean())
-        monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
+        _set_matrix_path("exact_f32")
         report[name] = row
         print(name, json.dumps(row))
         assert row["exact_f32_mfma"]["max"] < TOL and row["fp16x3"]["max"] < TOL and row["bf16x3"]["max"] < TOL
@@ -510,8 +524,8 @@ def test_other_backbones_on_foreign_graphs(kind, gpu_device):
             m.predict(data)
 
 
-def test_fp16_split_falls_back_when_a_weight_exceeds_float16(gpu_device, monkeypatch):
-    """BGNN_SPLIT_F16 with a weight beyond 65 504: the float16 image is left out at model load and the bf16 split runs."""
+def test_fp16_split_falls_back_when_a_weight_exceeds_float16(gpu_device):
+    """matrix_path = fp16x3 with a weight beyond 65 504: the float16 image is left out at model load and the bf16 split runs."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     sd = dict(synthetic.synthetic_state_dict(in_channels=7, seed=1234))
@@ -520,11 +534,11 @@ def test_fp16_split_falls_back_when_a_weight_exceeds_float16(gpu_device, monkeyp
     model = _model(sd)
     d, m, _ = synthetic.synthetic_tile(48, 40, 6, "V1")
     g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
-    monkeypatch.delenv("BGNN_SPLIT_BF16", raising=False); monkeypatch.delenv("BGNN_SPLIT_F16", raising=False)
+    _set_matrix_path("exact_f32")
     exact = model.predict(g)["class_logits"].clone()
-    monkeypatch.setenv("BGNN_SPLIT_F16", "1")
+    _set_matrix_path("fp16x3")
     f16 = model.predict(g)["class_logits"].clone()
-    monkeypatch.delenv("BGNN_SPLIT_F16"); monkeypatch.setenv("BGNN_SPLIT_BF16", "1")
+    _set_matrix_path("bf16x3")
     bf16 = model.predict(g)["class_logits"].clone()
     assert torch.isfinite(f16).all() and torch.equal(f16, bf16)
     assert (f16 - exact).abs().max().item() < 1e-2 * max(1.0, exact.abs().max().item())

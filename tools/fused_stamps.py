@@ -1,4 +1,7 @@
+"""Per-phase cycle sums of the fused layer kernel.  Needs the diagnostic build of the library:
+    python __graft_entry__.py --diag && BGNN_LIB=bathymetric-gnn_amd/libbgnn_hip_diag.so python tools/fused_stamps.py"""
 import os, sys, ctypes as C
+os.environ.setdefault("BGNN_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bathymetric-gnn_amd", "libbgnn_hip_diag.so"))
 os.environ["BGNN_FUSED_STAMPS"]="1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
