@@ -193,10 +193,9 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
   {   // defaults from the environment, read once per context
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     BgnnOpts &o = c->opts;
-    o.matrix_path = getenv("BGNN_SPLIT_F16") ? 2 : getenv("BGNN_SPLIT_BF16") ? 1 : 0;
+    o.matrix_path = getenv("BGNN_BF16") ? 3 : getenv("BGNN_SPLIT_F16") ? 2 : getenv("BGNN_SPLIT_BF16") ? 1 : 0;
     o.fused = getenv("BGNN_NO_FUSED") ? 0 : 1;
     o.fold_extractor = getenv("BGNN_NO_FOLD") ? 0 : 1;
-    o.fused_column_split = getenv("BGNN_FUSED_SPLIT") ? 1 : 0;
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
@@ -212,7 +211,7 @@ static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
       {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor},
-      {"fused_column_split", &o.fused_column_split}, {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
+      {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
   for (auto &t : tab) if (strcmp(t.n, name) == 0) return t.p;
@@ -223,7 +222,7 @@ int bgnn_ctx_set_option(bgnn_ctx *ctx, const char *name, int value) {
   BGNN_REQUIRE(ctx && name, "bgnn_ctx_set_option: NULL argument");
   int *p = option_slot(ctx, name);
   BGNN_REQUIRE(p, "bgnn_ctx_set_option: unknown option '%s'", name);
-  if (p == &ctx->opts.matrix_path) BGNN_REQUIRE(value >= 0 && value <= 2, "matrix_path=%d (0 exact f32, 1 bf16x3, 2 fp16x3)", value);
+  if (p == &ctx->opts.matrix_path) BGNN_REQUIRE(value >= 0 && value <= 3, "matrix_path=%d (0 exact f32, 1 bf16x3, 2 fp16x3, 3 bf16 storage)", value);
   if ((p == &ctx->opts.diag_mask || p == &ctx->opts.diag_stamps || p == &ctx->opts.gemm_diag) && value != 0)
     BGNN_REQUIRE(BGNN_DIAG, "option '%s' needs the diagnostic build of the library (python __graft_entry__.py --diag)", name);
   *p = value;
@@ -377,6 +376,18 @@ static bool pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool
               dst[((((size_t)hc * NT + t) * 2 + part) * 2 + kg) * 256 + m * 8 + i] = v;
             }
   return true;
+}
+
+// bf16 (hi only) image for the bf16 storage path: [D/16 half-chunks][NC/32 tiles][1 KiB = k-group 2 x column 32 x k 8]
+static void pack_bf16_image(const float *Wt, int D, int NC, float *dst_as_float) {
+  uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
+  const int NT = NC / 32;
+  for (int hc = 0; hc < D / 16; ++hc)
+    for (int t = 0; t < NT; ++t)
+      for (int kg = 0; kg < 2; ++kg)
+        for (int m = 0; m < 32; ++m)
+          for (int i = 0; i < 8; ++i)
+            dst[(((size_t)hc * NT + t) * 2 + kg) * 256 + m * 8 + i] = bf16_rne(Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m]);
 }
 
 int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
@@ -541,28 +552,31 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
 
   // bf16 and float16 hi / lo images of the fused kernels' next-stage weights (layers 1.., the heads' first layers) and
   // of the folded layer-0 weight
-  std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0);
-  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0;
+  std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0), o_wbf(L, 0);
+  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0, o_hW0bf = 0, o_l0fbf = 0;
   bool f16_ok = true;                  // every weight fits float16: else BGNN_SPLIT_F16 falls back to the bf16 split
   if (gat) {
     for (int l = 1; l < L; ++l) {
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
-      o_wsp[l] = reserve((size_t)D * HC); o_wsp16[l] = reserve((size_t)D * HC);
+      o_wsp[l] = reserve((size_t)D * HC); o_wsp16[l] = reserve((size_t)D * HC); o_wbf[l] = reserve((size_t)D * HC / 2);
     }
-    o_hW0sp = reserve((size_t)hid * HT); o_hW0sp16 = reserve((size_t)hid * HT);
-    o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0);
+    o_hW0sp = reserve((size_t)hid * HT); o_hW0sp16 = reserve((size_t)hid * HT); o_hW0bf = reserve((size_t)hid * HT / 2);
+    o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0); o_l0fbf = reserve((size_t)hid * HC0 / 2);
     for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
       pack_split(src.data(), D, HC, pk.data() + o_wsp[l], false);
       if (!pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true)) f16_ok = false;
+      pack_bf16_image(src.data(), D, HC, pk.data() + o_wbf[l]);
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
     pack_split(src.data(), hid, HT, pk.data() + o_hW0sp, false);
     if (!pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true)) f16_ok = false;
+    pack_bf16_image(src.data(), hid, HT, pk.data() + o_hW0bf);
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
     if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
+    pack_bf16_image(src0.data(), hid, HC0, pk.data() + o_l0fbf);
   }
 
   bgnn_model *m = new bgnn_model();
@@ -575,6 +589,8 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
   m->l0f_Wsp = gat ? m->blob + o_l0fsp : nullptr;
   m->l0f_Wsp16 = gat && f16_ok ? m->blob + o_l0fsp16 : nullptr;
+  m->l0f_Wbf = gat ? m->blob + o_l0fbf : nullptr;
+  m->hd_W0bf = gat ? m->blob + o_hW0bf : nullptr;
   m->layers.resize(L);
   for (int l = 0; l < L && !gat; ++l) {
     BgnnLayer &Ly = m->layers[l];
@@ -597,6 +613,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
     Ly.Wsp16 = l > 0 && f16_ok ? m->blob + o_wsp16[l] : nullptr;
+    Ly.Wbf = l > 0 ? m->blob + o_wbf[l] : nullptr;
     Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
   }
   m->head_hidden_total = HT;
@@ -825,7 +842,15 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   float *X = (float *)pa, *Y = (float *)pb, *hidb = (float *)phid;
   float *asdX = (float *)pasd, *asdY = asdX + rows * 2 * d.heads;
   const int64_t *dm = g->d_counts;
-  const bool use_fused = ctx->opts.fused && !tr;   // the fused layers carry the folded eval statistics
+  const bool use_fused = ctx->opts.fused && !tr;
+  // matrix_path 3 (BASELINE config 3): layer activations xw are stored as bf16 and multiplied on the bf16 MFMA; it exists
+  // only on the fused stencil path of the default model shape and only in eval mode
+  const bool bf16 = ctx->opts.matrix_path == 3 && !tr;
+  if (bf16) {
+    BGNN_REQUIRE(gat && use_fused && g->kind == 0 && hid == 64 && d.heads == 4 && d.num_layers >= 2 && g->ED == 3 && !o->hidden,
+                 "matrix_path = bf16 (bf16 activation storage) runs on the fused stencil path of the default model shape only "
+                 "(GAT, hidden 64, heads 4, >= 2 layers, 3 edge features, graphs built by bgnn_graph_build)");
+  }   // the fused layers carry the folded eval statistics
   void *bnws = nullptr;
   if (tr) BGNN_TRY(ctx_workspace(ctx, 5, bn_train_workspace_bytes(maxw >= 256 ? 256 : maxw), &bnws));
   size_t tr_off = 0;
@@ -895,9 +920,10 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
                                L0.att_src, L0.att_dst, asdX, L0.heads, hid,
-                               sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr,
-                               sm == 2 && m->l0f_Wsp16 ? 2 : sm ? 1 : 0));
+                               sm == 3 ? m->l0f_Wbf : sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr,
+                               sm == 3 ? 3 : sm == 2 && m->l0f_Wsp16 ? 2 : sm ? 1 : 0));
     } else {
+      BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));
       BGNN_TRY(launch_gemm_f32(ctx, Y, L0.d_in, L0.Wt, nullptr, X, L0.heads * hid, dm, rows, L0.d_in, L0.heads * hid, 0,
@@ -917,6 +943,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       int rc = use_fused ? launch_fused_layer_next(ctx, g, L, Ln, hid, d.edge_dim, X, asdX, Y, asdY) : BGNN_ERR_UNSUPPORTED;
       if (rc == BGNN_OK) { std::swap(X, Y); std::swap(asdX, asdY); continue; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
+      BGNN_REQUIRE(!bf16, "matrix_path = bf16: no fused instance for layer %d of this model / graph", (int)l);
       rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
       if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
       BGNN_TRY(rc);
@@ -930,6 +957,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
                          : BGNN_ERR_UNSUPPORTED;
       if (rc == BGNN_OK) { if (grids) grids->done = true; return BGNN_OK; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
+      BGNN_REQUIRE(!bf16, "matrix_path = bf16: no fused instance for the last layer of this model / graph");
       rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
       if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
       BGNN_TRY(rc);
@@ -1035,7 +1063,7 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
     o.predicted_class = (int64_t *)p;
     o.confidence = (float *)(o.predicted_class + rows);
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
-    const bool try_fused = ctx->opts.fused && g->kind == 0 && (g->K == 4 || g->K == 8) &&
+    const bool try_fused = ctx->opts.fused && g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->ED == 3 &&
                            m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
     rc = forward_impl(ctx, m, g, thr_auto, thr_review, try_fused ? &none : &o, &go);
     if (rc == BGNN_OK && !go.done) {

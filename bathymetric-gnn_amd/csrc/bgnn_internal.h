@@ -73,10 +73,9 @@ struct BgnnWorkItem {
 // BGNN_SPLIT_BF16, BGNN_NO_FUSED, BGNN_NO_FOLD, ...); afterwards only bgnn_ctx_set_option changes them -- no getenv on
 // the launch path.
 struct BgnnOpts {
-  int matrix_path = 0;       // 0 exact f32, 1 bf16x3, 2 fp16x3 (opt-in operand-split matrix paths)
+  int matrix_path = 0;       // 0 exact f32, 1 bf16x3, 2 fp16x3 (opt-in operand-split matrix paths), 3 bf16 activation storage + bf16 MFMA
   int fused = 1;             // 0: K3 / K4 / K5 / K6 as separate kernels
   int fold_extractor = 1;    // 0: run the extractor's second Linear and lin of layer 0 unfolded
-  int fused_column_split = 0;  // experiment: 8-wave workgroups with the accumulator split by columns
   int fused_lds_pad_kb = 0;    // experiment: pad the fused kernel's LDS request (occupancy)
   int diag_mask = 0;         // BGNN_DIAG builds only: phase ablation bits of the fused kernel
   int diag_stamps = 0;       // BGNN_DIAG builds only: per-phase s_memtime sums
@@ -123,6 +122,7 @@ struct BgnnLayer {
   float *shift;     // [width]  (conv bias - mean) * scale + BN bias
   float *Wsp;       // Wt as a bf16 hi / lo split image for the bf16x3 matrix path (same byte geometry as Wt; see pack_split)
   float *Wsp16;     // the same with float16 parts (fp16x3)
+  float *Wbf;       // Wt as a bf16 (hi only) image for the bf16 storage path: [D/16][NC/32][1 KiB] in MFMA A-fragment lane order
   // non-attention backbones (desc.gnn_type != BGNN_GNN_GAT): Wt = GCN lin^T [hid][hid] | SAGE [lin_l^T ; lin_r^T] [2 hid][hid]
   // with BatchNorm folded in | GIN nn.0^T [hid][hid]; then
   float *b1;        // GIN nn.0 bias [hid]
@@ -142,6 +142,7 @@ struct bgnn_model {
   float *fe_W0t, *fe_b0, *fe_W1t, *fe_b1;     // [in8][hid], [hid], [hid][hid], [hid]
   float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
   float *l0f_Wsp = nullptr, *l0f_Wsp16 = nullptr;   // l0f_Wt as bf16 / float16 hi / lo split images
+  float *l0f_Wbf = nullptr, *hd_W0bf = nullptr;     // l0f_Wt / hd_W0t as bf16 (hi only) images
   std::vector<BgnnLayer> layers;
   float *ones = nullptr;      // [256] of 1.0f: the identity scale of an unfolded epilogue
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
@@ -225,9 +226,9 @@ int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLay
                                const float *asd, float *out, int relu);
 // fused K4 + next K3 (EPI_NEXT) / K4(last) + K5 + K6 (EPI_HEADS); BGNN_ERR_UNSUPPORTED when no instance fits
 int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, int ED,
-                            const float *xw, const float *asd, float *xw_next, float *asd_next);
+                            const void *xw, const float *asd, void *xw_next, float *asd_next);
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
-                             const float *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
+                             const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);
 int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv);
 int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const float *x, int D, const float *dinv,

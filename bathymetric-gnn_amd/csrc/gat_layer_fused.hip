@@ -17,6 +17,15 @@
 //               16 x NT MFMAs | barrier | DMA W rows 0-15 of slab s+1 | 16 x NT MFMAs | barrier | DMA W rows 16-31
 // so every DMA has at least half a slab of matrix work (plus the next gather) to land.
 //
+// Stencils (template K): 4 / 8 (the reference's connectivities, halo of 1 cell: 10 x 18 rows per block) and 16
+// ("16-dilated", BASELINE config 3: the 8 base offsets and the same x 2; halo of 2 cells: 12 x 20 rows).
+//
+// Matrix / storage modes (template SP):
+//   0  exact f32: activations f32 in HBM, v_mfma_f32_32x32x2_f32 (default; the parity path)
+//   1  bf16x3, 2 fp16x3: activations f32 in HBM, operands split hi + lo in registers, three 16-bit MFMAs (opt-in)
+//   3  bf16: activations (xw) stored as bf16 in HBM, one v_mfma_f32_32x32x16_bf16 per 16 k; softmax, aggregation, BatchNorm,
+//      attention dots and every accumulator stay f32 (BASELINE config 3 "bf16 node features"; not a parity path)
+//
 // Reference semantics: models/gnn.py:173-188 (conv -> norm -> relu), :392-406 (heads),
 // :427-449 (predict), models/pipeline.py:278-307 (grids); GATConv per SURVEY Appendix B.
 #include <stdlib.h>
@@ -49,21 +58,21 @@ enum { EPI_NEXT = 0, EPI_HEADS = 1 };
 struct FusedArgs {
   TileBlocks tb;
   const int32_t *node_id;
-  const float *xw;        // [rows][HC]   this layer's lin(x)
+  const void *xw;         // [rows][HC]   this layer's lin(x): f32, or bf16 with SP = 3
   const float *asd;       // [rows][2H]
-  const float *eattr;     // [rows][K][ED]
-  const float *V;         // [H][ED]
+  const float *eattr;     // [rows][K][3]
+  const float *V;         // [H][3]
   const float *scale;     // [HC] folded bias + BatchNorm
   const float *shift;
-  const float *Wt;        // [HC][NC] next stage weight (transposed)
+  const float *Wt;        // [HC][NC] next stage weight (transposed); split / bf16 image with SP != 0
   const float *zero_page; // >= 16 B of zeros (source of halo rows that have no node)
   float *dump;            // >= 1 KiB scratch row: stores of rows that have no node land here (keeps the epilogue branch-free)
-  int ED, relu, dbg;
-  unsigned long long *stamps;   // diagnostic build only (BGNN_FUSED_STAMPS): per-phase cycle sums
+  int relu, dbg;
+  unsigned long long *stamps;   // diagnostic build only: per-phase cycle sums
   // EPI_NEXT
   const float *att_src;   // [NC]
   const float *att_dst;
-  float *out;             // [rows][NC]
+  void *out;              // [rows][NC]  f32, or bf16 with SP = 3
   float *asd_out;         // [rows][2*H2]
   int H2, C2;
   // EPI_HEADS
@@ -78,6 +87,7 @@ struct FusedArgs {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS reads issued from inline asm.  hipcc cannot tell an LDS-DMA's destination from the address of a
 // later ds_read, so with a DMA in flight it puts s_waitcnt vmcnt(0) in front of every compiler-visible
@@ -90,6 +100,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read4(uint32_t addr) {
   f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read4u(uint32_t addr) {
+  u32x4 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
@@ -139,8 +155,8 @@ struct MfmaGroups {
 // accumulation on v_mfma_f32_32x32x16_bf16 -- 3 instructions of 32 cycles per 16 k instead of 8 x 64 cycles of
 // v_mfma_f32_32x32x2_f32, and on the matrix pipe proper: unlike the f32 MFMA (which runs at the VALU rate and blocks
 // its SIMD neighbour) it co-executes with the other workgroup's vector work.  Class logits move by ~6e-6
-// (tools/bf16_split_accuracy.py); the exact-f32 path stays the default.
-// fp16x3 (BGNN_SPLIT_F16=1) is the same scheme with float16 parts on v_mfma_f32_32x32x16_f16: 11-bit parts instead of 8,
+// (tests/study_bf16_split_accuracy.py); the exact-f32 path stays the default.
+// fp16x3 is the same scheme with float16 parts on v_mfma_f32_32x32x16_f16: 11-bit parts instead of 8,
 // so hi + lo carries 22 bits and the logits land within ~5e-7 of the float64 forward (float32 itself: 2e-7) -- but only
 // while |x| stays below 65 504 (float16 range); larger activations would saturate.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -153,6 +169,13 @@ __device__ __forceinline__ void split_lp(const f32x4 &ga, const f32x4 &gb, V8 &h
   for (int i = 0; i < 8; ++i) hi[i] = (E)v[i];
 #pragma unroll
   for (int i = 0; i < 8; ++i) lo[i] = (E)(v[i] - (float)hi[i]);
+}
+__device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 &ga, const f32x4 &gb) {
+  const float v[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];       // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return r;
 }
 __device__ __forceinline__ f32x16 mfma_lp(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -181,63 +204,97 @@ struct SplitTiles {
   }
 };
 
+// plain bf16 (SP = 3): one MFMA per tile and 16 k; tile t's fragment sits at wh + t KiB (hi-only image)
+template <int NT, int T>
+struct Bf16Tiles {
+  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const bf16x8 &x, uint32_t wh, f32x4 aw) {
+    lds_reads_done();
+    f32x4 nw = aw;
+    if constexpr (T + 1 < NT) nw = lds_read4<(T + 1) * 1024>(wh);
+    acc[T] = mfma_lp(__builtin_bit_cast(bf16x8, aw), x, acc[T]);
+    if constexpr (T + 1 < NT) Bf16Tiles<NT, T + 1>::step(acc, x, wh, nw);
+  }
+  __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const bf16x8 &x, uint32_t wh) {
+    static_assert(T == 0, "entry point");
+    step(acc, x, wh, lds_read4<0>(wh));
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NT, int NW = 4, int ROWS = 32>
-__device__ __forceinline__ void stage_w_chunk(const float *Wt, float *dst, int k0, int wave, int lane) {
-  // rows k0..k0+ROWS-1 of Wt[.][NC]: ROWS*NC contiguous floats = ROWS*NT/8 pieces of 1 KiB over NW waves
-  constexpr int NC = NT * 32;
-  const char *src = reinterpret_cast<const char *>(Wt + (int64_t)k0 * NC);
-  constexpr int NQ = ROWS * NT / 8;
-  if (NW > 4) asm volatile("" : "+v"(lane));          // 128-register budget: do not keep per-piece 64-bit offsets alive
+// One HALF of a slab's W chunk (16 k rows of every column) is BYTES contiguous bytes of the weight image: 16 x NC f32
+// (exact and split images share that byte geometry) or 16 x NC bf16 (hi-only image, SP = 3) = NQ pieces of 1 KiB
+// dealt over the 4 waves.
+template <int NT, int SP>
+struct WHalf {
+  static constexpr int BYTES = SP == 3 ? NT * 1024 : 2 * NT * 1024;
+  static constexpr int NQ = BYTES / 1024;
+  static constexpr int PER_WAVE = NQ / 4;                 // floor: a wait that counts on this many is conservative
+};
+template <int NT, int SP>
+__device__ __forceinline__ void stage_w_half(const float *Wt, float *wbuf, int half_index, int wave, int lane) {
+  using G = WHalf<NT, SP>;
+  const char *src = reinterpret_cast<const char *>(Wt) + (int64_t)half_index * G::BYTES;
+  float *dst = wbuf + (half_index & 1) * (G::BYTES / 4);
 #pragma unroll
-  for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
-    const int q = j * NW + wave;
-    if (q < NQ)
+  for (int j = 0; j < (G::NQ + 3) / 4; ++j) {
+    const int q = j * 4 + wave;
+    if (q < G::NQ)
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void *)(dst + q * 256), 16, 0, 0);
   }
 }
 
 constexpr int FT_H = 8;                                  // fused kernel: 8 x 16 cell blocks
-constexpr int FHR = (FT_H + 2) * HALO_W;                 // 180 halo rows
 
-template <int HC, int C, int K, int NT, int EPI>
-struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and launcher agree through this)
-  static constexpr int H = HC / C, NC = NT * 32;
-  static constexpr int RA = FHR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : 0);
-  static constexpr int RSZ = RA > RB ? RA : RB;
-  static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
-  static constexpr int FLOATS = FHR * 32 + 32 * NC + RSZ + FHR + 4 + 128 * APITCH;
+template <int K>
+struct FusedGeom {                                       // halo geometry of one block
+  static constexpr int R = K == 16 ? 2 : 1;              // halo radius in cells
+  static constexpr int HW = TILE_W + 2 * R;              // halo row width  (18 / 20)
+  static constexpr int HR = (FT_H + 2 * R) * HW;         // halo rows       (180 / 240)
 };
 
-template <int HC, int C, int K, int NT, int EPI, int NS, int SP = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3
-__global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fused_kernel(FusedArgs a) {
-  static_assert(!SP || NS == 1, "the bf16x3 path is built for the 4-wave form");
+template <int HC, int C, int K, int NT, int EPI, int SP>
+struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and launcher agree through this)
+  static constexpr int H = HC / C, NC = NT * 32, HR = FusedGeom<K>::HR;
+  static constexpr int XB = SP == 3 ? 2 : 4;             // bytes per stored activation
+  static constexpr int SLAB = HR * 32 * XB / 4;          // [HR][32 channels]
+  static constexpr int WBUF = 2 * WHalf<NT, SP>::BYTES / 4;
+  // the epilogue's four wave-private 32 x 36 store patches reuse slab (+ wbuf)
+  static constexpr int PATCH_PAD = EPI == EPI_NEXT && SLAB + WBUF < 4 * 32 * TILED_PITCH ? 4 * 32 * TILED_PITCH - SLAB - WBUF : 0;
+  static constexpr int RA = HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : 0);
+  static constexpr int RSZ = RA > RB ? RA : RB;
+  static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
+  static constexpr int FLOATS = SLAB + WBUF + PATCH_PAD + RSZ + HR + 4 + 128 * APITCH;
+  static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
+};
+
+template <int HC, int C, int K, int NT, int EPI, int SP = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3, 3 bf16 storage + MFMA
+__global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) void gat_layer_fused_kernel(FusedArgs a) {
   // (narrow next stages leave registers and LDS for a third workgroup per CU)
-  // 4*NS waves, two workgroups per CU.  Wave w: node group ng = w & 3 (cells 32ng..32ng+31, two tile rows) and,
-  // for NS = 2, column half nh = w >> 2 of the NC output channels.  Lane (r, hl): node r of the group, k-half hl.
-  // NS = 2 halves the accumulator (64 registers) so that 16 waves fit a CU: the two waves of a node group each
-  // gather the same B operands (cheap) and multiply them into their own half of the columns.  More resident
-  // waves = more of the per-workgroup latency chains (halo ids, alpha, DMA waits, epilogue) hidden under MFMAs.
-  constexpr int NTH = 256 * NS, NTL = NT / NS;
+  // 4 waves.  Wave w: cells 32w..32w+31 of the block (two tile rows).  Lane (r, hl): node r of the group, k-half hl.
+  constexpr int NTH = 256;
   constexpr int H = HC / C;
   constexpr int NC = NT * 32;
   constexpr int NSLAB = HC / 32, SPH = C / 32;
-  constexpr int HR = FHR, HW_ = HALO_W;
-  static_assert(NS == 1 || EPI == EPI_NEXT, "column split is built for the layer -> layer form only");
+  using Geo = FusedGeom<K>;
+  using Lds = FusedLds<HC, C, K, NT, EPI, SP>;
+  constexpr int HR = Geo::HR, HW_ = Geo::HW, RAD = Geo::R;
+  constexpr int XB = Lds::XB;                            // bytes per stored activation
+  constexpr int ROWB = 32 * XB;                          // bytes of one halo row's slab (128 / 64)
+  constexpr int CPR = ROWB / 16;                         // 16-byte chunks per row slab (8 / 4)
   using Off = StencilOffsets<K>;
   extern __shared__ __attribute__((aligned(128))) float lds[];
   float *slab = lds;                                   // [HR][32]  halo rows of the current slab, 16-B chunks XOR-swizzled
-  float *wbuf = slab + HR * 32;                        // [32][NC]  W_{l+1} rows of the current slab
+  float *wbuf = slab + Lds::SLAB;                      // W_{l+1} rows of the current slab: two 16-row halves
   // Region R is time-shared: alpha_src of the halo rows during phase A, then (from the first slab barrier on)
   // the folded scale / shift table and, behind it, the next layer's att_src | att_dst for the epilogue.
-  constexpr int RSZ = FusedLds<HC, C, K, NT, EPI>::RSZ, APITCH = FusedLds<HC, C, K, NT, EPI>::APITCH;
-  float *has = wbuf + 32 * NC;                         // [HR][H]   (phase A)
+  constexpr int RSZ = Lds::RSZ, APITCH = Lds::APITCH;
+  float *has = wbuf + Lds::WBUF + Lds::PATCH_PAD;      // [HR][H]   (phase A)
   float *scsh = has;                                   // [2][HC]   folded scale / shift (slab loop)
   float *attr = has + 2 * HC;                          // [2][NC]   att_src | att_dst (epilogue, EPI_NEXT)
   int *hid = reinterpret_cast<int *>(has + RSZ);       // [HR]
@@ -249,41 +306,39 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 #endif
   const BlockPos pos = decode_block<FT_H>(a.tb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ng = wave & 3, nh = wave >> 2;
   const int r = lane & 31, hl = lane >> 5;
-  const int cell = ng * 32 + r;                        // block-local cell of this lane
+  const int cell = wave * 32 + r;                      // block-local cell of this lane
   const int tr = cell / TILE_W, tc = cell % TILE_W;
-  const int self_idx = (tr + 1) * HW_ + tc + 1;
+  const int self_idx = (tr + RAD) * HW_ + tc + RAD;
 
   // W rows of slab 0 depend on nothing: first in the VM queue.
-  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, 0, wave, lane);
-  stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, 16, wave, lane);
+  stage_w_half<NT, SP>(a.Wt, wbuf, 0, wave, lane);
+  stage_w_half<NT, SP>(a.Wt, wbuf, 1, wave, lane);
 
   // Prologue loads, two dependent rounds with everything of a round in flight together:
   //   round 1: node id of this thread's halo row (HR <= NTH: one row per thread), of this lane's own cell, and of
-  //            the <= NPIECE halo rows whose chunks this thread moves by DMA (8 lanes share a row);
+  //            the <= NPIECE halo rows whose chunks this thread moves by DMA (CPR lanes share a row);
   //   -> slab 0's DMA is issued straight from those registers (no LDS round trip, no barrier);
-  //   round 2: alpha_src of the halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...
-  //            for NS = 1) -- consumed in phase A, so their latency hides behind the halo bookkeeping.
+  //   round 2: alpha_src of the halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...)
+  //            -- consumed in phase A, so their latency hides behind the halo bookkeeping.
   static_assert(HR <= NTH, "one halo row per thread");
-  constexpr int NHL = (H + 2 * NS - 1) / (2 * NS);      // heads per lane
-  constexpr int NPIECE = (HR * 8 + NTH - 1) / NTH;
-  static_assert((NPIECE - 2) * NTH + NTH - 64 < HR * 8, "every wave moves NPIECE or NPIECE - 1 pieces");
-  const bool pre = a.ED == 3 && !DBG(32);
+  constexpr int NHL = (H + 1) / 2;                      // heads per lane
+  constexpr int NPIECE = (HR * CPR + NTH - 1) / NTH;
+  static_assert((NPIECE - 2) * NTH + NTH - 64 < HR * CPR, "every wave moves NPIECE or NPIECE - 1 pieces");
   int my_pre = -1, hid_v = -1;
   {
-    const int gr = pos.r0 + tid / HW_ - 1, gc = pos.c0 + tid % HW_ - 1;
+    const int gr = pos.r0 + tid / HW_ - RAD, gc = pos.c0 + tid % HW_ - RAD;
     if (tid < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) hid_v = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
-  if (pre) {
+  if (!DBG(32)) {
     const int gr = pos.r0 + tr, gc = pos.c0 + tc;
     if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
   int drow[NPIECE];
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) {
-    const int row = (p * NTH + tid) >> 3;
-    const int gr = pos.r0 + row / HW_ - 1, gc = pos.c0 + row % HW_ - 1;
+    const int row = (p * NTH + tid) / CPR;
+    const int gr = pos.r0 + row / HW_ - RAD, gc = pos.c0 + row % HW_ - RAD;
     drow[p] = -1;
     if (row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) drow[p] = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
@@ -297,15 +352,17 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   float vpre[NHL][3];
 #pragma unroll
   for (int i = 0; i < NHL; ++i) {
-    const int hh = nh * 2 + hl + i * 2 * NS;
+    const int hh = hl + i * 2;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) vpre[i][f] = (pre && hh < H) ? a.V[hh * 3 + f] : 0.0f;
+    for (int f = 0; f < 3; ++f) vpre[i][f] = hh < H ? a.V[hh * 3 + f] : 0.0f;
   }
 
-  // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 8 rows x 128 B;
-  // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk
-  // p ^ ((row >> 1) & 7).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
+  // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 64 / CPR rows x ROWB bytes;
+  // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk p ^ swz(row), with
+  // swz(row) = (row >> 1) & 7 for 128-byte rows and (row >> 2) & 3 for 64-byte rows (16 consecutive rows then cover the
+  // 16 distinct 16-byte bank groups).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
   // offsets (32 bits, relative to the smallest node id this WAVE touches) are computed once.
+  auto swz = [](int row) { return XB == 4 ? (row >> 1) & 7 : (row >> 2) & 3; };
   int id0;
   {
     int m = 0x7fffffff;
@@ -319,21 +376,21 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) {
     const int idx = p * NTH + tid;
-    const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
-    doff[p] = drow[p] >= 0 ? (uint32_t)(drow[p] - id0) * (uint32_t)(HC * 4) + (uint32_t)(c * 16) : 0xffffffffu;
+    const int row = idx / CPR, c = (idx % CPR) ^ swz(row);
+    doff[p] = drow[p] >= 0 ? (uint32_t)(drow[p] - id0) * (uint32_t)(HC * XB) + (uint32_t)(c * 16) : 0xffffffffu;
   }
-  const char *xbase = reinterpret_cast<const char *>(a.xw + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * HC);
+  const char *xbase = reinterpret_cast<const char *>(a.xw) + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * (HC * XB);
   // Rows without a node read the context's zero page, so that EVERY wave issues a fixed number of slab pieces
-  // (npc: 6 / 6 / 6 / 5 for NTH = 256) and the counted waits below can leave exactly the next slab in flight.
+  // (npc) and the counted waits below can leave exactly the next slab in flight.
   const char *zp = reinterpret_cast<const char *>(a.zero_page);
   int npc = 0;
 #pragma unroll
-  for (int p = 0; p < NPIECE; ++p) npc += (p * NTH + wave * 64 < HR * 8) ? 1 : 0;
+  for (int p = 0; p < NPIECE; ++p) npc += (p * NTH + wave * 64 < HR * CPR) ? 1 : 0;
   auto issue_slab = [&](int s) {
-    const char *sb = xbase + s * 128;                  // wave-uniform
+    const char *sb = xbase + s * ROWB;                 // wave-uniform
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) {
-      if (p * NTH + tid < HR * 8) {
+      if (p * NTH + tid < HR * CPR) {
         const char *src = doff[p] != 0xffffffffu ? sb + doff[p] : zp;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src),
                                          (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
@@ -356,7 +413,7 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
     }
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
-      const int hh = nh * 2 + hl + i * 2 * NS;
+      const int hh = hl + i * 2;
       adv[i] = hh < H ? a.asd[(int64_t)my_pre * 2 * H + H + hh] : 0.0f;
     }
   }
@@ -368,21 +425,17 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   __syncthreads();
   BGNN_STAMP(1)   // round 2, halo tables in LDS
 
-  // ---- phase A: attention coefficients -> LDS.  The 2*NS lanes that share a cell (lane halves x column halves)
-  // take the heads round-robin.
+  // ---- phase A: attention coefficients -> LDS.  The two lanes that share a cell take the heads round-robin.
   {
     const int my = DBG(32) ? -1 : hid[self_idx];
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
-      const int hh = nh * 2 + hl + i * 2 * NS;
+      const int hh = hl + i * 2;
       if (hh < H) {
         float part[K + 1];
 #pragma unroll
         for (int b = 0; b <= K; ++b) part[b] = 0.0f;
-        if (my >= 0) {
-          if (pre) attention_coefficients_head_pre<H, K>(self_idx, hh, hid, has, eraw, adv[i], vpre[i], part);
-          else attention_coefficients_head<H, K>(my, self_idx, hh, hid, has, a.asd, a.eattr, a.V, a.ED, part);
-        }
+        if (my >= 0) attention_coefficients_head_pre<H, K, HW_>(self_idx, hh, hid, has, eraw, adv[i], vpre[i], part);
 #pragma unroll
         for (int b = 0; b <= K; ++b) alx[cell * APITCH + hh * (K + 1) + b] = part[b];
       }
@@ -391,30 +444,31 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
   }
 
   BGNN_STAMP(2)   // phase A
-  f32x16 acc[NTL];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < NTL; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
   const uint32_t slab0 = lds_addr(slab);
-  const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + nh * NTL * 32 + r);
-  // chunk (16 B = 4 channels) ownership of lane (r, hl) inside a 32-channel slab: exact-f32 path 2j + hl (k = 8j + 4hl + i
-  // of f32 k-step j); bf16x3 path {2hl, 2hl + 1} for k-step 0 and {4 + 2hl, 5 + 2hl} for k-step 1 (k = 16 step + 8hl + i)
+  const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r);
+  // chunk (16 B) ownership of lane (r, hl) inside a 32-channel slab: exact-f32 path channel chunks 2j + hl (k = 8j + 4hl + i
+  // of f32 k-step j); 16-bit MFMA paths channels 8hl..8hl+7 for k-step 0 and 16+8hl.. for k-step 1 (k = 16 step + 8hl + i)
   constexpr uint32_t CX1 = SP ? 16 : 32, CX2 = 64, CX3 = SP ? 80 : 96;
   const uint32_t scsh0 = lds_addr(scsh) + (SP ? hl * 32 : hl * 16);
-  const uint32_t wsp0 = lds_addr(wbuf) + lane * 16;      // bf16x3: A fragments are stored in lane order
+  const uint32_t wsp0 = lds_addr(wbuf) + lane * 16;      // 16-bit MFMA paths: A fragments are stored in lane order
   const uint32_t alx0 = lds_addr(alx + cell * APITCH);
+  constexpr uint32_t WHALF = WHalf<NT, SP>::BYTES;
 
-  // ---- slabs.  Lane (r, hl) gathers exactly the 16 values it feeds to the MFMA as B operand: channel chunks
-  // 2j + hl (j = 0..3) of node r, i.e. k = 8j + 4hl + i of k-step j -- no LDS round trip, no lane exchange.
+  // ---- slabs.  Lane (r, hl) gathers exactly the 16 values it feeds to the MFMA as B operand -- no LDS round trip, no
+  // lane exchange.
   {
 #pragma unroll 1
     for (int s = 0; s < NSLAB; ++s) {
       // VM queue order per wave: [slab s] [W rows 0-15 of slab s: WA] [W rows 16-31: WB] [slab s+1] [WA s+1] ...
-      // WA / WB are NTL/2 pieces per wave each (unconditional); slab pieces are exec-masked, so they are never
+      // WA / WB are WH pieces per wave each (unconditional); slab pieces are exec-masked, so they are never
       // counted on: a wait that must cover a W half uses only the W pieces issued after it.
-      constexpr int WH = (16 * NT / 8) / (4 * NS);       // pieces per wave in one W half
+      constexpr int WH = WHalf<NT, SP>::PER_WAVE;
       // (when the pieces do not divide evenly some waves issue one more: the floor only makes their wait conservative)
       if (s == 0) wait_vm_lgkm<0>();                    // (slab 0 was queued BEHIND its W rows: wait for everything)
       else wait_vm_lgkm<2 * WH>();
@@ -436,23 +490,39 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       }
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
-      int sidx = self_idx;
-      if (NS > 1) asm volatile("" : "+v"(sidx));        // 128-register budget: re-derive the 9 row addresses per slab
       f32x4 g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (!DBG(1))
 #pragma unroll
       for (int b = 0; b <= K; ++b) {
-        const int nidx = b == K ? sidx : sidx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
-        // slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5))
-        const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
-        f32x4 x[4];
+        const int nidx = b == K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
         const float alpha = lds_read1<0>(ap + 4 * b);
-        x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ CX1); x[2] = lds_read4<0>(rb ^ CX2); x[3] = lds_read4<0>(rb ^ CX3);
-        lds_reads_done();
+        if constexpr (SP == 3) {
+          // 64-byte rows of bf16: chunk hl (channels 8hl..8hl+7) and chunk 2 + hl (16+8hl..), swizzled by (row >> 2) & 3
+          const uint32_t rb = slab0 + nidx * 64 + ((((nidx >> 2) & 3) ^ hl) << 4);
+          const u32x4 xa = lds_read4u<0>(rb), xb = lds_read4u<0>(rb ^ 32);
+          lds_reads_done();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
+          for (int j = 0; j < 2; ++j) {                   // dword j of a chunk = channels (2j, 2j+1) as (low, high) halves
+            const u32x4 &x = j == 0 ? xa : xb;
+            g[2 * j].x += alpha * __uint_as_float(x.x << 16); g[2 * j].y += alpha * __uint_as_float(x.x & 0xffff0000u);
+            g[2 * j].z += alpha * __uint_as_float(x.y << 16); g[2 * j].w += alpha * __uint_as_float(x.y & 0xffff0000u);
+            g[2 * j + 1].x += alpha * __uint_as_float(x.z << 16); g[2 * j + 1].y += alpha * __uint_as_float(x.z & 0xffff0000u);
+            g[2 * j + 1].z += alpha * __uint_as_float(x.w << 16); g[2 * j + 1].w += alpha * __uint_as_float(x.w & 0xffff0000u);
+          }
+          // the sums are due HERE: without this the unpacked values of several neighbours are kept in registers and the
+          // FMAs sunk below the following reads (16 more live registers per neighbour -> spills)
+          asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
+        } else {
+          // slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5))
+          const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
+          f32x4 x[4];
+          x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ CX1); x[2] = lds_read4<0>(rb ^ CX2); x[3] = lds_read4<0>(rb ^ CX3);
+          lds_reads_done();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
+        }
       }
       // layer epilogue: (+bias, BatchNorm) folded, ReLU -> h_{l+1}, in registers
       {
@@ -483,64 +553,70 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
       using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
       using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
       LP8 xh0, xl0, xh1, xl1;
-      if constexpr (SP != 0) { split_lp<LP8, LPE>(g[0], g[1], xh0, xl0); split_lp<LP8, LPE>(g[2], g[3], xh1, xl1); }
+      if constexpr (SP == 1 || SP == 2) { split_lp<LP8, LPE>(g[0], g[1], xh0, xl0); split_lp<LP8, LPE>(g[2], g[3], xh1, xl1); }
+      if constexpr (SP == 3) { xh0 = to_bf16x8(g[0], g[1]); xh1 = to_bf16x8(g[2], g[3]); }
       if (!DBG(2)) {
-        if constexpr (SP != 0) SplitTiles<NTL, 0, LP8>::run(acc, xh0, xl0, wsp0);
-        else MfmaGroups<NTL, NC, 0, 4>::run(acc, g, wbuf0);
+        if constexpr (SP == 3) Bf16Tiles<NT, 0>::run(acc, xh0, wsp0);
+        else if constexpr (SP != 0) SplitTiles<NT, 0, LP8>::run(acc, xh0, xl0, wsp0);
+        else MfmaGroups<NT, NC, 0, 4>::run(acc, g, wbuf0);
       }
       // WB(s) landed; the npc pieces of slab s+1 issued above stay in flight
       if (s + 1 < NSLAB && !DBG(4)) { if (npc == NPIECE) wait_vm_lgkm<NPIECE>(); else wait_vm_lgkm<NPIECE - 1>(); }
       else wait_vm_lgkm<0>();
       __builtin_amdgcn_s_barrier();                     // every wave is done with W rows 0-15
-      if (s + 1 < NSLAB && !DBG(8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf, (s + 1) * 32, wave, lane);
+      if (s + 1 < NSLAB && !DBG(8)) stage_w_half<NT, SP>(a.Wt, wbuf, 2 * (s + 1), wave, lane);
       if (!DBG(2)) {
-        if constexpr (SP != 0) SplitTiles<NTL, 0, LP8>::run(acc, xh1, xl1, wsp0 + 16 * NC * 4);
-        else MfmaGroups<NTL, NC, 4, 8>::run(acc, g, wbuf0);
+        if constexpr (SP == 3) Bf16Tiles<NT, 0>::run(acc, xh1, wsp0 + WHALF);
+        else if constexpr (SP != 0) SplitTiles<NT, 0, LP8>::run(acc, xh1, xl1, wsp0 + WHALF);
+        else MfmaGroups<NT, NC, 4, 8>::run(acc, g, wbuf0);
       }
       BGNN_STAMP(6)   // MFMA
       if (s + 1 < NSLAB) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                   // every wave is done with W rows 16-31
-        if (!DBG(8)) stage_w_chunk<NT, 4 * NS, 16>(a.Wt, wbuf + 16 * NC, (s + 1) * 32 + 16, wave, lane);
+        if (!DBG(8)) stage_w_half<NT, SP>(a.Wt, wbuf, 2 * (s + 1) + 1, wave, lane);
         BGNN_STAMP(7)   // barrier + WB DMA issue
       }
     }
   }
 
   const float *attl = attr;                             // att_src | att_dst (DMA'd there during slab 0)
-  // NS == 1: the store patches below stay inside the slab region, which every wave left at the last slab's second
-  // barrier -- a wave goes straight from its last MFMA into its own epilogue.  NS == 2: the patches reach into wbuf.
-  if (EPI == EPI_NEXT && NS > 1) __syncthreads();
+  // exact / split paths: the store patches below stay inside the slab region, which every wave left at the last slab's
+  // second barrier -- a wave goes straight from its last MFMA into its own epilogue.  bf16 storage: the slab region is
+  // smaller than the four patches, which then reach into wbuf: wait until every wave has read its last W fragments.
+  if (EPI == EPI_NEXT && Lds::SLAB < 4 * 32 * TILED_PITCH) __syncthreads();
   if (!DBG(64)) {
     const int mr = tr, mc = tc;
     const int id = hid[self_idx];
     if (EPI == EPI_NEXT) {
       // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32).
-      // att_src / att_dst were staged into LDS (wbuf is free now): no global-load latency chain here.
-      constexpr int TPH = C / 32, H2 = NT / TPH, H2L = NTL / TPH > 0 ? NTL / TPH : 1;
-      static_assert(EPI != EPI_NEXT || NTL % TPH == 0, "a wave column share must hold whole heads");
+      // att_src / att_dst were staged into LDS: no global-load latency chain here.
+      constexpr int TPH = C / 32, H2 = NT / TPH;
+      static_assert(EPI != EPI_NEXT || NT % TPH == 0, "a wave's columns hold whole heads");
       typedef float f32x2 __attribute__((ext_vector_type(2)));
-      f32x2 ps[H2L], pd[H2L];                            // two-lane partial sums: the products go out as v_pk_fma_f32
+      f32x2 ps[H2 > 0 ? H2 : 1], pd[H2 > 0 ? H2 : 1];    // two-lane partial sums: the products go out as v_pk_fma_f32
 #pragma unroll
-      for (int hd = 0; hd < H2L; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
-      const uint32_t asl = lds_addr(attl + nh * NTL * 32 + 4 * hl);
+      for (int hd = 0; hd < H2; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
+      const uint32_t asl = lds_addr(attl + 4 * hl);
       // Row-per-lane stores (32 rows x 32 B per instruction) are store-issue bound; instead each 32x32 tile
-      // is transposed through a wave-private LDS patch (the slab region is free now) and written out as whole
-      // 128-byte row segments, 8 rows per instruction.
+      // is transposed through a wave-private LDS patch and written out as whole row segments: f32 128 bytes per row,
+      // 8 rows per instruction; bf16 64 bytes per row, 16 rows per instruction.
       float *patch = slab + wave * (32 * TILED_PITCH);
-      float *prow[4];                                   // output row of patch row (lane>>3) + 8k, column chunk lane&7
+      constexpr int LPR = SP == 3 ? 4 : 8;              // lanes per stored row
+      constexpr int NSTORE = 32 * LPR / 64;             // store instructions per tile (2 / 4)
+      char *prow[NSTORE];                               // output row of patch row (lane / LPR) + (64 / LPR) k, column chunk lane % LPR
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = ng * 32 + (lane >> 3) + 8 * k;
-        const int rid = hid[(c / TILE_W + 1) * HW_ + c % TILE_W + 1];
-        prow[k] = (rid >= 0 ? a.out + (int64_t)rid * NC : a.dump) + nh * NTL * 32 + (lane & 7) * 4;
+      for (int k = 0; k < NSTORE; ++k) {
+        const int c = wave * 32 + lane / LPR + (64 / LPR) * k;
+        const int rid = hid[(c / TILE_W + RAD) * HW_ + c % TILE_W + RAD];
+        prow[k] = (rid >= 0 ? reinterpret_cast<char *>(a.out) + (int64_t)rid * (NC * XB) : reinterpret_cast<char *>(a.dump)) + (lane % LPR) * 16;
       }
       // The att reads go through the asm path with an explicit wait per tile: left to the scheduler, all 2*NT*4
       // of them are hoisted above the stores, which -- next to 128 live accumulators -- spills them to scratch, and
       // every scratch reload then waits (vmcnt) for the stores in flight.
       static_assert(NC * 4 + 96 + 7 * 128 < 65536, "att offsets fit the ds_read immediate");
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) {
+      for (int t = 0; t < NT; ++t) {
         f32x4 s4[4], d4[4];
         s4[0] = lds_read4<0>(asl + t * 128); s4[1] = lds_read4<32>(asl + t * 128);
         s4[2] = lds_read4<64>(asl + t * 128); s4[3] = lds_read4<96>(asl + t * 128);
@@ -557,20 +633,30 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
         }
         asm volatile("" : "+v"(ps[t / TPH]), "+v"(pd[t / TPH]));   // the dots are due HERE (not sunk below the stores)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SP == 3) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<float4 *>(prow[k] + t * 32) =
-              *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
+          for (int k = 0; k < NSTORE; ++k) {            // 8 consecutive columns -> 8 bf16 = one 16-byte store
+            const float *pp = patch + (lane / LPR + (64 / LPR) * k) * TILED_PITCH + (lane % LPR) * 8;
+            const float4 lo = *reinterpret_cast<const float4 *>(pp), hi = *reinterpret_cast<const float4 *>(pp + 4);
+            const bf16x8 o = to_bf16x8((f32x4){lo.x, lo.y, lo.z, lo.w}, (f32x4){hi.x, hi.y, hi.z, hi.w});
+            *reinterpret_cast<bf16x8 *>(prow[k] + t * 64) = o;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NSTORE; ++k)
+            *reinterpret_cast<float4 *>(prow[k] + t * 128) =
+                *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * k) * TILED_PITCH + (lane & 7) * 4);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int hd = 0; hd < H2L; ++hd) {
+      for (int hd = 0; hd < H2; ++hd) {
         const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
         const float s_ = sl + __shfl_xor(sl, 32);
         const float d_ = dl + __shfl_xor(dl, 32);
         if (id >= 0 && hl == 0) {
-          a.asd_out[(int64_t)id * 2 * H2 + nh * H2L + hd] = s_;
-          a.asd_out[(int64_t)id * 2 * H2 + H2 + nh * H2L + hd] = d_;
+          a.asd_out[(int64_t)id * 2 * H2 + hd] = s_;
+          a.asd_out[(int64_t)id * 2 * H2 + H2 + hd] = d_;
         }
       }
     } else {
@@ -668,96 +754,103 @@ __global__ __launch_bounds__(256 * NS, (NT <= 3 ? 3 : 2) * NS) void gat_layer_fu
 #endif
 }
 
-template <int HC, int C, int K, int NT, int EPI, int NS = 1, int SP = 0>
+template <int HC, int C, int K, int NT, int EPI, int SP = 0>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
-  constexpr int H = HC / C;
-  constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI>::FLOATS * 4;
+  constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI, SP>::FLOATS * 4;
+  static_assert(lds_bytes <= 160 * 1024, "one workgroup fits the CU's LDS");
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
-  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, NS, SP>;
+  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, SP>;
   const size_t lds_launch = std::max(lds_bytes, (size_t)ctx->opts.fused_lds_pad_kb * 1024);   // (pad: occupancy experiment)
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)std::max(lds_launch, lds_bytes)));
     configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(kern, dim3(a.tb.n_blocks), dim3(256 * NS), lds_launch, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.tb.n_blocks), dim3(256), lds_launch, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;
 }
 
-static bool fused_supported(const bgnn_graph *g, int C) {
-  return g->kind == 0 && (g->K == 4 || g->K == 8) && g->n_blocks3 > 0 && C == 64 && g->max_w <= 8192;
+// stencil dispatch: K = 8 and 4 (reference connectivities) on every matrix path; K = 16 ("16-dilated") on the exact-f32
+// path (the parity instance, one workgroup per CU) and on the bf16 path (BASELINE config 3)
+template <int HC, int NT, int EPI>
+static int launch_by_stencil(bgnn_ctx *ctx, const bgnn_graph *g, int sp, const FusedArgs &a) {
+  switch (sp) {
+    case 0:
+      return g->K == 8 ? launch_inst<HC, 64, 8, NT, EPI, 0>(ctx, a) : g->K == 4 ? launch_inst<HC, 64, 4, NT, EPI, 0>(ctx, a)
+                                                                                 : launch_inst<HC, 64, 16, NT, EPI, 0>(ctx, a);
+    case 3:
+      return g->K == 8 ? launch_inst<HC, 64, 8, NT, EPI, 3>(ctx, a) : g->K == 4 ? launch_inst<HC, 64, 4, NT, EPI, 3>(ctx, a)
+                                                                                 : launch_inst<HC, 64, 16, NT, EPI, 3>(ctx, a);
+    default: break;
+  }
+  if (g->K == 16) return BGNN_ERR_UNSUPPORTED;
+  if (sp == 1) return g->K == 8 ? launch_inst<HC, 64, 8, NT, EPI, 1>(ctx, a) : launch_inst<HC, 64, 4, NT, EPI, 1>(ctx, a);
+  return g->K == 8 ? launch_inst<HC, 64, 8, NT, EPI, 2>(ctx, a) : launch_inst<HC, 64, 4, NT, EPI, 2>(ctx, a);
 }
 
-static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, int ED, const float *xw, const float *asd,
-                        int relu) {
+static bool fused_supported(const bgnn_graph *g, int C, int ED) {
+  return g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->n_blocks3 > 0 && C == 64 && ED == 3 && g->max_w <= 8192;
+}
+
+static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, const void *xw, const float *asd, int relu) {
   a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items3;
   a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
   a.node_id = g->d_node_id; a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
-  a.ED = ED; a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
+  a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
   a.dbg = BGNN_DIAG ? g->ctx->opts.diag_mask : 0;
   a.stamps = BGNN_DIAG && g->ctx->opts.diag_stamps ? g->ctx->stamps : nullptr;
 }
 
 // aggregate of layer L (width HC = L.heads*C) fused with the GEMM of the next layer `Ln`
 int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, int ED,
-                            const float *xw, const float *asd, float *xw_next, float *asd_next) {
-  if (!fused_supported(g, C)) return BGNN_ERR_UNSUPPORTED;
+                            const void *xw, const float *asd, void *xw_next, float *asd_next) {
+  if (!fused_supported(g, C, ED)) return BGNN_ERR_UNSUPPORTED;
   const int HC = L.heads * C, NC = Ln.heads * C;
   if (Ln.d_in != HC) return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
-  fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
-  int split = ctx->opts.matrix_path;                                   // opt-in bf16x3 / fp16x3 matrix path
+  fill_common(a, g, L, xw, asd, L.concat ? 1 : 0);
+  int split = ctx->opts.matrix_path;                                   // 0 exact, 1 bf16x3, 2 fp16x3 (opt-in), 3 bf16 storage
   if (split == 2 && !Ln.Wsp16) split = 1;                              // a weight beyond float16's range: bf16 split instead
-  a.Wt = split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wt; a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next;
-  a.asd_out = asd_next;
+  a.Wt = split == 3 ? Ln.Wbf : split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wt;
+  a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
   ProfScope ps(ctx, BGNN_K_FUSED);
-  if (split) {
-#define BGNN_FUSED_SP(hc, nt)                                                                           \
-    if (HC == hc && NC == nt * 32) {                                                                    \
-      if (split == 2)                                                                                   \
-        return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, 1, 2>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, 1, 2>(ctx, a); \
-      return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, 1, 1>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, 1, 1>(ctx, a);   \
-    }
-    BGNN_FUSED_SP(256, 8) BGNN_FUSED_SP(256, 2)
-#undef BGNN_FUSED_SP
-    a.Wt = Ln.Wt;                                                     // other shapes: exact-f32 instances only
-  }
-#define BGNN_FUSED_CASE(hc, nt, ns)                                                                     \
+  const bool main_shape = (HC == 256 && NC == 256) || (HC == 256 && NC == 64);
+  if (split == 3 && !main_shape) return BGNN_ERR_UNSUPPORTED;          // bf16 storage: the default model's shapes only
+  if ((split == 1 || split == 2) && (!main_shape || g->K == 16)) { split = 0; a.Wt = Ln.Wt; }   // other shapes: exact-f32 instances only
+#define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
+  BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
+#undef BGNN_FUSED_CASE
+  if (g->K == 16) return BGNN_ERR_UNSUPPORTED;
+#define BGNN_FUSED_CASE(hc, nt)                                                                         \
   if (HC == hc && NC == nt * 32)                                                                        \
-    return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT, ns>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT, ns>(ctx, a);
-  // Column split (16 waves per CU at 128 registers): correct, but hipcc spills inside the gather loop at that
-  // budget and every spill reload waits on the in-flight DMAs -- 1.5x slower than NS = 1 today.  Opt-in only.
-  const int ns_big = ctx->opts.fused_column_split ? 2 : 1;
-  if (ns_big == 2) { BGNN_FUSED_CASE(256, 8, 2) }
-  BGNN_FUSED_CASE(256, 8, 1) BGNN_FUSED_CASE(256, 2, 1) BGNN_FUSED_CASE(128, 4, 1) BGNN_FUSED_CASE(128, 2, 1) BGNN_FUSED_CASE(64, 2, 1)
+    return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT>(ctx, a);
+  BGNN_FUSED_CASE(128, 4) BGNN_FUSED_CASE(128, 2) BGNN_FUSED_CASE(64, 2)
 #undef BGNN_FUSED_CASE
   return BGNN_ERR_UNSUPPORTED;
 }
 
 // aggregate of the LAST layer (HC = C, one head) fused with the heads (+ grids)
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
-                             const float *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
+                             const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid) {
-  if (!fused_supported(g, C) || L.heads != 1 || m->desc.num_classes > 4 || m->head_hidden_total != 96 ||
+  if (!fused_supported(g, C, ED) || L.heads != 1 || m->desc.num_classes > 4 || m->head_hidden_total != 96 ||
       (m->desc.predict_correction ? 3 : 2) * (C / 2) > 96 || o->hidden)
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
-  fill_common(a, g, L, ED, xw, asd, L.concat ? 1 : 0);
+  fill_common(a, g, L, xw, asd, L.concat ? 1 : 0);
   int split = ctx->opts.matrix_path;
   if (split == 2 && !m->hd_W0sp16) split = 1;
-  a.Wt = split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0t; a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
+  if ((split == 1 || split == 2) && g->K == 16) split = 0;
+  a.Wt = split == 3 ? m->hd_W0bf : split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0t;
+  a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
   a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;
   a.thr_auto = thr_auto; a.thr_review = thr_review; a.norm_floor = norm_floor; a.o = *o;
   a.cls_grid = cls_grid; a.conf_grid = conf_grid; a.corr_grid = corr_grid;
   ProfScope ps(ctx, BGNN_K_FUSED);
-  if (split == 2)
-    return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS, 1, 2>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS, 1, 2>(ctx, a);
-  if (split == 1)
-    return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS, 1, 1>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS, 1, 1>(ctx, a);
-  return g->K == 8 ? launch_inst<64, 64, 8, 3, EPI_HEADS>(ctx, a) : launch_inst<64, 64, 4, 3, EPI_HEADS>(ctx, a);
+  return launch_by_stencil<64, 3, EPI_HEADS>(ctx, g, split, a);
 }
 
 }  // namespace bgnn

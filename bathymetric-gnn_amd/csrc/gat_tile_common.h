@@ -15,6 +15,11 @@ template <> struct StencilOffsets<8> {   // graph_construction.py:83-87
   static constexpr int dc[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 };
 
+template <> struct StencilOffsets<16> {  // "16-dilated" (BASELINE config 3's k = 16; not in the reference): the 8 base offsets, then the same x 2
+  static constexpr int dr[16] = {-1, -1, -1, 0, 0, 1, 1, 1, -2, -2, -2, 0, 0, 2, 2, 2};
+  static constexpr int dc[16] = {-1, 0, 1, -1, 1, -1, 0, 1, -2, 0, 2, -2, 2, -2, 0, 2};
+};
+
 constexpr int TILE_W = 16;                    // cell blocks are TH x 16 (TH = 16: tiled aggregate, TH = 8: fused layer)
 constexpr int HALO_W = TILE_W + 2;            // 18
 constexpr int TILED_PITCH = 36;               // dwords per staged 32-channel row slab (32 + 4 pad)
@@ -230,7 +235,7 @@ __device__ __forceinline__ void attention_coefficients_head(int my, int self_idx
 // attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
 // edge-attribute block, `ad` = its alpha_dst for head hh, `v` = V[hh][0..2].  Lets the caller issue those global loads before the
 // halo ids are known (one latency less on the workgroup's critical path).
-template <int H, int K>
+template <int H, int K, int HWID = HALO_W>
 __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, int hh, const int *hid, const float *has,
                                                                 const float (&eraw)[K * 3], float ad, const float (&v)[3],
                                                                 float *out) {
@@ -242,7 +247,7 @@ __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, in
   bool present[K];
 #pragma unroll
   for (int b = 0; b < K; ++b) {
-    const int nidx = self_idx - Off::dr[b] * HALO_W - Off::dc[b];
+    const int nidx = self_idx - Off::dr[b] * HWID - Off::dc[b];
     present[b] = hid[nidx] >= 0;
     float dot = 0.0f;
 #pragma unroll

@@ -231,20 +231,23 @@ __device__ __forceinline__ f32x16 mfma_lp(const f16x8 &a, const f16x8 &b, const 
 
 // SP (1 bf16x3, 2 fp16x3): operand-split matrix path (opt-in, see gat_layer_fused.hip): Wt is then the hi / lo split image of pack_split_bf16 and X
 // is split in registers; lane (r, h) owns k = 16 step + 8h + i of every 16-wide k-step.
+// SP = 3 (bf16 activation storage, BASELINE config 3): Wt is the hi-only bf16 image, X is rounded to bf16 in registers, one
+// MFMA per tile and 16 k, and Y is written as bf16 (the attention dots are taken from the f32 accumulators).
 template <int NT, bool ATT, int SP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   constexpr int NC = NT * 32, K = 64;
+  constexpr int WFLOATS = SP == 3 ? K * NC / 2 : K * NC;   // bytes of the weight image / 4
   extern __shared__ __attribute__((aligned(128))) float wres_lds[];
   float *wl = wres_lds;                              // [64][NC]
   constexpr int PP = 68;                              // patch pitch: two 32-column tiles side by side + 4 pad
-  float *patches = wl + K * NC;                      // [8][32 * PP]
+  float *patches = wl + WFLOATS;                     // [8][32 * PP]
   float *attl = patches + 8 * 32 * PP;               // [2][NC]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int NW = blockDim.x >> 6;                    // 8 (4 only in the occupancy experiment)
   {
     const char *src = reinterpret_cast<const char *>(a.Wt);
-    constexpr int NQ = K * NC * 4 / 1024;            // 1-KiB pieces
+    constexpr int NQ = WFLOATS * 4 / 1024;           // 1-KiB pieces
     for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
       const int q = j * NW + wave;
       if (q < NQ)
@@ -275,7 +278,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    if constexpr (SP != 0) {
+    if constexpr (SP == 3) {
+      if (!(BGNN_DIAG && (a.dbg & 2))) {
+#pragma unroll
+        for (int st = 0; st < K / 16; ++st) {
+          const float v[8] = {ax[2 * st].x, ax[2 * st].y, ax[2 * st].z, ax[2 * st].w,
+                              ax[2 * st + 1].x, ax[2 * st + 1].y, ax[2 * st + 1].z, ax[2 * st + 1].w};
+          bf16x8 xh;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xh[i] = (__bf16)v[i];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {               // half-chunk st: tile t at (st * NT + t) KiB of the hi-only image
+            const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + (st * NT + t) * 1024 + lane * 16);
+            acc[t] = mfma_lp(wh, xh, acc[t]);
+          }
+        }
+      }
+    } else if constexpr (SP != 0) {
       using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
       using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
       if (!(BGNN_DIAG && (a.dbg & 2))) {
@@ -314,11 +333,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     // stores leave as 256-byte row segments (two tiles side by side in the patch): 16 lanes x 16 B per row, 4 rows per
     // instruction -- half as many separate DRAM bursts per 1-KiB output row as 128-byte segments
     static_assert(NT % 2 == 0, "tiles are stored in pairs");
-    float *dst[8];
+    constexpr int YB = SP == 3 ? 2 : 4;              // bytes per stored output element
+    char *dst[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int64_t rr = row0 + (lane >> 4) + 4 * k;
-      dst[k] = (rr < M ? a.Y + rr * a.ldy : a.dump) + (lane & 15) * 4;
+      dst[k] = (rr < M ? reinterpret_cast<char *>(a.Y) + rr * a.ldy * YB : reinterpret_cast<char *>(a.dump)) + (lane & 15) * 4 * YB;
     }
     float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
 #pragma unroll
@@ -362,9 +382,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if ((t & 1) && !(BGNN_DIAG && (a.dbg & 1))) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          *reinterpret_cast<float4 *>(dst[k] + (t - 1) * 32) =
-              *reinterpret_cast<const float4 *>(patch + ((lane >> 4) + 4 * k) * PP + (lane & 15) * 4);
+        for (int k = 0; k < 8; ++k) {
+          const float4 v4 = *reinterpret_cast<const float4 *>(patch + ((lane >> 4) + 4 * k) * PP + (lane & 15) * 4);
+          if constexpr (SP == 3) {                       // 4 columns -> 4 bf16 = one 8-byte store
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o;
+            o[0] = (__bf16)v4.x; o[1] = (__bf16)v4.y; o[2] = (__bf16)v4.z; o[3] = (__bf16)v4.w;
+            *reinterpret_cast<bf16x4 *>(dst[k] + (t - 1) * 32 * YB) = o;
+          } else {
+            *reinterpret_cast<float4 *>(dst[k] + (t - 1) * 32 * YB) = v4;
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -389,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 
 template <int NT, bool ATT, int SP = 0>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
-  constexpr size_t lds_bytes = (size_t)(64 * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
+  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
   auto kern = gemm_wres64_kernel<NT, ATT, SP>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
@@ -403,6 +431,7 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
   return BGNN_OK;
 }
 
+// (split_mode 3: Y receives bf16 [M][ldy], see gemm_wres64_kernel)
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
                     const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode) {
@@ -416,11 +445,12 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   const bool no_wres = ctx->opts.gemm_no_wres != 0;
   // the split image is only read by the W-resident ATT form (NC 64 or 256); with a split path switched on that form runs
   // at EVERY batch size, so that a node's result does not depend on how many other nodes share its batch
-  if (!(K == 64 && !no_wres && att_src && (NC == 64 || NC == 256))) Wt_split = nullptr;
-  if (K == 64 && !no_wres && (max_rows >= 65536 || Wt_split)) {    // W-resident persistent form
+  if (split_mode == 3) BGNN_REQUIRE(K == 64 && att_src && (NC == 64 || NC == 256) && Wt_split, "gemm: bf16 output needs the W-resident form");
+  if (!(K == 64 && (!no_wres || split_mode == 3) && att_src && (NC == 64 || NC == 256))) Wt_split = nullptr;
+  if (K == 64 && (!no_wres || split_mode == 3) && (max_rows >= 65536 || Wt_split)) {    // W-resident persistent form
     switch (NC / 32) {
 #define BGNN_WRES_CASE(NT) case NT:                                                                                 \
-        if (Wt_split) { a.Wt = Wt_split; return split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \
+        if (Wt_split) { a.Wt = Wt_split; return split_mode == 3 ? launch_wres64<NT, true, 3>(ctx, a) : split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \
         return att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
       BGNN_WRES_CASE(2) BGNN_WRES_CASE(8)
 #undef BGNN_WRES_CASE

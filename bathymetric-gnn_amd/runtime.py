@@ -27,7 +27,7 @@ EF_ZERO = 3
 
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4
 ABI_VERSION = 4
-MATRIX_PATHS = {"exact_f32": 0, "bf16x3": 1, "fp16x3": 2}
+MATRIX_PATHS = {"exact_f32": 0, "bf16x3": 1, "fp16x3": 2, "bf16": 3}
 
 
 GNN_TYPES = {"GAT": 0, "GCN": 1, "GraphSAGE": 2, "GIN": 3}      # BGNN_GNN_*

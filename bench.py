@@ -33,8 +33,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA (= vector fp32 peak)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3):
-    """SURVEY.md 8(d) per-node figures (fp32, compulsory traffic: each tensor read once + written once)."""
+def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3, act_bytes=4):
+    """SURVEY.md 8(d) per-node figures (compulsory traffic: each tensor read once + written once).  ``act_bytes``: bytes per
+    stored layer activation (4 = fp32, the reference's dtype; 2 = bf16 storage of BASELINE config 3).  ``fused_bytes``
+    prices the fused launches (xW in / next xW out at ``act_bytes``; attention dots and edge attributes stay f32)."""
     agg_bytes = 0
     gemm_flops = 2 * (in_ch * hidden)                              # feature extractor layer 1 (layer 2 is folded into lin_0: executed flops)
     gemm_bytes = 4 * (8 + hidden) + 4 * (hidden + hidden)
@@ -65,15 +67,15 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
             Hn = 1 if l + 1 == num_layers - 1 else heads
             nc = Hn * hidden
             fused_flops += 2 * hc * nc
-            fused_bytes += 4 * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * nc + 4 * 2 * Hn
+            fused_bytes += act_bytes * hc + 4 * 2 * H + 4 * deg * edge_dim + act_bytes * nc + 4 * 2 * Hn
         else:
             fused_flops += 2 * hidden * nh * (hidden // 2)
-            fused_bytes += 4 * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * 3
+            fused_bytes += act_bytes * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * 3
     return {"aggregate_bytes": agg_bytes, "gemm_flops": gemm_flops, "gemm_bytes": gemm_bytes, "build_bytes": build_bytes,
             "fused_flops": fused_flops, "fused_bytes": fused_bytes, "front_flops": front_flops}
 
 
-def cpu_baseline(n_tiles, tile, sd, seed0):
+def cpu_baseline(n_tiles, tile, sd, seed0, connectivity="8-connected"):
     """The CPU oracle (vectorised numpy graph build + fp32 torch forward issuing torch_geometric's op
     sequence + scatter) on `n_tiles` tiles of the same workload.  kind = "port"."""
     from bathymetric_gnn_amd import synthetic
@@ -85,15 +87,16 @@ def cpu_baseline(n_tiles, tile, sd, seed0):
     nodes = 0
     t0 = time.perf_counter()
     tg = 0.0
+    k = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}[connectivity]
     for d, m, _ in tiles:
         a = time.perf_counter()
-        g = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+        g = graph_cpu.build_graph(d, m, None, (0.5, 0.5), connectivity=connectivity)
         tg += time.perf_counter() - a
         gat_cpu.process_tile(sd, g)
         nodes += g.num_nodes
     dt = time.perf_counter() - t0
     return {"value": nodes / dt, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_tiles} tiles of {tile}x{tile} (k=8, 4-layer GAT, fp32): numpy graph build + torch CPU forward "
+            "sample": f"{n_tiles} tiles of {tile}x{tile} (k={k}, 4-layer GAT, fp32): numpy graph build + torch CPU forward "
                       f"+ scatter, {dt:.1f} s wall ({tg:.1f} s of it graph build); os.cpu_count()={os.cpu_count()}"}
 
 
@@ -158,9 +161,13 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="run K3 / K4 / K5 / K6 as separate kernels (standalone gather-aggregate roofline)")
     ap.add_argument("--cpu-tiles", type=int, default=4)
-    ap.add_argument("--workload", default="tiles", choices=["tiles", "vr"],
+    ap.add_argument("--workload", default="tiles", choices=["tiles", "vr", "c3"],
                     help="tiles: B uniform tiles per step (headline). vr: BASELINE config 4 -- a stream of 4096 ragged "
-                         "refinement grids (3x3..50x50, in=8) packed by the reference's 50 000-node batch budget")
+                         "refinement grids (3x3..50x50, in=8) packed by the reference's 50 000-node batch budget. "
+                         "c3: BASELINE configs[2] -- B tiles of 256x256 with k=16 (the '16-dilated' stencil, a build-side "
+                         "extension) and bf16 node features (layer activations stored as bf16, bf16 MFMA, f32 accumulate)")
+    ap.add_argument("--connectivity", default=None, choices=["4-connected", "8-connected", "16-dilated"])
+    ap.add_argument("--bf16", action="store_true", help="matrix_path = bf16 (bf16 activation storage + bf16 MFMA)")
     ap.add_argument("--vr-grids", type=int, default=4096)
     ap.add_argument("--vr-budget", type=int, default=50000)
     args = ap.parse_args()
@@ -193,15 +200,21 @@ def main():
     model = BathymetricGNN(in_channels=in_ch, num_gnn_layers=args.layers, edge_dim=3, dropout=0.0)
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     model.to(dev).eval()
-    gb = GraphBuilder(device=dev)
+    c3 = args.workload == "c3"
+    conn = args.connectivity or ("16-dilated" if c3 else "8-connected")
+    deg = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}[conn]
+    if c3:
+        args.workload, args.bf16 = "tiles", True
+    gb = GraphBuilder(connectivity=conn, device=dev)
     eng = TileBatchEngine(model, gb, dev)
     ctx = eng.ctx
     # run-time switches of the library context (the environment is only read when a context is created)
     if args.unfused:
         ctx.set_option("fused", 0)
-    if args.split_f16 or args.split_bf16:
-        ctx.set_option("matrix_path", "fp16x3" if args.split_f16 else "bf16x3")
-    split_main = {0: None, 1: "bf16x3", 2: "fp16x3"}[ctx.get_option("matrix_path")]
+    if args.split_f16 or args.split_bf16 or args.bf16:
+        ctx.set_option("matrix_path", "bf16" if args.bf16 else "fp16x3" if args.split_f16 else "bf16x3")
+    split_main = {0: None, 1: "bf16x3", 2: "fp16x3", 3: "bf16"}[ctx.get_option("matrix_path")]
+    bf16 = split_main == "bf16"
     unfused = not ctx.get_option("fused")
     nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
 
@@ -216,8 +229,9 @@ def main():
         hw = np.tile(np.array([[S, S]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
         out = torch.empty((3, d_t.numel()), dtype=torch.float32, device=dev)
         nodes_per_step = int(mask.sum())
-        workload_name = (f"{B} tiles of {S}x{S} per GPU per step, 8-connected (k=8), {args.layers}-layer GAT "
-                         f"(hidden 64, heads 4), mask {args.variant}, inputs resident in HBM")
+        workload_name = (f"{B} tiles of {S}x{S} per GPU per step, {conn} (k={deg}), {args.layers}-layer GAT "
+                         f"(hidden 64, heads 4), mask {args.variant}, inputs resident in HBM"
+                         + (", layer activations stored as bf16 (bf16 MFMA, f32 softmax / aggregation / accumulation)" if bf16 else ""))
 
         def step():
             eng.infer_device(hw, res, d_t, m_t, None, out=out, n_nodes_out=nn_dev)
@@ -267,7 +281,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        am = algorithmic_model(num_layers=args.layers)
+        am = algorithmic_model(num_layers=args.layers, deg=deg, act_bytes=2 if bf16 else 4)
         nodes_total = nodes_per_step * args.steps * world
         value = nodes_total / elapsed
         kernels = {}
@@ -289,7 +303,10 @@ def main():
                     "algorithmic_work_per_node_per_forward": work_per_node, "traffic": None, "note": note}
         roofs = {}
         if prof["fused"]["launches"]:
-            if split_main:
+            if bf16:
+                roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", am["fused_flops"],
+                                           "bf16 MFMA, f32 accumulate: priced against the dense bf16 MFMA peak (the kernel is not matrix-bound)")
+            elif split_main:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", 3 * am["fused_flops"],
                                            f"{split_main}: executed flops = 3 x algorithmic, priced against the dense bf16 / f16 MFMA peak")
             else:
@@ -306,7 +323,7 @@ def main():
         # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach if present
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         # (the counters were collected on the default workload only: 128 tiles of 256 x 256, 4 layers)
-        if os.path.exists(pmc) and args.workload == "tiles" and (B, S, args.layers) == (128, 256, 4):
+        if os.path.exists(pmc) and args.workload == "tiles" and (B, S, args.layers, deg) == (128, 256, 4, 8) and not bf16:
             try:
                 t = json.load(open(pmc))
                 for v in roofs.values():
@@ -325,7 +342,10 @@ def main():
             "metric": "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": f"f32 ({split_main} split-operand MFMA, f32 accumulate)" if split_main else "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("bf16 (layer activations stored as bf16, bf16 MFMA; f32 softmax / aggregation / accumulation / outputs)" if bf16
+                      else f"f32 ({split_main} split-operand MFMA, f32 accumulate)" if split_main else "f32"),
+            "data": "synthetic",
             "config": {"workload": workload_name,
                        "tiles_per_gpu": B if args.workload == "tiles" else args.vr_grids, "tile": S if args.workload == "tiles" else "3..50",
                        "nodes_per_step_per_gpu": nodes_per_step,
@@ -333,7 +353,7 @@ def main():
             "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                        "kernel", "avg_launch_ms")},
             "rooflines": roofs, "kernels": kernels, "path": "unfused" if unfused else "fused",
-            "matrix_path": f"{split_main} split (opt-in)" if split_main else "exact f32",
+            "matrix_path": "bf16 storage + bf16 MFMA (BASELINE configs[2])" if bf16 else f"{split_main} split (opt-in)" if split_main else "exact f32",
         }
         if world == 1 and args.workload == "tiles" and not unfused:
             # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
@@ -395,7 +415,7 @@ def main():
             line["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
                                    "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
-            line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100, conn)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if dist is not None:

@@ -55,10 +55,12 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
 
 /* Run-time switches of a context (all int-valued).  Defaults are taken from the environment ONCE, when the context is
  * created (the variable in brackets); afterwards only this call changes them:
- *   "matrix_path"     0 exact f32 (default), 1 bf16x3, 2 fp16x3: opt-in operand-split MFMA paths [BGNN_SPLIT_BF16 / BGNN_SPLIT_F16]
+ *   "matrix_path"     0 exact f32 (default), 1 bf16x3, 2 fp16x3: opt-in operand-split MFMA paths [BGNN_SPLIT_BF16 / BGNN_SPLIT_F16];
+ *                     3 bf16: layer activations stored as bf16 in HBM and multiplied on the bf16 MFMA, float32 softmax /
+ *                     aggregation / accumulation (BASELINE config 3 "bf16 node features"; no 1e-4 contract) [BGNN_BF16]
  *   "fused"           1 (default): K4 fused with the next K3 / K5 + K6; 0: separate kernels           [BGNN_NO_FUSED]
  *   "fold_extractor"  1 (default): extractor layer 2 folded into lin of GAT layer 0; 0: unfolded chain [BGNN_NO_FOLD]
- * plus experiment / diagnostic knobs ("fused_column_split", "fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",
+ * plus experiment / diagnostic knobs ("fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",
  * "diag_stamps", "gemm_diag" exist only in the diagnostic build of the library).  Unknown names -> BGNN_ERR_INVALID. */
 int bgnn_ctx_set_option(bgnn_ctx *ctx, const char *name, int value);
 int bgnn_ctx_get_option(bgnn_ctx *ctx, const char *name, int *value);

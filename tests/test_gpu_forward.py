@@ -601,3 +601,127 @@ def test_training_mode_refusals(gpu_device):
     g0 = GraphBuilder().build_graph(np.full((4, 4), 1.0e6, np.float32), np.zeros((4, 4), bool), None, (1.0, 1.0))
     assert m(g0)["class_logits"].shape == (0, 3)                                 # an empty batch passes through
     assert int(m.gnn.norms[0].module.num_batches_tracked) == int(np.asarray(sd["gnn.norms.0.module.num_batches_tracked"]))
+
+
+# ---- BASELINE configs[2]: k = 16 ("16-dilated" stencil) and bf16 node features -------------------------------------------
+# Neither exists in the reference (config/config.py:221-222 validates 4 / 8-connected only; everything is float32), so there
+# is no reference-held vector: edge_index / features are checked against the oracle's identical extension, the forward
+# against the oracle's float64 forward.  bf16 storage has NO 1e-4 contract: the achieved error is printed and bounded.
+BF16_LOGIT_BOUND = 3e-2        # absolute, on |logit| <= ~0.4 (calibrated heads); observed values are printed by the test
+
+
+def _fp64_distance(out, ref64):
+    e = (out["class_logits"].double().cpu() - ref64["class_logits"]).abs()
+    return float(e.max()), float((e ** 2).mean().sqrt())
+
+
+def test_config3_k16_exact_f32_fused_instance(gpu_device):
+    """k = 16 through the FUSED layer kernels (halo of two cells) on the exact-f32 path: the 1e-4 bar still holds against
+    the oracle's extension (the test above this section covers a small ragged tile; this one a batch of full tiles)."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    tiles = [synthetic.synthetic_tile(96, 80, 40 + i, v) for i, v in enumerate(["V1", "V0"])]
+    ogs = [graph_cpu.build_graph(d, m, None, (0.5, 0.5), connectivity="16-dilated") for d, m, _ in tiles]
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), ogs[0].x, ogs[0].edge_index, ogs[0].edge_attr)
+    model = _model(sd)
+    gb = GraphBuilder(connectivity="16-dilated")
+    assert rt.get_context(gpu_device).get_option("matrix_path") == 0
+    for (d, m, _), og in zip(tiles, ogs):
+        g = gb.build_graph(d, m, None, (0.5, 0.5))
+        assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
+        _compare(model.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
+    res = TileBatchEngine(model, gb, gpu_device).infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 2)
+    for r, og in zip(res, ogs):
+        ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
+        assert np.abs(r["confidence"] - ref["confidence"]).max() < TOL and np.abs(r["correction"] - ref["correction"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("conn", ["16-dilated", "8-connected"])
+def test_config3_bf16_storage_distance_to_float64(conn, gpu_device):
+    """configs[2]: 256 x 256 tile, k = 16, layer activations stored as bf16 (matrix_path = bf16).  Reports and bounds the
+    distance of the class logits to the oracle's float64 forward, next to the exact-f32 path's; the predicted class must
+    agree with the float64 forward on nearly every node that has a clear winner."""
+    import json
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(256, 256, 1, "V1")
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5), connectivity=conn)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
+    model = _model(sd)
+    g = GraphBuilder(connectivity=conn).build_graph(d, m, None, (0.5, 0.5))
+    assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)                 # (i) bit-equal edge list
+    ref64 = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr, dtype=torch.float64)
+    _set_matrix_path("exact_f32")
+    exact = model.predict(g)
+    _set_matrix_path("bf16")
+    out = model.predict(g)
+    out2 = model.predict(g)
+    assert torch.equal(out["class_logits"], out2["class_logits"])                    # deterministic
+    e_exact, e_bf16 = _fp64_distance(exact, ref64), _fp64_distance(out, ref64)
+    conf_err = float((out["confidence"].double().cpu() - ref64["confidence"]).abs().max())
+    top2 = torch.topk(ref64["class_probs"], 2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.02
+    agree = float((out["predicted_class"].cpu()[clear] == ref64["predicted_class"][clear]).double().mean())
+    row = {"connectivity": conn, "nodes": int(og.x.shape[0]), "logit_abs_max": float(ref64["class_logits"].abs().max()),
+           "exact_f32": {"max": e_exact[0], "rms": e_exact[1]}, "bf16_storage": {"max": e_bf16[0], "rms": e_bf16[1]},
+           "bf16_confidence_max_err": conf_err, "class_agreement_on_clear_nodes": agree, "clear_fraction": float(clear.double().mean())}
+    print("config3", json.dumps(row))
+    assert e_exact[0] < TOL
+    assert e_bf16[0] < BF16_LOGIT_BOUND and e_bf16[1] < BF16_LOGIT_BOUND / 4, row
+    assert agree > 0.98, row
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):
+        json.dump(row, open(os.path.join(out_dir, f"config3_accuracy_{conn}.json"), "w"), indent=1)
+
+
+def test_config3_bf16_batch_properties(gpu_device):
+    """bf16 storage through the per-batch entry: tiles of a batch are independent (permuting them permutes the outputs bit
+    for bit), invalid cells are exactly 0, the grids equal predict()'s per-node results, and the node count is right."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    model = _model(synthetic.synthetic_state_dict(seed=1234))
+    gb = GraphBuilder(connectivity="16-dilated")
+    eng = TileBatchEngine(model, gb, gpu_device)
+    B, n = 6, 128
+    depth, mask, _ = synthetic.synthetic_tile_batch(B, n, n, 300, "V1")
+    hw = np.tile(np.array([[n, n]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
+    up = lambda dd, mm: (torch.from_numpy(dd).cuda().reshape(-1), torch.from_numpy(mm.view(np.uint8)).cuda().reshape(-1))
+    _set_matrix_path("bf16")
+    nn = torch.zeros(1, dtype=torch.int64, device="cuda")
+    out = eng.infer_device(hw, res, *up(depth, mask), None, n_nodes_out=nn).clone()
+    assert int(nn.item()) == int(mask.sum())
+    perm = np.random.default_rng(1).permutation(B)
+    out_p = eng.infer_device(hw, res, *up(depth[perm], mask[perm]), None)
+    assert torch.equal(out.reshape(3, B, n * n)[:, perm], out_p.reshape(3, B, n * n))
+    inval = ~torch.from_numpy(mask).cuda().reshape(-1)
+    assert float(out[:, inval].abs().max()) == 0.0
+    o = model.predict(gb.build_graphs(list(depth), list(mask), None, [(0.5, 0.5)] * B))
+    assert torch.equal(out[0][~inval], o["predicted_class"].float()) and torch.equal(out[1][~inval], o["confidence"])
+    assert (o["class_probs"].sum(-1) - 1).abs().max().item() < 1e-5
+    # ragged batches take the same kernels through the block table
+    tiles = [synthetic.synthetic_tile(h, w, 80 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (64, 64)])]
+    r_bf = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 1.0)] * 3)
+    _set_matrix_path("exact_f32")
+    r_ex = eng.infer([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 1.0)] * 3)
+    for a, b in zip(r_bf, r_ex):
+        assert np.abs(a["confidence"] - b["confidence"]).max() < 2e-2 and a["confidence"].shape == b["confidence"].shape
+
+
+def test_bf16_storage_refuses_what_it_does_not_cover(gpu_device):
+    """matrix_path = bf16 exists on the fused stencil path of the default model shape only: anything else fails loudly
+    instead of silently running another precision."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import Data, GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(24, 24, 3, "V1")
+    g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
+    _set_matrix_path("bf16")
+    small = _model(synthetic.synthetic_state_dict(hidden=32, seed=5), hidden=32)
+    with pytest.raises(ValueError, match="bf16"):
+        small.predict(g)
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    model = _model(synthetic.synthetic_state_dict(seed=5))
+    with pytest.raises(ValueError, match="bf16"):
+        model.predict(Data(x=torch.from_numpy(og.x), edge_index=torch.from_numpy(og.edge_index), edge_attr=torch.from_numpy(og.edge_attr)))
+    assert model.predict(g)["class_logits"].shape == (int(m.sum()), 3)
