@@ -676,6 +676,9 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
     g->F = nf;
   }
   int64_t cells = 0;
+  int64_t cells_est = 0;
+  for (int t = 0; t < tiles->n_tiles; ++t) cells_est += (int64_t)tiles->hw[2 * t] * tiles->hw[2 * t + 1];
+  const int item_cells = (int)std::min<int64_t>(2048, std::max<int64_t>(256, cells_est / (4 * ctx->num_cus)));
   std::vector<BgnnWorkItem> items, items2, items3;
   bool uniform = true;
   g->h_tiles.resize(tiles->n_tiles);
@@ -693,7 +696,9 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
     m.rx = tiles->resolution[2 * t]; m.ry = tiles->resolution[2 * t + 1];
     cells += (int64_t)h * w;
     if (cells >= ((int64_t)1 << 30)) { delete g; set_error("batch too large: 2^30 cells or more; split it"); return BGNN_ERR_INVALID; }
-    int rows_per = std::max(1, 2048 / w);
+    // row bands of the feature kernel: ~2048 cells each for big batches, down to one 256-thread pass (256 cells) when the
+    // batch is small, so that a single tile still spreads over the whole chip
+    int rows_per = std::max(1, item_cells / w);
     for (int r0 = 0; r0 < h; r0 += rows_per) items.push_back({t, r0, std::min(rows_per, h - r0), 0});
     if (h != tiles->hw[0] || w != tiles->hw[1]) uniform = false;
     if (w > g->max_w) g->max_w = w;
