@@ -211,7 +211,7 @@ class BathymetricGNN(nn.Module):
         self.classification_head = ClassificationHead(hidden_channels, hidden_channels // 2, num_classes, dropout)
         self.confidence_head = ConfidenceHead(hidden_channels, hidden_channels // 2, dropout)
         self.correction_head = CorrectionHead(hidden_channels, hidden_channels // 2, dropout) if predict_correction else None
-        self._native = None          # (ctx, handle)
+        self._native = {}            # id(ctx) -> (ctx, handle)
         self._native_key = None
         for sub in (self.feature_extractor, self.classification_head, self.confidence_head, self.correction_head):
             if sub is not None:
@@ -256,18 +256,21 @@ class BathymetricGNN(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _drop_native(self):
-        if self._native is not None:
-            ctx, h = self._native
+        for ctx, h in (self._native or {}).values():
             try:
                 ctx.lib.bgnn_model_destroy(h)
             except Exception:
                 pass
-        self._native, self._native_key = None, None
+        self._native, self._native_key = {}, None
 
     def native(self, ctx: rt.Context):
-        key = (ctx.device.index, self._weights_version())
+        """The packed model on ``ctx`` (one per library context; rebuilt when a weight changes)."""
+        key = self._weights_version()
         if self._native is None or self._native_key != key:
             self._drop_native()
+            self._native_key = key
+        ent = self._native.get(id(ctx))
+        if ent is None:
             blob = self.pack_weights()
             desc = self._desc()
             n = ctx.lib.bgnn_model_weight_count(C.byref(desc))
@@ -276,8 +279,8 @@ class BathymetricGNN(nn.Module):
             h = C.c_void_p()
             rt.check(ctx.lib.bgnn_model_create(ctx.handle, C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)),
                                                blob.size, C.byref(h)))
-            self._native, self._native_key = (ctx, h), key
-        return self._native[1]
+            ent = self._native[id(ctx)] = (ctx, h)
+        return ent[1]
 
     def __del__(self):
         try:

@@ -112,20 +112,23 @@ class TileBatchEngine:
 
     def __init__(self, model: BathymetricGNN, graph_builder: GraphBuilder, device=None,
                  auto_correct_threshold: float = 0.85, review_threshold: float = 0.6,
-                 norm_floor: float = CORRECTION_NORM_FLOOR):
+                 norm_floor: float = CORRECTION_NORM_FLOOR, ctx: Optional[rt.Context] = None):
         self.model = model
         self.graph_builder = graph_builder
-        self.ctx = rt.get_context(device if device is not None else graph_builder._device)
+        # ``ctx``: an extra library context (``rt.new_context``) -- engines on different contexts overlap their batches
+        self.ctx = ctx if ctx is not None else rt.get_context(device if device is not None else graph_builder._device)
         self.auto_correct_threshold = auto_correct_threshold
         self.review_threshold = review_threshold
         self.norm_floor = norm_floor
 
     def infer_device(self, hw: np.ndarray, res: np.ndarray, depth_t: torch.Tensor, mask_t: torch.Tensor,
                      unc_t: Optional[torch.Tensor], out=None,
-                     n_nodes_out: Optional[torch.Tensor] = None):
+                     n_nodes_out: Optional[torch.Tensor] = None, defer_end: bool = False):
         """Device-resident tiles in, device-resident grids out: returns float32 [3, cells]
         (classification, confidence, correction), same cell layout as ``depth_t``.  Asynchronous
-        with respect to the host."""
+        with respect to the host.  ``defer_end``: do not order the caller's torch stream behind this batch yet (the
+        caller calls ``engine.ctx.end()`` before it reads ``out``): batches given to engines on different contexts
+        then run concurrently."""
         ctx = self.ctx
         cells = depth_t.numel()
         if out is None:
@@ -139,7 +142,8 @@ class TileBatchEngine:
             ctx.handle, model_h, C.byref(tiles), C.byref(self.graph_builder._opts),
             C.c_float(self.auto_correct_threshold), C.c_float(self.review_threshold), C.c_float(self.norm_floor),
             rt.ptr(out[0]), rt.ptr(out[1]), rt.ptr(out[2]), rt.ptr(n_nodes_out)))
-        ctx.end()
+        if not defer_end:
+            ctx.end()
         return out
 
     def infer(self, depths: Sequence[np.ndarray], masks: Sequence[Optional[np.ndarray]],

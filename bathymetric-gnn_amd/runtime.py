@@ -248,6 +248,13 @@ def get_context(device=None) -> Context:
         return ctx
 
 
+def new_context(device=None) -> Context:
+    """An ADDITIONAL library context on ``device`` (own HIP stream, own arenas): batches submitted to different contexts
+    overlap on the GPU -- the tail of one small batch's kernels runs beside the head of the next one's.  The caller keeps
+    it alive; ``get_context`` keeps returning the device's default context."""
+    return Context(resolve_device(device))
+
+
 def make_graph_opts(connectivity: str, include_self_loops: bool, node_features, edge_features) -> GraphOpts:
     conn = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}.get(connectivity)
     if conn is None:

@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="matrix_path = bf16 (bf16 activation storage + bf16 MFMA)")
     ap.add_argument("--vr-grids", type=int, default=4096)
     ap.add_argument("--vr-budget", type=int, default=50000)
+    ap.add_argument("--vr-streams", type=int, default=4,
+                    help="vr workload: library contexts (HIP streams) the batches are dealt over: the tail of one 50 000-node "
+                         "batch's kernels overlaps the head of the next one's")
     args = ap.parse_args()
 
     # N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (device_count() does not
@@ -251,11 +254,19 @@ def main():
             hw_b, res_b, d_b, m_b, u_b = gb.upload_tiles([x[0] for x in b], [x[1] for x in b], [x[2] for x in b], [x[3] for x in b])
             dev_batches.append((hw_b, res_b, d_b, m_b, u_b, torch.empty((3, d_b.numel()), dtype=torch.float32, device=dev)))
         workload_name = (f"{args.vr_grids} ragged refinement grids (3x3..50x50, in=8) per GPU per step in {len(batches)} batches "
-                         f"of >= {args.vr_budget} nodes, 8-connected, {args.layers}-layer GAT, inputs resident in HBM")
+                         f"of >= {args.vr_budget} nodes dealt over {max(1, args.vr_streams)} HIP stream(s), 8-connected, {args.layers}-layer GAT, "
+                         f"inputs resident in HBM")
+
+        engines = [eng] + [TileBatchEngine(model, gb, dev, ctx=rt.new_context(dev)) for _ in range(max(1, args.vr_streams) - 1)]
+        for e in engines[1:]:
+            for k in ("fused", "matrix_path"):
+                e.ctx.set_option(k, ctx.get_option(k))
 
         def step():
-            for hw_b, res_b, d_b, m_b, u_b, o_b in dev_batches:
-                eng.infer_device(hw_b, res_b, d_b, m_b, u_b, out=o_b)
+            for i, (hw_b, res_b, d_b, m_b, u_b, o_b) in enumerate(dev_batches):
+                engines[i % len(engines)].infer_device(hw_b, res_b, d_b, m_b, u_b, out=o_b, defer_end=True)
+            for e in engines:
+                e.ctx.end()
 
     def barrier():
         if dist is not None:
@@ -265,14 +276,19 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profile(rt.K_NAMES)                                  # HIP events around every kernel class
+    all_ctx = [ctx] + ([e.ctx for e in engines[1:]] if args.workload == "vr" else [])
+    for c in all_ctx:
+        c.profile(rt.K_NAMES)                                # HIP events around every kernel class
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    ctx.profile([])
+    prof = {k: {"ms": 0.0, "launches": 0} for k in rt.K_NAMES}
+    for c in all_ctx:
+        for k, v in c.profile_read().items():
+            prof[k]["ms"] += v["ms"]; prof[k]["launches"] += v["launches"]
+        c.profile([])
     if args.workload == "tiles":
         assert int(nn_dev.item()) == nodes_per_step
     if dist is not None:

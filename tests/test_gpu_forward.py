@@ -725,3 +725,31 @@ def test_bf16_storage_refuses_what_it_does_not_cover(gpu_device):
     with pytest.raises(ValueError, match="bf16"):
         model.predict(Data(x=torch.from_numpy(og.x), edge_index=torch.from_numpy(og.edge_index), edge_attr=torch.from_numpy(og.edge_attr)))
     assert model.predict(g)["class_logits"].shape == (int(m.sum()), 3)
+
+
+def test_batches_dealt_over_two_contexts_give_the_same_grids(gpu_device):
+    """Small ragged batches dealt round-robin over two library contexts (two HIP streams; bench.py --workload vr) overlap on
+    the GPU; every batch's grids must equal the ones the default context produces alone, bit for bit."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    model = _model(synthetic.synthetic_state_dict(in_channels=8, seed=1234), in_channels=8)
+    gb = GraphBuilder(device=gpu_device)
+    eng0 = TileBatchEngine(model, gb, gpu_device)
+    engines = [eng0, TileBatchEngine(model, gb, gpu_device, ctx=rt.new_context(gpu_device))]
+    assert engines[1].ctx is not eng0.ctx and engines[1].ctx.stream != eng0.ctx.stream
+    grids = synthetic.vr_grid_stream(90, seed0=7000)
+    batches = []
+    for i in range(0, len(grids), 15):
+        b = grids[i:i + 15]
+        masks = [(d != 1.0e6) & np.isfinite(d) for d, _, _ in b]
+        batches.append(gb.upload_tiles([x[0] for x in b], masks, [x[1] for x in b], [x[2] for x in b]))
+    ref = [eng0.infer_device(hw, res, d, m, u).clone() for hw, res, d, m, u in batches]
+    torch.cuda.synchronize()
+    for _ in range(3):                                   # a few rounds: arenas of both contexts get reused
+        outs = [engines[i % 2].infer_device(hw, res, d, m, u, defer_end=True) for i, (hw, res, d, m, u) in enumerate(batches)]
+        for e in engines:
+            e.ctx.end()
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
