@@ -35,18 +35,76 @@ def shard_info():
 
 
 def exchange_tile_results(mine: dict) -> dict:
-    """Union of every rank's {tile index: result dict}.  One object all-gather per survey; the data path
-    itself (graph build, forward, scatter) has no collective."""
+    """Union of every rank's {tile index: result dict} for the host-stitch path (every rank merges, so every rank needs
+    every tile).  The grids travel as ONE float32 tensor per rank (``all_gather`` of [count, channels, h, w] blocks padded
+    to the largest count; the tile indices as an int64 tensor) -- no pickling.  The data path itself (graph build,
+    forward, scatter) has no collective.  For large surveys use the device path (row bands + halo rows), which moves
+    ~0.5 GB per band boundary instead of every tile to every rank."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return mine
-    parts = [None] * dist.get_world_size()
-    dist.all_gather_object(parts, mine)
+    world = dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    keys = sorted(next(iter(mine.values())).keys()) if mine else []
+    shape = tuple(next(iter(mine.values()))[keys[0]].shape) if mine else (0, 0)
+    # agree on (channel names are fixed by the caller) count, tile shape
+    meta = torch.tensor([len(mine), len(keys), shape[0], shape[1]], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    metas = [m.cpu().numpy() for m in metas]
+    nmax = int(max(m[0] for m in metas))
+    nk, th, tw = (int(max(m[i] for m in metas)) for i in (1, 2, 3))
+    if nmax == 0:
+        return mine
+    assert all(m[0] == 0 or (m[1], m[2], m[3]) == (nk, th, tw) for m in metas), "tiles of one survey share one shape"
+    if not keys:                                           # this rank holds no tile: it still takes part in the collective
+        keys = ["cleaned_depth", "classification", "confidence", "correction"][:nk]
+    idx = torch.full((nmax,), -1, dtype=torch.int64)
+    blk = torch.zeros((nmax, nk, th, tw), dtype=torch.float32)
+    for j, (i, r) in enumerate(sorted(mine.items())):
+        idx[j] = i
+        for c, k in enumerate(keys):
+            blk[j, c] = torch.from_numpy(np.ascontiguousarray(r[k], dtype=np.float32))
+    idx, blk = idx.to(dev), blk.to(dev)
+    idxs = [torch.empty_like(idx) for _ in range(world)]
+    blks = [torch.empty_like(blk) for _ in range(world)]
+    dist.all_gather(idxs, idx)
+    dist.all_gather(blks, blk)
     out = {}
-    for p in parts:
-        out.update(p)
+    for ii, bb in zip(idxs, blks):
+        ii = ii.cpu().numpy(); bb = bb.cpu().numpy()
+        for j, i in enumerate(ii):
+            if i >= 0:
+                out[int(i)] = {k: bb[j, c] for c, k in enumerate(keys)}
     return out
 
+
+def gather_bands_to_rank0(plan, rank: int, band: Optional[torch.Tensor], width: int, channels: int = 4):
+    """The sharded survey path's last step: every rank's stitched band [channels, rows, width] (float32) goes to rank 0 by
+    point-to-point ``send`` / ``recv`` of the tensor itself (RCCL under ``nccl``; staged through the host under ``gloo``),
+    one message per band -- not an all-gather of pickled arrays to everybody.  Rank 0 returns the assembled
+    [channels, H, width] host array, the other ranks None."""
+    import torch.distributed as dist
+    via_host = dist.get_backend() == "gloo"
+    H = max(p["cell_rows"][1] for p in plan)
+    if rank != 0:
+        R0, R1 = plan[rank]["cell_rows"]
+        if R1 > R0:
+            t = band.contiguous()
+            dist.send(t.cpu() if via_host else t, dst=0)
+        return None
+    host = np.empty((channels, H, width), np.float32)
+    R0, R1 = plan[0]["cell_rows"]
+    if R1 > R0:
+        host[:, R0:R1] = band.cpu().numpy()
+    for k in range(1, len(plan)):
+        R0, R1 = plan[k]["cell_rows"]
+        if R1 == R0:
+            continue
+        buf = torch.empty((channels, R1 - R0, width), dtype=torch.float32, device="cpu" if via_host else band.device)
+        dist.recv(buf, src=k)
+        host[:, R0:R1] = buf.cpu().numpy()
+    return host
 
 
 def survey_shard_plan(row_start, row_end, height: int, world: int):
@@ -334,7 +392,8 @@ class BathymetricPipeline:
 
     # ---- whole grid ----------------------------------------------------------------------------
     def process_survey_device(self, depth_t: torch.Tensor, valid_t: torch.Tensor, unc_t: Optional[torch.Tensor],
-                              resolution, shard: Optional[Tuple[int, int]] = None):
+                              resolution, shard: Optional[Tuple[int, int]] = None,
+                              survey_shape: Optional[Tuple[int, int]] = None, row_offset: int = 0):
         """Survey resident in HBM in, ``[4, H, W]`` float32 device tensor out (classification, confidence,
         correction, cleaned depth): tiles are cut (``bgnn_cut_tiles``), filtered by ``min_valid_ratio``
         (``bgnn_tile_valid_counts``), classified batch by batch into three long per-tile result arrays and
@@ -346,12 +405,20 @@ class BathymetricPipeline:
         survey): the rank classifies the tile rows ``survey_shard_plan`` gives it, receives the few earlier tile
         rows that reach into its band of survey rows (``exchange_halo_tile_rows``, the only inter-GPU traffic)
         and stitches that band; returns ``(row0, row1, [4, row1-row0, W])``.  Every cell sees the same tiles in
-        the same ascending order as on one GPU, so the bands concatenate to the single-GPU result bit for bit."""
+        the same ascending order as on one GPU, so the bands concatenate to the single-GPU result bit for bit.
+
+        A rank does not need the whole survey: with ``survey_shape=(H, W)`` and ``row_offset``, ``depth_t`` / ``valid_t`` /
+        ``unc_t`` hold only the survey rows ``[row_offset, row_offset + depth_t.shape[0])`` -- what the rank's own tile rows
+        span (``survey_rows_of_rank``)."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
         eng, ctx, dev = self._engine, self._engine.ctx, self._engine.ctx.device
         tm = self.tile_manager
-        H, W = (int(v) for v in depth_t.shape)
+        LH, W = (int(v) for v in depth_t.shape)              # rows held locally
+        H = int(survey_shape[0]) if survey_shape is not None else LH
+        assert survey_shape is None or int(survey_shape[1]) == W
+        row_offset = int(row_offset)
+        assert 0 <= row_offset and row_offset + LH <= H
         assert depth_t.dtype == torch.float32 and depth_t.is_contiguous() and valid_t.is_contiguous() and valid_t.shape == depth_t.shape
         valid_u8 = valid_t.view(torch.uint8) if valid_t.dtype == torch.bool else valid_t
         ntr, ntc, specs = tm.compute_tile_grid((H, W))
@@ -365,13 +432,18 @@ class BathymetricPipeline:
         me = plan[rank]
         ta, tb = me["tile_rows"]; R0, R1 = me["cell_rows"]
         own = np.arange(ta * ntc, tb * ntc)                              # my tiles, ascending spec order
+        if len(own):
+            assert rs[ta] >= row_offset and re[tb - 1] <= row_offset + LH, "the local rows do not cover this rank's tile rows"
+        assert R0 == R1 or (R0 >= row_offset and R1 <= row_offset + LH)
         # ---- min_valid_ratio filter (iterate_tiles, tiling.py:203-209), exact integer counts ----
         keep = np.zeros(0, bool)
         if len(own):
-            org_t = torch.from_numpy(np.ascontiguousarray(sa[own, :2], dtype=np.int32)).to(dev)
+            org = np.ascontiguousarray(sa[own, :2], dtype=np.int32)
+            org[:, 0] -= row_offset                                      # origins in local rows
+            org_t = torch.from_numpy(org).to(dev)
             cnt_t = torch.empty(len(own), dtype=torch.int64, device=dev)
             ctx.begin()
-            rt.check(ctx.lib.bgnn_tile_valid_counts(ctx.handle, H, W, rt.ptr(valid_u8), len(own), rt.ptr(org_t), th, tw, rt.ptr(cnt_t)))
+            rt.check(ctx.lib.bgnn_tile_valid_counts(ctx.handle, LH, W, rt.ptr(valid_u8), len(own), rt.ptr(org_t), th, tw, rt.ptr(cnt_t)))
             ctx.end()
             keep = ~((cnt_t.cpu().numpy() / cells) < tm.min_valid_ratio)    # same float64 test as iterate_tiles
         proc = np.nonzero(keep)[0]                                       # positions in `own`
@@ -393,7 +465,7 @@ class BathymetricPipeline:
                 nb = min(self.tile_batch, n_proc - b0)
                 o_b = org_t[proc_t[b0:b0 + nb]].contiguous()
                 ctx.begin()
-                rt.check(ctx.lib.bgnn_cut_tiles(ctx.handle, H, W, rt.ptr(depth_t), rt.ptr(valid_u8), rt.ptr(unc_t), nb, rt.ptr(o_b),
+                rt.check(ctx.lib.bgnn_cut_tiles(ctx.handle, LH, W, rt.ptr(depth_t), rt.ptr(valid_u8), rt.ptr(unc_t), nb, rt.ptr(o_b),
                                                 th, tw, rt.ptr(d_b), rt.ptr(m_b), rt.ptr(u_b)))
                 ctx.end()
                 lo, hi, n = b0 * cells, (b0 + nb) * cells, nb * cells
@@ -449,38 +521,58 @@ class BathymetricPipeline:
             ctx.begin()
             rt.check(ctx.lib.bgnn_stitch_tiles(
                 ctx.handle, R1 - R0, W, len(rows_inv), ntc, rt.ptr(rs_t), rt.ptr(re_t), rt.ptr(cs_t), rt.ptr(ce_t), rt.ptr(rw_t),
-                rt.ptr(cw_t), pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr), rt.ptr(depth_t[R0:R1]),
-                rt.ptr(valid_u8[R0:R1]), C.c_float(self.config.inference.auto_correct_threshold),
+                rt.ptr(cw_t), pitch, rt.ptr(off_t), rt.ptr(r_cls), rt.ptr(r_conf), rt.ptr(r_corr),
+                rt.ptr(depth_t[R0 - row_offset:R1 - row_offset]), rt.ptr(valid_u8[R0 - row_offset:R1 - row_offset]),
+                C.c_float(self.config.inference.auto_correct_threshold),
                 rt.ptr(o[0]), rt.ptr(o[1]), rt.ptr(o[2]), rt.ptr(o[3])))
             ctx.end()
         self.last_tile_counts = (n_proc, len(own) - n_proc)
         logger.info(f"Processed {n_proc} tiles ({len(own) - n_proc} skipped below min_valid_ratio)")
         return o if shard is None else (R0, R1, o)
 
-    def process_grid_device(self, grid: BathymetricGrid) -> Dict[str, np.ndarray]:
+    def survey_rows_of_rank(self, shape, rank: int, world: int):
+        """Survey rows ``[lo, hi)`` rank ``rank`` of ``world`` must hold for a survey of ``shape``: the span of its own tile
+        rows (its band of cell rows lies inside it).  (0, 0) for a rank without tile rows."""
+        ntr, ntc, specs = self.tile_manager.compute_tile_grid(tuple(int(v) for v in shape))
+        rs = np.array([specs[i * ntc].row_start for i in range(ntr)], np.int64)
+        re = np.array([specs[i * ntc].row_end for i in range(ntr)], np.int64)
+        plan = survey_shard_plan(rs, re, int(shape[0]), world)
+        ta, tb = plan[rank]["tile_rows"]
+        return (int(rs[ta]), int(re[tb - 1])) if tb > ta else (0, 0), plan
+
+    def process_grid_device(self, grid: BathymetricGrid) -> Optional[Dict[str, np.ndarray]]:
         """Survey path with everything between the two PCIe crossings on the device: the survey is uploaded once,
-        processed by ``process_survey_device`` (row-band sharded when torch.distributed is initialised) and the
-        four result grids come back in one copy.  Same results as the host merge (``host_stitch = True``), bit for
-        bit, for any number of GPUs."""
+        processed by ``process_survey_device`` and the four result grids come back in one copy.  Same results as the host
+        merge (``host_stitch = True``), bit for bit, for any number of GPUs.
+
+        Under an initialised ``torch.distributed`` job the survey is row-band sharded: every rank uploads ONLY the rows its
+        own tile rows span (not the whole survey), classifies and stitches its band, and the bands go to rank 0 as tensors
+        (``gather_bands_to_rank0``).  Rank 0 returns the result dict; the other ranks return None."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
         dev = self._engine.ctx.device
         valid_np = grid.valid_mask
-        depth_t = torch.from_numpy(np.ascontiguousarray(grid.depth, dtype=np.float32)).to(dev)
-        valid_t = torch.from_numpy(np.ascontiguousarray(valid_np).view(np.uint8)).to(dev)
         use_unc = self.model.in_channels == 8 and grid.uncertainty is not None
-        unc_t = torch.from_numpy(np.ascontiguousarray(grid.uncertainty, dtype=np.float32)).to(dev) if use_unc else None
+        up = lambda a, lo, hi, dt: torch.from_numpy(np.ascontiguousarray(a[lo:hi], dtype=dt)).to(dev)
         rank, world = shard_info()
+        H, W = (int(v) for v in grid.shape)
         if world == 1:
+            depth_t = up(grid.depth, 0, H, np.float32)
+            valid_t = torch.from_numpy(np.ascontiguousarray(valid_np).view(np.uint8)).to(dev)
+            unc_t = up(grid.uncertainty, 0, H, np.float32) if use_unc else None
             host = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution).cpu().numpy()
-        else:               # row bands: each rank stitches its own band; the bands are gathered once at the end
-            import torch.distributed as dist
-            r0, r1, band = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution, shard=(rank, world))
-            parts = [None] * world
-            dist.all_gather_object(parts, (r0, r1, band.cpu().numpy()))
-            host = np.empty((4,) + tuple(grid.shape), np.float32)
-            for a, b, arr in parts:
-                host[:, a:b] = arr
+        else:               # row bands: each rank holds and stitches its own rows; the bands are gathered once at the end
+            (lo, hi), plan = self.survey_rows_of_rank((H, W), rank, world)
+            band = None
+            if hi > lo:
+                depth_t = up(grid.depth, lo, hi, np.float32)
+                valid_t = torch.from_numpy(np.ascontiguousarray(valid_np[lo:hi]).view(np.uint8)).to(dev)
+                unc_t = up(grid.uncertainty, lo, hi, np.float32) if use_unc else None
+                _, _, band = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution, shard=(rank, world),
+                                                        survey_shape=(H, W), row_offset=lo)
+            host = gather_bands_to_rank0(plan, rank, band, W)
+            if host is None:
+                return None
         return {"cleaned_depth": host[3], "classification": host[0], "confidence": host[1], "correction": host[2],
                 "valid_mask": valid_np.astype(np.float32)}
 

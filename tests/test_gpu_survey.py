@@ -61,3 +61,65 @@ def test_survey_crop_property(gpu_device):
     f = full.cpu().numpy()
     for k, name in enumerate(("classification", "confidence", "correction", "cleaned_depth")):
         assert np.array_equal(np.nan_to_num(res[name]).view(np.uint32), np.nan_to_num(f[k]).view(np.uint32))
+
+
+def test_config5_full_size_survey_resident_in_hbm(gpu_device):
+    """BASELINE config 5 at FULL size on one GPU (models/pipeline.py:170-190 is the loop it stands for): a 60000 x 60000
+    survey @0.5 m resident in HBM (14.4 GB of depth, ~151 GB peak), 24 336 overlapping 512 x 512 tiles, classified and
+    stitched on the device.  Size-independent property: a 1280 x 1280 crop on the tile lattice at the FAR corner (cell
+    offsets > 2^31, per-tile result offsets > 2^32) re-processed alone reproduces the survey's interior bit for bit.
+    The heads are calibrated (tests/_calibration.py) so that classes mix and _apply_corrections really fires.
+    Falls back to 20000 x 20000 when less than 200 GB of HBM is free (the numbers are printed either way)."""
+    import json, os, time
+    from _calibration import calibrate_heads
+    from oracle import graph_cpu
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.config import Config
+    from bathymetric_gnn_amd.models import BathymetricGNN, BathymetricPipeline
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    S = 60000 if free > 200e9 else 20000
+    depth, valid = synthetic.synthetic_survey_device(S, gpu_device, seed=0)
+    # the synthetic depth runs from -20 m to -20 - 0.015 S m across the survey, so the head outputs drift with position:
+    # calibrate on a crop from the MIDDLE of the survey -- classes then change over across it
+    d0 = depth[S // 2:S // 2 + 96, S // 2:S // 2 + 96].cpu().numpy()
+    og = graph_cpu.build_graph(d0, np.ones_like(d0, bool), None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
+    m = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    cfg = Config(); cfg.tile.tile_size, cfg.tile.overlap = 512, 128
+    pipe = BathymetricPipeline(cfg, tile_batch=32)
+    pipe.set_model(m.to(gpu_device).eval())
+    _, _, specs = pipe.tile_manager.compute_tile_grid((S, S))
+    pipe.process_survey_device(depth[:1024, :1024].contiguous(), valid[:1024, :1024].contiguous(), None, (0.5, 0.5))   # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    o = pipe.process_survey_device(depth, valid, None, (0.5, 0.5))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    n_proc, n_skip = pipe.last_tile_counts
+    assert n_proc + n_skip == len(specs) and n_skip > 0 and (S != 60000 or len(specs) == 24336)
+    hist = [int(((o[0] == k) & valid).sum().item()) for k in range(3)]
+    n_valid = int(valid.sum().item())
+    corrected = int(((o[3] != depth) & valid).sum().item())
+    nan = torch.isnan(o[0])
+    assert not bool((nan & valid).any().item())                            # every valid cell has a class ...
+    assert 0 < int(nan.sum().item()) <= S * S - n_valid                    # ... NaN only on nodata cells no processed tile covers
+    del nan
+    assert sum(hist) == n_valid and sum(h > 0.005 * n_valid for h in hist) >= 2, hist    # classes change over across the survey
+    assert corrected > 0                                                    # _apply_corrections fired
+    k = (S - 1280) // 384 - 1
+    r0 = c0 = 384 * k
+    sub = pipe.process_survey_device(depth[r0:r0 + 1280, c0:c0 + 1280].contiguous(), valid[r0:r0 + 1280, c0:c0 + 1280].contiguous(),
+                                     None, (0.5, 0.5))
+    a = o[:, r0 + 128:r0 + 1152, c0 + 128:c0 + 1152].contiguous().view(torch.int32)
+    b = sub[:, 128:1152, 128:1152].contiguous().view(torch.int32)
+    same = bool(torch.equal(a, b))
+    row = {"survey": f"{S}x{S}", "tiles": len(specs), "tiles_processed": n_proc, "tiles_skipped": n_skip,
+           "node_evals": n_proc * 512 * 512, "wall_s": dt, "node_evals_per_s": n_proc * 512 * 512 / dt, "valid_cells": n_valid,
+           "class_histogram": hist, "cells_corrected": corrected, "hbm_peak_GB": torch.cuda.max_memory_allocated() / 1e9,
+           "crop_origin": [r0, c0], "crop_bit_identical": same}
+    print("config5", json.dumps(row))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):
+        json.dump(row, open(os.path.join(out_dir, "config5_full_survey.json"), "w"), indent=1)
+    del o, sub, depth, valid
+    torch.cuda.empty_cache()
+    assert same

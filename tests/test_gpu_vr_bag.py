@@ -161,16 +161,18 @@ def test_process_refinements_non_contiguous_layout(gpu_device):
     assert w2._corrections_applied == w._corrections_applied
 
 
-def test_config4_scale_stream_device_equals_loop(gpu_device):
-    """BASELINE config 4 at a quarter of its size (~1 000 refinement grids 3x3..50x50, ~0.7 M cells): the whole-BAG device
-    path and the reference-shaped 50 000-node loop write identical records and report identical counters."""
+@pytest.mark.parametrize("base,min_grids", [(35, 900), (70, 4096)])
+def test_config4_scale_stream_device_equals_loop(base, min_grids, gpu_device):
+    """BASELINE config 4 at a quarter of its size (~1 000 refinement grids 3x3..50x50, ~0.7 M cells) and at FULL size
+    (>= 4 096 grids, ~2.9 M cells): the whole-BAG device path and the reference-shaped 50 000-node loop
+    (scripts/inference_native.py:520-538) write identical records and report identical counters."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import VRBagHandler
     from bathymetric_gnn_amd.scripts.inference_native import run_refinements
     proc = _processor(8)
-    md, ref = synthetic.synthetic_vr_bag(35, 35, seed=4000)
+    md, ref = synthetic.synthetic_vr_bag(base, base, seed=4000)
     h = VRBagHandler.from_arrays(md, ref)
-    assert h.num_refinement_cells > 900
+    assert h.num_refinement_cells >= min_grids
     w_loop, w_dev = h.copy_and_open_for_writing(), h.copy_and_open_for_writing()
     st_loop = run_refinements(proc, h, w_loop, 0.01)
     st_dev = proc.process_refinements(h, w_dev, 0.01)

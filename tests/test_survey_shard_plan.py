@@ -94,3 +94,43 @@ def test_halo_exchange_gloo_three_ranks():
             assert np.array_equal(got[t], 100 * src + t + np.arange(1000, dtype=np.float32))
             n_recv += 1
     assert n_recv == 3            # rank 1 <- row 0; rank 2 <- rows 0 and 1
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bathymetric_gnn_amd.models.pipeline import gather_bands_to_rank0, survey_shard_plan
+    rs, re = _rows(1000, 512, 128)
+    plan = survey_shard_plan(rs, re, 1000, world)          # world 4 > 3 tile rows: one rank owns nothing
+    R0, R1 = plan[rank]["cell_rows"]
+    W = 37
+    band = None
+    if R1 > R0:
+        rows = torch.arange(R0, R1, dtype=torch.float32)[None, :, None]
+        band = (rows * 1000 + torch.arange(W, dtype=torch.float32)[None, None, :] + 0.25 * torch.arange(4, dtype=torch.float32)[:, None, None]).contiguous()
+    host = gather_bands_to_rank0(plan, rank, band, W)
+    q.put((rank, None if host is None else host.copy(), [list(p["cell_rows"]) for p in plan]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_gather_to_rank0_gloo_four_ranks():
+    """The sharded survey's last step: bands travel to rank 0 as tensors (one point-to-point message per band), ranks without
+    a band send nothing, rank 0 assembles [channels, H, W]; the other ranks get None."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 4, port, q)) for r in range(4)]
+    for pr in procs:
+        pr.start()
+    res = {r: (h, bands) for r, h, bands in (q.get(timeout=180) for _ in range(4))}
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(res[r][0] is None for r in (1, 2, 3))
+    host, bands = res[0]
+    assert host.shape == (4, 1000, 37) and sum(b[1] - b[0] for b in bands) == 1000 and any(b[0] == b[1] for b in bands)
+    exp = (np.arange(1000, dtype=np.float32)[None, :, None] * 1000 + np.arange(37, dtype=np.float32)[None, None, :]
+           + 0.25 * np.arange(4, dtype=np.float32)[:, None, None])
+    assert np.array_equal(host, exp)

@@ -17,19 +17,7 @@ ap.add_argument("--d2h", action="store_true", help="also copy the four result gr
 args = ap.parse_args()
 S = args.size
 dev = torch.device("cuda:0")
-g = torch.Generator(device=dev); g.manual_seed(0)
-depth = torch.empty((S, S), dtype=torch.float32, device=dev)
-c = torch.arange(S, dtype=torch.float32, device=dev)[None, :]
-band = 4096
-for r0 in range(0, S, band):                     # in row bands: no survey-sized temporaries
-    r1 = min(S, r0 + band)
-    r = torch.arange(r0, r1, dtype=torch.float32, device=dev)[:, None]
-    d = -20 - 0.01 * c - 0.005 * r + 0.5 * torch.sin(2 * np.pi * r / 37) * torch.cos(2 * np.pi * c / 53)
-    d += 0.05 * torch.randn((r1 - r0, S), generator=g, device=dev)
-    depth[r0:r1] = d
-del d
-depth[: S // 10, : S // 8] = 1.0e6               # a nodata corner: tiles skipped by min_valid_ratio, ragged edge
-valid = (depth != 1.0e6) & torch.isfinite(depth)
+depth, valid = synthetic.synthetic_survey_device(S, dev, seed=0)
 cfg = Config(); cfg.tile.tile_size, cfg.tile.overlap = 512, 128
 pipe = BathymetricPipeline(cfg, tile_batch=args.tile_batch)
 sd = synthetic.synthetic_state_dict(seed=1234)

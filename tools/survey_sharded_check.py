@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Row-band sharded survey path on real kernels: WORLD ranks (gloo transport, all on cuda:0 of a one-GPU box -- on an
-8-GPU node each rank takes its own GPU and the nccl backend) run BathymetricPipeline.process_survey_device with
-shard=(rank, world); rank 0 also runs the unsharded path and checks that the gathered bands equal it bit for bit.
+8-GPU node each rank takes its own GPU and the nccl backend) run BathymetricPipeline.process_grid_device
+(each rank uploads only the survey rows its own tile rows span, exchanges halo tile rows point to point, stitches its band;
+the bands go to rank 0 as tensors); rank 0 also runs the unsharded path and checks that the result equals it bit for bit.
 The launcher process itself never touches the GPU (children are started before anything initialises HIP)."""
 import argparse, json, os, socket, sys, time
 import numpy as np
@@ -27,20 +28,26 @@ def worker(rank, world, port, size, tile, overlap, q):
     pipe.set_model(m)
     d, mk, _ = synthetic.synthetic_tile(size, size - 37, 5, "V1")
     d[: size // 3, : size // 4] = 1.0e6
+    from bathymetric_gnn_amd.data import BathymetricGrid
+    grid = BathymetricGrid(depth=d, nodata_value=1.0e6, resolution=(0.5, 0.5))
     depth = torch.from_numpy(d).to(dev); valid = (depth != 1.0e6) & torch.isfinite(depth)
     pipe.process_survey_device(depth[:tile, :tile].contiguous(), valid[:tile, :tile].contiguous(), None, (0.5, 0.5))   # warm-up
+    (lo, hi), plan = pipe.survey_rows_of_rank(d.shape, rank, world)
     dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    r0, r1, band = pipe.process_survey_device(depth, valid, None, (0.5, 0.5), shard=(rank, world))
+    # the product path: every rank uploads ONLY its own rows, stitches its band, bands go to rank 0 as tensors
+    res = pipe.process_grid_device(grid)
     torch.cuda.synchronize(); dist.barrier(); dt = time.perf_counter() - t0
-    parts = [None] * world
-    dist.all_gather_object(parts, (r0, r1, band.cpu().numpy(), pipe.last_tile_counts))
+    assert (res is None) == (rank != 0)
+    counts = [None] * world
+    dist.all_gather_object(counts, (list(plan[rank]["cell_rows"]), [lo, hi], list(getattr(pipe, "last_tile_counts", (0, 0)))))   # (bookkeeping only)
     if rank == 0:
         full = pipe.process_survey_device(depth, valid, None, (0.5, 0.5)).cpu().numpy()
-        got = np.concatenate([p[2] for p in parts], axis=1)
+        got = np.stack([res["classification"], res["confidence"], res["correction"], res["cleaned_depth"]])
         same = got.shape == full.shape and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(full).view(np.uint32)) \
             and np.array_equal(np.isnan(got), np.isnan(full))
-        q.put({"world": world, "survey": list(d.shape), "tile": [tile, overlap], "bands": [[int(p[0]), int(p[1])] for p in parts],
-               "tiles_per_rank": [list(p[3]) for p in parts], "sharded_wall_s": dt, "bit_identical_to_single_gpu": bool(same)})
+        q.put({"world": world, "survey": list(d.shape), "tile": [tile, overlap], "bands": [c[0] for c in counts],
+               "rows_uploaded_per_rank": [c[1] for c in counts], "tiles_per_rank": [c[2] for c in counts], "sharded_wall_s": dt,
+               "bit_identical_to_single_gpu": bool(same)})
     dist.barrier()
     dist.destroy_process_group()
 
