@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   {
 #pragma unroll 1
     for (int s = 0; s < NSLAB; ++s) {
+      const uint32_t slabs = slab0;
       // VM queue order per wave: [slab s] [W rows 0-15 of slab s: WA] [W rows 16-31: WB] [slab s+1] [WA s+1] ...
       // WA / WB are WH pieces per wave each (unconditional); slab pieces are exec-masked, so they are never
       // counted on: a wait that must cover a W half uses only the W pieces issued after it.
@@ -493,35 +494,58 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       f32x4 g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!DBG(1))
-#pragma unroll
-      for (int b = 0; b <= K; ++b) {
-        const int nidx = b == K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
-        const float alpha = lds_read1<0>(ap + 4 * b);
+      if (!DBG(1)) {
+        // Software-pipelined gather: the LDS reads of neighbour b + 1 are issued BEFORE the wait for neighbour b (LDS returns
+        // in order, so a counted lgkmcnt leaves exactly the younger neighbour's reads in flight).  Only the first neighbour's
+        // read latency is exposed; without this every neighbour pays it (9 x ~120 cycles per slab while BOTH workgroups of a
+        // CU tend to sit in their gather phase at the same time, i.e. with the matrix pipe idle).  The row base addresses are
+        // kept (K + 1 registers); the three other chunk slots are re-derived by XOR, which frees the registers the second
+        // read buffer needs.
+        auto nb_index = [&](int b) { return b >= K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0]; };
         if constexpr (SP == 3) {
           // 64-byte rows of bf16: chunk hl (channels 8hl..8hl+7) and chunk 2 + hl (16+8hl..), swizzled by (row >> 2) & 3
-          const uint32_t rb = slab0 + nidx * 64 + ((((nidx >> 2) & 3) ^ hl) << 4);
-          const u32x4 xa = lds_read4u<0>(rb), xb = lds_read4u<0>(rb ^ 32);
-          lds_reads_done();
+          auto rowbase = [&](int b) { const int nidx = nb_index(b); return slabs + nidx * 64 + ((((nidx >> 2) & 3) ^ hl) << 4); };
+          u32x4 xa[2], xb[2]; float al[2];
+          { const uint32_t rb = rowbase(0); al[0] = lds_read1<0>(ap); xa[0] = lds_read4u<0>(rb); xb[0] = lds_read4u<0>(rb ^ 32); }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {                   // dword j of a chunk = channels (2j, 2j+1) as (low, high) halves
-            const u32x4 &x = j == 0 ? xa : xb;
-            g[2 * j].x += alpha * __uint_as_float(x.x << 16); g[2 * j].y += alpha * __uint_as_float(x.x & 0xffff0000u);
-            g[2 * j].z += alpha * __uint_as_float(x.y << 16); g[2 * j].w += alpha * __uint_as_float(x.y & 0xffff0000u);
-            g[2 * j + 1].x += alpha * __uint_as_float(x.z << 16); g[2 * j + 1].y += alpha * __uint_as_float(x.z & 0xffff0000u);
-            g[2 * j + 1].z += alpha * __uint_as_float(x.w << 16); g[2 * j + 1].w += alpha * __uint_as_float(x.w & 0xffff0000u);
+          for (int b = 0; b <= K; ++b) {
+            const int cur = b & 1, nxt = cur ^ 1;
+            if (b < K) {
+              const uint32_t rb = rowbase(b + 1);
+              al[nxt] = lds_read1<0>(ap + 4 * (b + 1)); xa[nxt] = lds_read4u<0>(rb); xb[nxt] = lds_read4u<0>(rb ^ 32);
+              asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float alpha = al[cur];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                   // dword j of a chunk = channels (2j, 2j+1) as (low, high) halves
+              const u32x4 &x = j == 0 ? xa[cur] : xb[cur];
+              g[2 * j].x += alpha * __uint_as_float(x.x << 16); g[2 * j].y += alpha * __uint_as_float(x.x & 0xffff0000u);
+              g[2 * j].z += alpha * __uint_as_float(x.y << 16); g[2 * j].w += alpha * __uint_as_float(x.y & 0xffff0000u);
+              g[2 * j + 1].x += alpha * __uint_as_float(x.z << 16); g[2 * j + 1].y += alpha * __uint_as_float(x.z & 0xffff0000u);
+              g[2 * j + 1].z += alpha * __uint_as_float(x.w << 16); g[2 * j + 1].w += alpha * __uint_as_float(x.w & 0xffff0000u);
+            }
+            // the sums are due HERE: without this the unpacked values of several neighbours are kept in registers and the
+            // FMAs sunk below the following reads (16 more live registers per neighbour -> spills)
+            asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
           }
-          // the sums are due HERE: without this the unpacked values of several neighbours are kept in registers and the
-          // FMAs sunk below the following reads (16 more live registers per neighbour -> spills)
-          asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
         } else {
-          // slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5))
-          const uint32_t rb = slab0 + nidx * 128 + (((((nidx >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
-          f32x4 x[4];
-          x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ CX1); x[2] = lds_read4<0>(rb ^ CX2); x[3] = lds_read4<0>(rb ^ CX3);
-          lds_reads_done();
+          // 128-byte rows of f32: slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5)).  (Not
+          // software-pipelined: measured, it buys nothing on the f32 paths -- the stamps put the gather at 4.6 % of a
+          // workgroup's lifetime -- and the second read buffer takes the kernel to 256 registers.)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
+          for (int b = 0; b <= K; ++b) {
+            const int nidx = nb_index(b);
+            const uint32_t rb = slabs + nidx * 128 + (((((nidx >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
+            f32x4 x[4];
+            const float alpha = lds_read1<0>(ap + 4 * b);
+            x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ CX1); x[2] = lds_read4<0>(rb ^ CX2); x[3] = lds_read4<0>(rb ^ CX3);
+            lds_reads_done();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
+          }
         }
       }
       // layer epilogue: (+bias, BatchNorm) folded, ReLU -> h_{l+1}, in registers

@@ -339,11 +339,14 @@ def main():
         # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach if present
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         # (the counters were collected on the default workload only: 128 tiles of 256 x 256, 4 layers)
-        if os.path.exists(pmc) and args.workload == "tiles" and (B, S, args.layers, deg) == (128, 256, 4, 8) and not bf16:
+        pmc_key = (":c3" if (deg == 16 and bf16) else None if (deg != 8 or bf16) else ":split" if split_main else "")
+        if os.path.exists(pmc) and args.workload == "tiles" and (B, S, args.layers) == (128, 256, 4) and pmc_key is not None:
             try:
                 t = json.load(open(pmc))
                 for v in roofs.values():
-                    e = t.get(v["kernel"] + ":split") if split_main else None
+                    e = t.get(v["kernel"] + pmc_key) if pmc_key else None
+                    if pmc_key == ":c3" and e is None:
+                        continue
                     v["traffic"] = (e or t.get(v["kernel"], {})).get("hbm_bytes_per_launch")
                     if v["traffic"] is not None:
                         v["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "

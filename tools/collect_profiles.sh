@@ -10,17 +10,17 @@ python3 $R/bench.py > $O/bench_fused.json
 python3 $R/bench.py --unfused --no-cpu-baseline > $O/bench_unfused.json
 python3 $R/bench.py --split-bf16 --no-cpu-baseline > $O/bench_split.json
 python3 $R/bench.py --split-f16 --no-cpu-baseline > $O/bench_split_f16.json
+python3 $R/bench.py --workload c3 --cpu-tiles 2 > $O/bench_c3.json
+python3 $R/bench.py --bf16 --no-cpu-baseline > $O/bench_bf16_k8.json
 python3 $R/bench.py --workload vr --vr-budget 50000 --no-cpu-baseline > $O/bench_vr_50k.json
 python3 $R/bench.py --workload vr --vr-budget 1000000 --no-cpu-baseline > $O/bench_vr_1M.json
-for mode in fused unfused split; do
-  flag=""; [ $mode = unfused ] && flag="--unfused"
-  if [ $mode = split ]; then export BGNN_SPLIT_BF16=1; else unset BGNN_SPLIT_BF16; fi
+for mode in fused unfused split c3; do
+  flag=""; [ $mode = unfused ] && flag="--unfused"; [ $mode = split ] && flag="--split-bf16"; [ $mode = c3 ] && flag="--workload c3"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${mode}_stats -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${mode}_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${mode}_write -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
   echo "$mode profiled"
 done
-unset BGNN_SPLIT_BF16
 # keep the merge small: drop the per-dispatch traces of the stats passes
 find $O -name "*kernel_trace.csv" -path "*_stats*" -delete
 ls $O

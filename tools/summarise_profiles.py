@@ -67,14 +67,15 @@ def main():
 
     for src_name, dst_name in (("bench_fused", "bench_fused"), ("bench_unfused", "bench_unfused"), ("bench_split", "bench_split"),
                                ("bench_split_f16", "bench_split_f16"), ("bench_vr_50k", "bench_vr_budget50k"),
-                               ("bench_vr_1M", "bench_vr_budget1M")):
+                               ("bench_vr_1M", "bench_vr_budget1M"), ("bench_c3", "bench_c3_k16_bf16"), ("bench_bf16_k8", "bench_bf16_k8")):
         p = os.path.join(a.src, src_name + ".json")
         if os.path.exists(p):
             line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
             json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{dst_name}.json"), "w"), indent=1)
 
     all_k, classes = {}, {}
-    for mode, label in (("fused", "fused, exact f32"), ("unfused", "unfused"), ("split", "fused, bf16x3")):
+    for mode, label in (("fused", "fused, exact f32"), ("unfused", "unfused"), ("split", "fused, bf16x3"),
+                        ("c3", "fused, k=16, bf16 storage (BASELINE configs[2])")):
         st = glob.glob(os.path.join(a.src, f"{mode}_stats", "**", "*kernel_stats.csv"), recursive=True)
         if st:
             shutil.copy(st[0], os.path.join(dst, f"{tag}_{mode}_kernel_stats.csv"))
@@ -95,7 +96,7 @@ def main():
             cls_acc[cls][1] += n
         for cls, (tot, n) in cls_acc.items():
             if cls in ("gat_layer_fused_kernel", "gat_aggregate_tiled_kernel", "gemm_f32_kernel", "features_kernel"):
-                key = cls if mode != "split" else cls + ":split"
+                key = cls if mode not in ("split", "c3") else cls + ":" + mode
                 if mode == "unfused" and cls != "gat_aggregate_tiled_kernel":
                     continue
                 classes[key] = {"hbm_bytes_per_launch": tot / n, "launches_sampled": n, "path": label}
