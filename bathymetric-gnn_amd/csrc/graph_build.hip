@@ -15,6 +15,7 @@
 //                           edge whose target is this node), -1 if absent; ascending b is the
 //                           order torch_geometric's scatter sees this node's in-edges
 //   eattr[rows][K][ED] f32  attributes of that edge
+#include <type_traits>
 #include "bgnn_internal.h"
 
 namespace bgnn {
@@ -489,23 +490,29 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
         }
       }
     };
-    if (st.K == 8 && a.ED == 3) {
-      // the usual shape: the node's stencil row (8 ids = 32 B) and attribute block (8 x 3 floats = 96 B) leave as
-      // whole 16-byte stores instead of 32 scattered dwords
-      int sids[8];
-      float evs[24];
+    // the usual shapes (3 edge features, K = 8 or 16): the node's stencil row (K ids) and attribute block (K x 3 floats) leave as
+    // whole 16-byte stores instead of 4 K scattered dwords (at K = 16 the scattered form wrote 5x the bytes)
+    auto emit_rows = [&](auto kk) {
+      constexpr int KK = decltype(kk)::value;
+      int sids[KK];
+      float evs[3 * KK];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
+      for (int b = 0; b < KK; ++b) {
         float ev[4];
         edge_slot(b, sids[b], ev);
         evs[3 * b] = ev[0]; evs[3 * b + 1] = ev[1]; evs[3 * b + 2] = ev[2];
       }
-      int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * 8);
-      np[0] = make_int4(sids[0], sids[1], sids[2], sids[3]);
-      np[1] = make_int4(sids[4], sids[5], sids[6], sids[7]);
-      float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * 24);
+      int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * KK);
 #pragma unroll
-      for (int q = 0; q < 6; ++q) ep[q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+      for (int q = 0; q < KK / 4; ++q) np[q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+      float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * (3 * KK));
+#pragma unroll
+      for (int q = 0; q < 3 * KK / 4; ++q) ep[q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+    };
+    if (st.K == 8 && a.ED == 3) {
+      emit_rows(std::integral_constant<int, 8>{});
+    } else if (st.K == 16 && a.ED == 3) {
+      emit_rows(std::integral_constant<int, 16>{});
     } else {
       for (int b = 0; b < st.K; ++b) {
         int sid;
