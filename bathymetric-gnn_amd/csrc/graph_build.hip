@@ -398,6 +398,9 @@ __device__ __forceinline__ float filled_at(const FeatureArgs &a, int64_t i) {
   return nan_to_num_f32(v);
 }
 
+// KV: stencil width with the vectorised table stores (8 or 16, 3 edge features), 0 = generic.  A template parameter so that
+// the K = 16 store path's registers (64 table values per node) do not set the occupancy of the K = 8 kernel.
+template <int KV>
 __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st) {
   const BgnnWorkItem it = a.items[blockIdx.x];
   const BgnnTileMeta t = a.tiles[it.tile];
@@ -509,10 +512,8 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
 #pragma unroll
       for (int q = 0; q < 3 * KK / 4; ++q) ep[q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
     };
-    if (st.K == 8 && a.ED == 3) {
-      emit_rows(std::integral_constant<int, 8>{});
-    } else if (st.K == 16 && a.ED == 3) {
-      emit_rows(std::integral_constant<int, 16>{});
+    if constexpr (KV != 0) {
+      emit_rows(std::integral_constant<int, KV>{});
     } else {
       for (int b = 0; b < st.K; ++b) {
         int sid;
@@ -702,7 +703,9 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     }
     if (tiles->uncertainty && !listed_unc) a.feat_ids[nf++] = BGNN_NF_UNCERTAINTY;
     for (int i = 0; i < opts->n_edge_features; ++i) a.edge_ids[i] = opts->edge_features[i];
-    hipLaunchKernelGGL(features_kernel, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    if (st.K == 8 && a.ED == 3) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 16 && a.ED == 3) hipLaunchKernelGGL(features_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else hipLaunchKernelGGL(features_kernel<0>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
   }
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;

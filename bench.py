@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (no PCIe-inclusive / split-path / single-tile side measurements, no CPU baseline): "
+                         "what the rocprofv3 passes run, so that a kernel's average duration in the trace is the full-batch one")
     ap.add_argument("--split-f16", action="store_true",
                     help="opt-in matrix path: float16 hi/lo operand split (fp16x3), float32 accumulation (|activations| < 65504)")
     ap.add_argument("--split-bf16", action="store_true",
@@ -374,7 +377,8 @@ def main():
             "rooflines": roofs, "kernels": kernels, "path": "unfused" if unfused else "fused",
             "matrix_path": "bf16 storage + bf16 MFMA (BASELINE configs[2])" if bf16 else f"{split_main} split (opt-in)" if split_main else "exact f32",
         }
-        if world == 1 and args.workload == "tiles" and not unfused:
+        extras = not args.no_extras
+        if extras and world == 1 and args.workload == "tiles" and not unfused:
             # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
             # D2H on three streams, two slots in flight.  Reported beside `value`, never as it.
             from bathymetric_gnn_amd.models.pipeline import HostTilePipeline
@@ -394,7 +398,7 @@ def main():
                                       "steps": n_pc, "bytes_per_cell": {"h2d": 5, "d2h": 12},
                                       "note": "host numpy tiles in, host grids out: pinned double-buffered staging, H2D / "
                                               "compute / D2H overlapped on three streams (HostTilePipeline)"}
-        if world == 1 and args.workload == "tiles" and not unfused and not split_main:
+        if extras and world == 1 and args.workload == "tiles" and not unfused and not split_main:
             # Opt-in matrix path, reported BESIDE the headline (never as it): bf16 hi/lo operand split (bf16x3) on the bf16
             # matrix cores with float32 accumulation.  Same inputs, same timing protocol; the distance of its class logits
             # to the exact-f32 path is measured on one tile of the batch.
@@ -419,7 +423,7 @@ def main():
                              "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
                              "note": f"matrix_path={env}: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
                                      "opt-in, not the headline"}
-        if world == 1 and args.workload == "tiles" and not unfused and B > 1:
+        if extras and world == 1 and args.workload == "tiles" and not unfused and B > 1:
             # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
             d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
             hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)
@@ -433,7 +437,7 @@ def main():
             torch.cuda.synchronize(dev); t_one = (time.perf_counter() - t3) / n_one
             line["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
                                    "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
+        if extras and world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
             line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100, conn)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))

@@ -16,9 +16,9 @@ python3 $R/bench.py --workload vr --vr-budget 50000 --no-cpu-baseline > $O/bench
 python3 $R/bench.py --workload vr --vr-budget 1000000 --no-cpu-baseline > $O/bench_vr_1M.json
 for mode in fused unfused split c3; do
   flag=""; [ $mode = unfused ] && flag="--unfused"; [ $mode = split ] && flag="--split-bf16"; [ $mode = c3 ] && flag="--workload c3"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${mode}_stats -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${mode}_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${mode}_write -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $flag > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${mode}_stats -- python3 $R/bench.py --no-extras --steps 5 --warmup 1 $flag > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${mode}_fetch -- python3 $R/bench.py --no-extras --steps 5 --warmup 1 $flag > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${mode}_write -- python3 $R/bench.py --no-extras --steps 5 --warmup 1 $flag > /dev/null 2>&1
   echo "$mode profiled"
 done
 # keep the merge small: drop the per-dispatch traces of the stats passes
