@@ -470,8 +470,13 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       // WA / WB are WH pieces per wave each (unconditional); slab pieces are exec-masked, so they are never
       // counted on: a wait that must cover a W half uses only the W pieces issued after it.
       constexpr int WH = WHalf<NT, SP>::PER_WAVE;
-      // (when the pieces do not divide evenly some waves issue one more: the floor only makes their wait conservative)
+      // When the pieces of a half do not divide evenly over the 4 waves, waves below NQ % 4 issue one more: their counted
+      // waits leave one more operation in flight per half (a wave-uniform branch between two immediates).  With the floor
+      // alone a narrow next stage (NQ = 2 or 3) waited for EVERYTHING at each of these points, the next slab included.
+      constexpr int WREM = WHalf<NT, SP>::NQ % 4;
+      const bool wextra = wave < WREM;
       if (s == 0) wait_vm_lgkm<0>();                    // (slab 0 was queued BEHIND its W rows: wait for everything)
+      else if (WREM && wextra) wait_vm_lgkm<2 * (WH + 1)>();
       else wait_vm_lgkm<2 * WH>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
       if (s == 0) {
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         }
       }
       BGNN_STAMP(4)   // gather + layer epilogue
-      wait_vm_lgkm<WH>();                               // WA(s) landed (WB(s) may still fly)
+      if (WREM && wextra) wait_vm_lgkm<WH + 1>(); else wait_vm_lgkm<WH>();   // WA(s) landed (WB(s) may still fly)
       __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
       BGNN_STAMP(5)   // wait for WA + barrier
       if (s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
