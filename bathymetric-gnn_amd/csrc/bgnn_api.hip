@@ -390,6 +390,16 @@ static void pack_bf16_image(const float *Wt, int D, int NC, float *dst_as_float)
             dst[(((size_t)hc * NT + t) * 2 + kg) * 256 + m * 8 + i] = bf16_rne(Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m]);
 }
 
+// column-permuted f32 image for the fused exact-f32 kernel: column 32 t + r of a row goes to (t / TG) * 32 TG + r * TG + t % TG,
+// TG = 4 / 2 / 1 tiles per LDS read (gat_layer_fused.hip: WTileGroup)
+static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst) {
+  const int NT = NC / 32, TG = NT % 4 == 0 ? 4 : NT % 2 == 0 ? 2 : 1;
+  for (int k = 0; k < D; ++k)
+    for (int t = 0; t < NT; ++t)
+      for (int r = 0; r < 32; ++r)
+        dst[(size_t)k * NC + (t / TG) * 32 * TG + r * TG + t % TG] = Wt[(size_t)k * NC + t * 32 + r];
+}
+
 int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
   BGNN_REQUIRE(ctx && d && w && out, "bgnn_model_create: NULL argument");
   BGNN_REQUIRE(d->hidden == 32 || d->hidden == 64, "hidden_channels=%d unsupported (32 or 64)", d->hidden);
@@ -552,14 +562,16 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
 
   // bf16 and float16 hi / lo images of the fused kernels' next-stage weights (layers 1.., the heads' first layers) and
   // of the folded layer-0 weight
-  std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0), o_wbf(L, 0);
-  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0, o_hW0bf = 0, o_l0fbf = 0;
+  std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0), o_wbf(L, 0), o_wfp(L, 0);
+  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0, o_hW0bf = 0, o_l0fbf = 0, o_hW0fp = 0;
   bool f16_ok = true;                  // every weight fits float16: else BGNN_SPLIT_F16 falls back to the bf16 split
   if (gat) {
     for (int l = 1; l < L; ++l) {
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       o_wsp[l] = reserve((size_t)D * HC); o_wsp16[l] = reserve((size_t)D * HC); o_wbf[l] = reserve((size_t)D * HC / 2);
+      o_wfp[l] = reserve((size_t)D * HC);
     }
+    o_hW0fp = reserve((size_t)hid * HT);
     o_hW0sp = reserve((size_t)hid * HT); o_hW0sp16 = reserve((size_t)hid * HT); o_hW0bf = reserve((size_t)hid * HT / 2);
     o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0); o_l0fbf = reserve((size_t)hid * HC0 / 2);
     for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
@@ -568,11 +580,13 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
       pack_split(src.data(), D, HC, pk.data() + o_wsp[l], false);
       if (!pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true)) f16_ok = false;
       pack_bf16_image(src.data(), D, HC, pk.data() + o_wbf[l]);
+      pack_tilegroup_image(src.data(), D, HC, pk.data() + o_wfp[l]);
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
     pack_split(src.data(), hid, HT, pk.data() + o_hW0sp, false);
     if (!pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true)) f16_ok = false;
     pack_bf16_image(src.data(), hid, HT, pk.data() + o_hW0bf);
+    pack_tilegroup_image(src.data(), hid, HT, pk.data() + o_hW0fp);
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
     if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
@@ -591,6 +605,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->l0f_Wsp16 = gat && f16_ok ? m->blob + o_l0fsp16 : nullptr;
   m->l0f_Wbf = gat ? m->blob + o_l0fbf : nullptr;
   m->hd_W0bf = gat ? m->blob + o_hW0bf : nullptr;
+  m->hd_W0fp = gat ? m->blob + o_hW0fp : nullptr;
   m->layers.resize(L);
   for (int l = 0; l < L && !gat; ++l) {
     BgnnLayer &Ly = m->layers[l];
@@ -614,6 +629,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
     Ly.Wsp16 = l > 0 && f16_ok ? m->blob + o_wsp16[l] : nullptr;
     Ly.Wbf = l > 0 ? m->blob + o_wbf[l] : nullptr;
+    Ly.Wfp = l > 0 ? m->blob + o_wfp[l] : nullptr;
     Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
   }
   m->head_hidden_total = HT;

@@ -122,6 +122,7 @@ struct BgnnLayer {
   float *shift;     // [width]  (conv bias - mean) * scale + BN bias
   float *Wsp;       // Wt as a bf16 hi / lo split image for the bf16x3 matrix path (same byte geometry as Wt; see pack_split)
   float *Wsp16;     // the same with float16 parts (fp16x3)
+  float *Wfp;       // Wt with the columns of every row permuted for the fused exact-f32 kernel (gat_layer_fused.hip: WTileGroup)
   float *Wbf;       // Wt as a bf16 (hi only) image for the bf16 storage path: [D/16][NC/32][1 KiB] in MFMA A-fragment lane order
   // non-attention backbones (desc.gnn_type != BGNN_GNN_GAT): Wt = GCN lin^T [hid][hid] | SAGE [lin_l^T ; lin_r^T] [2 hid][hid]
   // with BatchNorm folded in | GIN nn.0^T [hid][hid]; then
@@ -143,6 +144,7 @@ struct bgnn_model {
   float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
   float *l0f_Wsp = nullptr, *l0f_Wsp16 = nullptr;   // l0f_Wt as bf16 / float16 hi / lo split images
   float *l0f_Wbf = nullptr, *hd_W0bf = nullptr;     // l0f_Wt / hd_W0t as bf16 (hi only) images
+  float *hd_W0fp = nullptr;                         // hd_W0t column-permuted for the fused exact-f32 kernel
   std::vector<BgnnLayer> layers;
   float *ones = nullptr;      // [256] of 1.0f: the identity scale of an unfolded epilogue
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32

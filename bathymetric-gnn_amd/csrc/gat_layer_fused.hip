@@ -123,14 +123,40 @@ __device__ __forceinline__ void lds_reads_done() {
 // MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
 // (+ 4*hl, folded into the base address).  The W fragments of group M+1 are requested before the MFMAs of
 // group M are issued, so their LDS latency hides under the matrix pipe.
+// On gfx950 the f32 MFMA shares the SIMD's issue with everything else (tools/mfma_overlap_probe.hip), so every instruction
+// beside the MFMAs costs matrix time: the W image therefore has its columns permuted (WTileGroup) so that ONE ds_read_b128 (or
+// b64) brings the fragments of TG = 4 (or 2) tiles of a k row -- 32 LDS reads per slab and wave instead of 128.
+template <int NT>
+struct WTileGroup {      // tiles per LDS read: column 32 t + r of W^T sits at (t / TG) * 32 TG + r * TG + t % TG of the image row
+  static constexpr int TG = NT % 4 == 0 ? 4 : NT % 2 == 0 ? 2 : 1;
+};
+template <int TG, int OFF>
+__device__ __forceinline__ void lds_read_frags(float *dst, uint32_t addr) {
+  if constexpr (TG == 4) {
+    const f32x4 v = lds_read4<OFF>(addr);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  } else if constexpr (TG == 2) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    dst[0] = v.x; dst[1] = v.y;
+  } else {
+    dst[0] = lds_read1<OFF>(addr);
+  }
+}
 template <int NT, int NC, int M, int END = 8>
 struct MfmaGroups {
   static constexpr int ROW = 8 * (M / 2) + 2 * (M & 1);
+  static constexpr int TG = WTileGroup<NT>::TG;
   __device__ static __forceinline__ void load(float (&wa)[NT], float (&wb)[NT], uint32_t wbuf0) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      wa[t] = lds_read1<ROW * NC * 4>(wbuf0 + t * 128);
-      wb[t] = lds_read1<(ROW + 1) * NC * 4>(wbuf0 + t * 128);
+    lload<0>(wa, wb, wbuf0);
+  }
+  template <int TH>
+  __device__ static __forceinline__ void lload(float (&wa)[NT], float (&wb)[NT], uint32_t wbuf0) {
+    if constexpr (TH < NT / TG) {
+      lds_read_frags<TG, (ROW * NC + TH * 32 * TG) * 4>(wa + TH * TG, wbuf0);
+      lds_read_frags<TG, ((ROW + 1) * NC + TH * 32 * TG) * 4>(wb + TH * TG, wbuf0);
+      lload<TH + 1>(wa, wb, wbuf0);
     }
   }
   __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const f32x4 (&g)[4], uint32_t wbuf0) {
@@ -303,6 +329,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 
 #if BGNN_DIAG
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long t_clk0 = t_prev, t_real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // in-kernel clock probe
 #endif
   const BlockPos pos = decode_block<FT_H>(a.tb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -451,7 +478,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
   const uint32_t slab0 = lds_addr(slab);
-  const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r);
+  const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r * WTileGroup<NT>::TG);   // (column-permuted image: WTileGroup)
   // chunk (16 B) ownership of lane (r, hl) inside a 32-channel slab: exact-f32 path channel chunks 2j + hl (k = 8j + 4hl + i
   // of f32 k-step j); 16-bit MFMA paths channels 8hl..8hl+7 for k-step 0 and 16+8hl.. for k-step 1 (k = 16 step + 8hl + i)
   constexpr uint32_t CX1 = SP ? 16 : 32, CX2 = 64, CX3 = SP ? 80 : 96;
@@ -779,7 +806,12 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   }
   BGNN_STAMP(8)   // final epilogue
 #if BGNN_DIAG
-  if (a.stamps && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
+  if (a.stamps && threadIdx.x == 0) {
+    atomicAdd(a.stamps + 15, 1ull);
+    // shader cycles and 100 MHz reference ticks of this workgroup's lifetime: clock = cycles / ticks x 100 MHz
+    atomicAdd(a.stamps + 13, __builtin_amdgcn_s_memtime() - t_clk0);
+    atomicAdd(a.stamps + 14, __builtin_amdgcn_s_memrealtime() - t_real0);
+  }
 #endif
 }
 
@@ -841,13 +873,13 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   fill_common(a, g, L, xw, asd, L.concat ? 1 : 0);
   int split = ctx->opts.matrix_path;                                   // 0 exact, 1 bf16x3, 2 fp16x3 (opt-in), 3 bf16 storage
   if (split == 2 && !Ln.Wsp16) split = 1;                              // a weight beyond float16's range: bf16 split instead
-  a.Wt = split == 3 ? Ln.Wbf : split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wt;
+  a.Wt = split == 3 ? Ln.Wbf : split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wfp;
   a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
   ProfScope ps(ctx, BGNN_K_FUSED);
   const bool main_shape = (HC == 256 && NC == 256) || (HC == 256 && NC == 64);
   if (split == 3 && !main_shape) return BGNN_ERR_UNSUPPORTED;          // bf16 storage: the default model's shapes only
-  if ((split == 1 || split == 2) && (!main_shape || g->K == 16)) { split = 0; a.Wt = Ln.Wt; }   // other shapes: exact-f32 instances only
+  if ((split == 1 || split == 2) && (!main_shape || g->K == 16)) { split = 0; a.Wt = Ln.Wfp; }   // other shapes: exact-f32 instances only
 #define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
   BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
 #undef BGNN_FUSED_CASE
@@ -872,7 +904,7 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
   int split = ctx->opts.matrix_path;
   if (split == 2 && !m->hd_W0sp16) split = 1;
   if ((split == 1 || split == 2) && g->K == 16) split = 0;
-  a.Wt = split == 3 ? m->hd_W0bf : split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0t;
+  a.Wt = split == 3 ? m->hd_W0bf : split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0fp;
   a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
   a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;

@@ -26,3 +26,6 @@ n=buf[15]; names=["prologue ids","dma offs+issue","phase A","wait slab+bar","gat
 tot=sum(buf[i] for i in range(9))
 print("blocks",n, "total cycles/block", tot/n)
 for i,nm in enumerate(names): print("%-20s %10.0f cycles/block  %5.1f%%"%(nm, buf[i]/n, 100*buf[i]/tot))
+if buf[14]:
+    print("in-kernel clock: %.0f MHz (s_memtime / s_memrealtime x 100 MHz over every workgroup's lifetime)" % (100.0 * buf[13] / buf[14]))
+    print("workgroup lifetime: %.1f us" % (buf[14] / n / 100.0))
