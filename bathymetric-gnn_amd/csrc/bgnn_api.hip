@@ -254,6 +254,7 @@ int bgnn_ctx_destroy(bgnn_ctx *ctx) {
   for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto &st : ctx->staging) { (void)hipEventDestroy(st.ev); (void)hipHostFree(st.p); }
   for (int i = 0; i < 6; ++i) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  for (auto &e : ctx->table_cache) { (void)hipFree(e.d_tiles); (void)hipFree(e.d_items); }
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   ctx->pool.trim();
   for (auto &kv : ctx->pool.live) (void)hipFree(kv.first);
@@ -652,7 +653,8 @@ int bgnn_model_destroy(bgnn_model *m) {
 // ---- graph ------------------------------------------------------------------------------------
 static void graph_free(bgnn_graph *g) {
   DevPool &P = g->ctx->pool;
-  P.release(g->d_tiles); P.release(g->d_items); P.release(g->d_node_id); P.release(g->d_cell_of_node);
+  if (!g->tables_cached) { P.release(g->d_tiles); P.release(g->d_items); }
+  P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
   P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm); P.release(g->d_items2); P.release(g->d_items3);
   delete g;
@@ -670,14 +672,20 @@ static int validate_opts(const bgnn_graph_opts *o) {
   return BGNN_OK;
 }
 
+static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out, int64_t *n_nodes_copy);
+
 int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out) {
+  return graph_build_impl(ctx, tiles, opts, out, nullptr);
+}
+
+static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out, int64_t *n_nodes_copy) {
   BGNN_REQUIRE(ctx && tiles && opts && out, "bgnn_graph_build: NULL argument");
   BGNN_REQUIRE(tiles->n_tiles >= 1, "bgnn_graph_build: n_tiles=%d", tiles->n_tiles);
   BGNN_REQUIRE(tiles->hw && tiles->resolution && tiles->depth && tiles->mask, "bgnn_graph_build: NULL tile array");
   BGNN_TRY(validate_opts(opts));
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
   bgnn_graph *g = new bgnn_graph();
-  g->ctx = ctx; g->kind = 0; g->n_tiles = tiles->n_tiles;
+  g->ctx = ctx; g->kind = 0; g->n_tiles = tiles->n_tiles; g->d_n_nodes_copy = n_nodes_copy;
   g->K = opts->connectivity; g->ED = opts->n_edge_features; g->include_self_loops = opts->include_self_loops ? 1 : 0;
   g->has_unc = tiles->uncertainty ? 1 : 0;
   // feature count (see launch_graph_build for the column rule)
@@ -739,8 +747,42 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
   DevPool &P = ctx->pool;
   int rc = BGNN_OK;
 #define GALLOC(ptr, type, count) if (rc == BGNN_OK) { void *_p = nullptr; rc = P.alloc((size_t)(count) * sizeof(type), &_p); ptr = (type *)_p; }
-  GALLOC(g->d_tiles, BgnnTileMeta, g->n_tiles)
-  GALLOC(g->d_items, BgnnWorkItem, g->n_items)
+  // uniform batches at one resolution: the two tables come from (or go into) the context's cache
+  bgnn_ctx::TableCache *hit = nullptr;
+  bool cacheable = uniform;
+  for (int t = 1; t < tiles->n_tiles && cacheable; ++t)
+    cacheable = tiles->resolution[2 * t] == tiles->resolution[0] && tiles->resolution[2 * t + 1] == tiles->resolution[1];
+  if (cacheable)
+    for (auto &e : ctx->table_cache)
+      if (e.n_tiles == g->n_tiles && e.h == g->uni_h && e.w == g->uni_w && e.item_cells == item_cells &&
+          e.rx == tiles->resolution[0] && e.ry == tiles->resolution[1]) { hit = &e; break; }
+  if (hit) {
+    g->d_tiles = hit->d_tiles; g->d_items = hit->d_items; g->tables_cached = true;
+    hit->stamp = ++ctx->table_stamp;
+  } else if (cacheable) {
+    if (ctx->table_cache.size() >= 8) {                    // evict the least recently used entry (nothing in flight reads it
+      size_t lru = 0;                                      //  after a stream sync)
+      for (size_t i = 1; i < ctx->table_cache.size(); ++i) if (ctx->table_cache[i].stamp < ctx->table_cache[lru].stamp) lru = i;
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(ctx->table_cache[lru].d_tiles); (void)hipFree(ctx->table_cache[lru].d_items);
+      ctx->table_cache.erase(ctx->table_cache.begin() + lru);
+    }
+    bgnn_ctx::TableCache e{g->n_tiles, g->uni_h, g->uni_w, item_cells, tiles->resolution[0], tiles->resolution[1], nullptr, nullptr,
+                           g->n_items, ++ctx->table_stamp};
+    if (hipMalloc((void **)&e.d_tiles, sizeof(BgnnTileMeta) * g->n_tiles) == hipSuccess &&
+        hipMalloc((void **)&e.d_items, sizeof(BgnnWorkItem) * g->n_items) == hipSuccess) {
+      ctx->table_cache.push_back(e);
+      g->d_tiles = e.d_tiles; g->d_items = e.d_items; g->tables_cached = true;
+    } else {
+      (void)hipGetLastError();
+      if (e.d_tiles) (void)hipFree(e.d_tiles);
+      cacheable = false;
+    }
+  }
+  if (!g->tables_cached) {
+    GALLOC(g->d_tiles, BgnnTileMeta, g->n_tiles)
+    GALLOC(g->d_items, BgnnWorkItem, g->n_items)
+  }
   GALLOC(g->d_node_id, int32_t, cells)
   GALLOC(g->d_cell_of_node, int32_t, cells)
   GALLOC(g->d_counts, int64_t, 4)
@@ -753,8 +795,8 @@ int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_op
 #undef GALLOC
   if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items2.data(), sizeof(BgnnWorkItem) * items2.size(), g->d_items2);
   if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items3.data(), sizeof(BgnnWorkItem) * items3.size(), g->d_items3);
-  if (rc == BGNN_OK) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
-  if (rc == BGNN_OK) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
+  if (rc == BGNN_OK && !hit) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
+  if (rc == BGNN_OK && !hit) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
   if (rc == BGNN_OK) rc = launch_graph_build(ctx, g, tiles, opts);
   if (rc != BGNN_OK) { graph_free(g); return rc; }
   *out = g;
@@ -1071,7 +1113,7 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
                      int64_t *n_nodes_out) {
   BGNN_REQUIRE(ctx && m && tiles && opts, "bgnn_infer_tiles: NULL argument");
   bgnn_graph *g = nullptr;
-  BGNN_TRY(bgnn_graph_build(ctx, tiles, opts, &g));
+  BGNN_TRY(graph_build_impl(ctx, tiles, opts, &g, n_nodes_out));   // (the compaction scan writes the node count there itself)
   const int64_t rows = g->row_capacity;
   GridOut go;
   go.cls = classification; go.conf = confidence; go.corr = correction; go.norm_floor = norm_floor;
@@ -1093,9 +1135,6 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
         rc = launch_results_to_grids(g, o.predicted_class, o.confidence, o.correction, norm_floor, classification,
                                      confidence, correction);
     }
-    if (rc == BGNN_OK && n_nodes_out)
-      rc = hipMemcpyAsync(n_nodes_out, g->d_counts, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
-               ? BGNN_OK : BGNN_ERR_HIP;
   }
   graph_free(g);   // buffers return to the pool; stream order keeps them valid for the work already queued
   return rc;

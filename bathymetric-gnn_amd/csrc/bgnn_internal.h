@@ -106,6 +106,11 @@ struct bgnn_ctx {
   // other stream work; a buffer is reused once its event has completed
   struct Staging { void *p; size_t cap; hipEvent_t ev; bool in_flight; };
   std::vector<Staging> staging;
+  // tile / work-item tables of uniform batches, kept on the device across calls: a pipeline cuts thousands of batches of one
+  // shape, and a single-tile call should not pay two host->device copies for 4 KiB of tables
+  struct TableCache { int32_t n_tiles, h, w, item_cells; double rx, ry; BgnnTileMeta *d_tiles; BgnnWorkItem *d_items; int32_t n_items; uint64_t stamp; };
+  std::vector<TableCache> table_cache;
+  uint64_t table_stamp = 0;
   int num_cus = 256;
   float *zero_page = nullptr;   // 16 KiB: [0,4K) zeros, [4K,4K+128) diagnostic counters, [8K,16K) dump rows
   unsigned long long *stamps = nullptr;   // 16 diagnostic counters (inside the zero page allocation)
@@ -171,6 +176,8 @@ struct bgnn_graph {
   int32_t *d_node_id = nullptr;       // [cells]  >=0 node id ; <0 : -(prefix+1)
   int32_t *d_cell_of_node = nullptr;  // [cells]
   int64_t *d_counts = nullptr;        // [0]=n_nodes [1]=n_edges(valid after export scan)
+  int64_t *d_n_nodes_copy = nullptr;  // caller's copy of the node count (bgnn_infer_tiles: written by the compaction scan itself)
+  bool tables_cached = false;         // d_tiles / d_items belong to the context's table cache (uniform batches)
   float *d_x8 = nullptr;              // [rows][8]
   float *d_local_std = nullptr;       // [rows]
   int32_t *d_nbr = nullptr;           // grid: [rows][K] ; generic: col[E]

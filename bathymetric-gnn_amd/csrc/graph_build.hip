@@ -108,7 +108,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(V val, int64_
 }
 
 // single block: exclusive scan of block_sums in place, total -> *total (int64)
-__global__ __launch_bounds__(1024) void scan_spine_kernel(int32_t *block_sums, int n_blocks, int64_t *total) {
+__global__ __launch_bounds__(1024) void scan_spine_kernel(int32_t *block_sums, int n_blocks, int64_t *total, int64_t *total_copy = nullptr) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   if (threadIdx.x == 0) carry_s = 0;
@@ -132,7 +132,10 @@ __global__ __launch_bounds__(1024) void scan_spine_kernel(int32_t *block_sums, i
     if (threadIdx.x == 1023) carry_s = carry + woff + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = (int64_t)carry_s;
+  if (threadIdx.x == 0) {
+    *total = (int64_t)carry_s;
+    if (total_copy) *total_copy = (int64_t)carry_s;
+  }
 }
 
 // block-local exclusive prefix of the thread's first element; returns it
@@ -178,6 +181,54 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_nodes_kernel(MaskValu
   }
 }
 
+// Small batches (<= SCAN_SMALL_BLOCKS chunks, e.g. one 256 x 256 tile): ONE launch instead of reduce + spine + apply.  Every
+// block counts the valid cells of all chunks before its own by itself (<= 126 KiB of mask bytes, 16 per load) -- redundant work
+// that is far cheaper than two more dependent launches on an otherwise idle chip.  The last block writes the total.
+constexpr int SCAN_SMALL_BLOCKS = 64;
+__global__ __launch_bounds__(SCAN_THREADS) void scan_small_nodes_kernel(MaskValue val, int64_t n, int32_t *node_id,
+                                                                        int32_t *cell_of_node, int64_t *total, int64_t *total_copy) {
+  __shared__ int red[SCAN_THREADS / 64];
+  __shared__ int off_s;
+  const int64_t before = (int64_t)blockIdx.x * SCAN_CHUNK;            // cells in earlier chunks (a multiple of 16)
+  int c = 0;
+  const uint4 *m16 = reinterpret_cast<const uint4 *>(val.mask);
+  for (int64_t i = threadIdx.x; i < before / 16; i += SCAN_THREADS) {
+    const uint4 q = m16[i];                                            // 16 mask bytes, each 0 or 1 (any non-zero counts)
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      c += ((w[k] & 0xffu) != 0) + ((w[k] & 0xff00u) != 0) + ((w[k] & 0xff0000u) != 0) + ((w[k] & 0xff000000u) != 0);
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) t += red[w];
+    off_s = t;
+  }
+  __syncthreads();
+  const int64_t base = before + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+  int v[SCAN_PER_THREAD];
+  int p = off_s + block_exclusive(val, n, base, v);
+#pragma unroll
+  for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+    if (base + j < n) {
+      if (v[j]) {
+        node_id[base + j] = p;
+        cell_of_node[p] = (int32_t)(base + j);
+        ++p;
+      } else {
+        node_id[base + j] = -(p + 1);
+      }
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) {   // last thread of the last chunk
+    *total = (int64_t)p;
+    if (total_copy) *total_copy = (int64_t)p;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1a: masked 5x5 box statistics, float64, same operation order as scipy.ndimage.uniform_filter
 // (graph_construction.py:378-432): axis 0 then axis 1, each a zero-extended running sum
@@ -199,67 +250,85 @@ __device__ __forceinline__ void masked_vals(const float *depth, const uint8_t *m
 // output is produced by the prologue, every later step is "s += X(l+2) - X(l-3)" with zeros beyond the axis); the / 5.0 of
 // uniform_filter1d and the finalisation's divisions / square root are taken off the chain (independent per element).
 // A single 256 x 256 tile went from 190 + 140 us to ~10 + ~20 us.
-constexpr int STATV_CH = 32;
+constexpr int STATV_CH = 16;
 
-// one thread per (tile, column): vertical pass.  Stores RAW running sums (the reader divides by 5.0).
-__global__ __launch_bounds__(64) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
-                                                     const uint8_t *mask, double *vs, double *vc, double *vq) {
+// vertical pass: 64 columns per 256-thread workgroup.  Outputs are produced in chunks of 16 rows (l = 1 + chunk + j); the rows
+// that ENTER those windows (l + 2) are loaded one chunk ahead by all four waves (row-major, coalesced) into a double-buffered
+// LDS tile; wave 0 (thread = column) runs the three running sums from LDS and parks the RAW sums (the reader divides by 5.0)
+// in an LDS tile that all four waves then write out.  Nothing but the additions is on the serial chain, and the chain's wave
+// issues no global memory operation inside the loop.
+__global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
+                                                      const uint8_t *mask, double *vs, double *vc, double *vq) {
+  __shared__ float in_d[2][STATV_CH * 64];
+  __shared__ uint8_t in_m[2][STATV_CH * 64];
+  __shared__ double outt[3][STATV_CH * 64];
   const BgnnTileMeta t = tiles[blockIdx.y];
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= t.w) return;
-  const int h = t.h, w = t.w;
-  const int64_t base = (int64_t)t.cell_off + c;
-  float nd[STATV_CH];                                  // rows fetched one chunk ahead: depth ...
-  uint32_t nm[STATV_CH];                               // ... and mask bytes, combined into bits only when the chunk is consumed
-  int nvalid = 0;                                      // rows of the fetched chunk that lie inside the tile
-  auto fetch = [&](int r0) {                           // rows r0 .. r0 + STATV_CH - 1 (rows >= h read row h - 1, cleared on use)
+  const int c0 = blockIdx.x * 64;
+  if (c0 >= t.w) return;                               // (uniform)
+  const int h = t.h, w = t.w, tid = threadIdx.x;
+  const int lc = tid & 63, lr = tid >> 6;              // loader / writer role: column lc, rows lr + 4k (k < 4) of a chunk
+  const bool col_ok = c0 + lc < w;
+  const int64_t base = (int64_t)t.cell_off + c0 + (col_ok ? lc : 0);
+  float pd[STATV_CH / 4]; uint32_t pm[STATV_CH / 4];   // chunk fetched ahead
+  auto fetch = [&](int r0) {                           // rows r0 .. r0 + 15 (rows >= h read row h - 1 and are cleared)
 #pragma unroll
-    for (int j = 0; j < STATV_CH; ++j) {
-      const int r = r0 + j;
+    for (int k = 0; k < STATV_CH / 4; ++k) {
+      const int r = r0 + lr + 4 * k;
       const int64_t o = base + (int64_t)(r < h ? r : h - 1) * w;
-      nd[j] = depth[o];
-      nm[j] = mask[o];
+      pd[k] = depth[o];
+      pm[k] = mask[o];
     }
-    nvalid = h - r0;
-    // every load above is ISSUED before anything below; the waits then sit at the first use, one chunk later (without this the
-    // compiler pairs each load with its use and waits per row)
-    asm volatile("" ::: "memory");
+    asm volatile("" ::: "memory");                     // every load is issued before anything below
   };
   fetch(3);
-  // initial window: rows 0..2 in ascending order (rows < 0 contribute nothing) = output 0
+  // wave 0, thread = column: initial window, rows 0..2 in ascending order (rows < 0 contribute nothing) = output 0
+  const bool chain = tid < 64;
   double hv[5], hc[5], hq[5];                          // hv[k] = X(last entered row - k); X = (value, count, square), 0 if masked
 #pragma unroll
   for (int k = 0; k < 5; ++k) { hv[k] = 0.0; hc[k] = 0.0; hq[k] = 0.0; }
   double s = 0.0, n = 0.0, q = 0.0;
+  if (chain) {
 #pragma unroll
-  for (int r = 0; r <= 2; ++r) {
-    double a = 0.0, b = 0.0, d = 0.0;
-    if (r < h) masked_vals(depth, mask, base + (int64_t)r * w, a, b, d);
-    s += a; n += b; q += d;
-    hv[2 - r] = a; hc[2 - r] = b; hq[2 - r] = d;
+    for (int r = 0; r <= 2; ++r) {
+      double a = 0.0, b = 0.0, d = 0.0;
+      if (r < h) masked_vals(depth, mask, base + (int64_t)r * w, a, b, d);
+      s += a; n += b; q += d;
+      hv[2 - r] = a; hc[2 - r] = b; hq[2 - r] = d;
+    }
+    if (col_ok) { vs[base] = s; vc[base] = n; vq[base] = q; }
   }
-  vs[base] = s; vc[base] = n; vq[base] = q;
-  // outputs l = 1 + chunk + j: row l + 2 enters, row l - 3 (= five entries back) leaves
-  for (int l0 = 1; l0 < h; l0 += STATV_CH) {
-    float cd[STATV_CH];
-    uint32_t cmask = 0;
+  int buf = 0;
+  for (int l0 = 1; l0 < h; l0 += STATV_CH, buf ^= 1) {
 #pragma unroll
-    for (int j = 0; j < STATV_CH; ++j) { cd[j] = nd[j]; cmask |= (nm[j] != 0 ? 1u : 0u) << j; }
-    cmask &= nvalid >= STATV_CH ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << nvalid) - 1u);
+    for (int k = 0; k < STATV_CH / 4; ++k) {
+      const int j = lr + 4 * k;
+      in_d[buf][j * 64 + lc] = pd[k];
+      in_m[buf][j * 64 + lc] = (l0 + 2 + j < h && pm[k]) ? (uint8_t)1 : (uint8_t)0;   // entering row l0 + j + 2
+    }
     if (l0 + STATV_CH < h) fetch(l0 + STATV_CH + 2);   // next chunk's loads fly under this chunk's chain
+    __syncthreads();
+    if (chain) {
 #pragma unroll
-    for (int j = 0; j < STATV_CH; ++j) {
-      const bool on = (cmask >> j) & 1u;
-      const double d = (double)cd[j];
-      const double a1 = on ? d : 0.0, b1 = on ? 1.0 : 0.0, d1 = on ? d * d : 0.0;
-      s += (a1 - hv[4]); n += (b1 - hc[4]); q += (d1 - hq[4]);
+      for (int j = 0; j < STATV_CH; ++j) {
+        const bool on = in_m[buf][j * 64 + tid] != 0;
+        const double d = (double)in_d[buf][j * 64 + tid];
+        const double a1 = on ? d : 0.0, b1 = on ? 1.0 : 0.0, d1 = on ? d * d : 0.0;
+        s += (a1 - hv[4]); n += (b1 - hc[4]); q += (d1 - hq[4]);
 #pragma unroll
-      for (int k = 4; k > 0; --k) { hv[k] = hv[k - 1]; hc[k] = hc[k - 1]; hq[k] = hq[k - 1]; }
-      hv[0] = a1; hc[0] = b1; hq[0] = d1;
-      const int l = l0 + j;
-      if (l < h) {
-        const int64_t o = base + (int64_t)l * w;
-        vs[o] = s; vc[o] = n; vq[o] = q;
+        for (int k = 4; k > 0; --k) { hv[k] = hv[k - 1]; hc[k] = hc[k - 1]; hq[k] = hq[k - 1]; }
+        hv[0] = a1; hc[0] = b1; hq[0] = d1;
+        outt[0][j * 64 + tid] = s; outt[1][j * 64 + tid] = n; outt[2][j * 64 + tid] = q;
+      }
+    }
+    __syncthreads();
+    if (col_ok) {
+#pragma unroll
+      for (int k = 0; k < STATV_CH / 4; ++k) {           // RAW running sums: the / 5.0 of uniform_filter1d is taken by the reader
+        const int j = lr + 4 * k, l = l0 + j;
+        if (l < h) {
+          const int64_t o = base + (int64_t)l * w;
+          vs[o] = outt[0][j * 64 + lc]; vc[o] = outt[1][j * 64 + lc]; vq[o] = outt[2][j * 64 + lc];
+        }
       }
     }
   }
@@ -638,14 +707,14 @@ __global__ void results_to_grids_kernel(const int32_t *node_id, int64_t n_cells,
 // host side
 // ------------------------------------------------------------------------------------------
 template <class V>
-static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_out, int64_t *total_dev) {
+static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_out, int64_t *total_dev, int64_t *total_copy = nullptr) {
   int n_blocks = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
   if (n_blocks < 1) n_blocks = 1;
   void *bs;
   BGNN_TRY(ctx_workspace(ctx, 5, (size_t)n_blocks * sizeof(int32_t), &bs));
   hipLaunchKernelGGL(scan_reduce_kernel<V>, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, val, n,
                      (int32_t *)bs);
-  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)bs, n_blocks, total_dev);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)bs, n_blocks, total_dev, total_copy);
   *block_off_out = (int32_t *)bs;
   return BGNN_OK;
 }
@@ -657,11 +726,16 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
   {
     ProfScope ps(ctx, BGNN_K_SCAN);
     MaskValue mv{tiles->mask};
-    int32_t *block_off;
-    BGNN_TRY(run_scan_counts(ctx, mv, cells, &block_off, g->d_counts));
     int n_blocks = (int)((cells + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    hipLaunchKernelGGL(scan_apply_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
-                       block_off, g->d_node_id, g->d_cell_of_node);
+    if (n_blocks <= SCAN_SMALL_BLOCKS && ((uintptr_t)tiles->mask & 15) == 0) {
+      hipLaunchKernelGGL(scan_small_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
+                         g->d_node_id, g->d_cell_of_node, g->d_counts, g->d_n_nodes_copy);
+    } else {
+      int32_t *block_off;
+      BGNN_TRY(run_scan_counts(ctx, mv, cells, &block_off, g->d_counts, g->d_n_nodes_copy));
+      hipLaunchKernelGGL(scan_apply_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
+                         block_off, g->d_node_id, g->d_cell_of_node);
+    }
   }
   // 2. box statistics
   double *vs, *vc, *vq;
@@ -677,7 +751,7 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
   for (auto &t : g->h_tiles) { if (t.h > max_h) max_h = t.h; if (t.w > max_w) max_w = t.w; }
   {
     ProfScope ps(ctx, BGNN_K_STATS);
-    hipLaunchKernelGGL(stats_v_kernel, dim3((max_w + 63) / 64, g->n_tiles), dim3(64), 0, ctx->stream, g->d_tiles,
+    hipLaunchKernelGGL(stats_v_kernel, dim3((max_w + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
                        tiles->depth, tiles->mask, vs, vc, vq);
     double *hs = vq + cells, *hn = hs + cells, *hq2 = hn + cells;
     hipLaunchKernelGGL(stats_h_kernel, dim3((max_h + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
