@@ -144,7 +144,7 @@ __device__ __forceinline__ void lds_read_frags(float *dst, uint32_t addr) {
     dst[0] = lds_read1<OFF>(addr);
   }
 }
-template <int NT, int NC, int M, int END = 8>
+template <int NT, int NC, int M, int END = 8, bool ZC = false>   // ZC: the first k row starts the accumulators from an inline 0
 struct MfmaGroups {
   static constexpr int ROW = 8 * (M / 2) + 2 * (M & 1);
   static constexpr int TG = WTileGroup<NT>::TG;
@@ -170,7 +170,14 @@ struct MfmaGroups {
     float na[NT], nb[NT];
     if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::load(na, nb, wbuf0);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (ZC) {             // the block's very first MFMAs: C = 0 as an inline constant -- no 16 NT v_mov to clear the accumulators
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], z, 0, 0, 0);
+      } else {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], acc[t], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t], g[M / 2][2 * (M & 1) + 1], acc[t], 0, 0, 0);
     if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::step(acc, g, wbuf0, na, nb);
@@ -332,7 +339,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   const unsigned long long t_clk0 = t_prev, t_real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // in-kernel clock probe
 #endif
   const BlockPos pos = decode_block<FT_H>(a.tb);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a SCALAR: LDS-DMA destinations (M0) and the "does this wave move piece q" tests then stay on the scalar
+  // unit instead of costing a v_readfirstlane / exec-mask sequence per DMA in the slab loop
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hl = lane >> 5;
   const int cell = wave * 32 + r;                      // block-local cell of this lane
   const int tr = cell / TILE_W, tc = cell % TILE_W;
@@ -399,27 +409,28 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o));
     id0 = __builtin_amdgcn_readfirstlane(m);             // 0x7fffffff: the wave's rows hold no node
   }
-  uint32_t doff[NPIECE];
+  // Per piece ONE 64-bit source base for the whole block: rows without a node read the context's zero page, which holds
+  // more than NSLAB * ROWB zero bytes, so that they can advance by ROWB per slab exactly like real rows (no per-slab select)
+  // and EVERY wave issues a fixed number of slab pieces (npc): the counted waits below can leave exactly the next slab in flight.
+  static_assert(NSLAB * ROWB <= 4096, "the zero page covers a whole block's worth of slab offsets");
+  const char *xbase = reinterpret_cast<const char *>(a.xw) + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * (HC * XB);
+  const char *zp = reinterpret_cast<const char *>(a.zero_page);
+  const char *dbase[NPIECE];
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) {
     const int idx = p * NTH + tid;
     const int row = idx / CPR, c = (idx % CPR) ^ swz(row);
-    doff[p] = drow[p] >= 0 ? (uint32_t)(drow[p] - id0) * (uint32_t)(HC * XB) + (uint32_t)(c * 16) : 0xffffffffu;
+    dbase[p] = drow[p] >= 0 ? xbase + ((uint32_t)(drow[p] - id0) * (uint32_t)(HC * XB) + (uint32_t)(c * 16)) : zp;
   }
-  const char *xbase = reinterpret_cast<const char *>(a.xw) + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * (HC * XB);
-  // Rows without a node read the context's zero page, so that EVERY wave issues a fixed number of slab pieces
-  // (npc) and the counted waits below can leave exactly the next slab in flight.
-  const char *zp = reinterpret_cast<const char *>(a.zero_page);
   int npc = 0;
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) npc += (p * NTH + wave * 64 < HR * CPR) ? 1 : 0;
   auto issue_slab = [&](int s) {
-    const char *sb = xbase + s * ROWB;                 // wave-uniform
+    const int sb = s * ROWB;                           // wave-uniform
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) {
-      if (p * NTH + tid < HR * CPR) {
-        const char *src = doff[p] != 0xffffffffu ? sb + doff[p] : zp;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src),
+      if ((p + 1) * NTH <= HR * CPR || p * NTH + tid < HR * CPR) {        // (only the last piece is partial: compile-time true before)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(dbase[p] + sb),
                                          (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
       }
     }
@@ -472,10 +483,12 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 
   BGNN_STAMP(2)   // phase A
   f32x16 acc[NT];
+  if constexpr (SP != 0 || BGNN_DIAG) {                  // (exact path: slab 0's first MFMAs start from an inline zero instead)
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+  }
 
   const uint32_t slab0 = lds_addr(slab);
   const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r * WTileGroup<NT>::TG);   // (column-permuted image: WTileGroup)
@@ -614,6 +627,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       if (!DBG(2)) {
         if constexpr (SP == 3) Bf16Tiles<NT, 0>::run(acc, xh0, wsp0);
         else if constexpr (SP != 0) SplitTiles<NT, 0, LP8>::run(acc, xh0, xl0, wsp0);
+        else if (s == 0 && !BGNN_DIAG) MfmaGroups<NT, NC, 0, 4, true>::run(acc, g, wbuf0);
         else MfmaGroups<NT, NC, 0, 4>::run(acc, g, wbuf0);
       }
       // WB(s) landed; the npc pieces of slab s+1 issued above stay in flight
