@@ -196,6 +196,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.matrix_path = getenv("BGNN_BF16") ? 3 : getenv("BGNN_SPLIT_F16") ? 2 : getenv("BGNN_SPLIT_BF16") ? 1 : 0;
     o.fused = getenv("BGNN_NO_FUSED") ? 0 : 1;
     o.fold_extractor = getenv("BGNN_NO_FOLD") ? 0 : 1;
+    o.ragged_atlas = getenv("BGNN_NO_ATLAS") ? 0 : 1;
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
@@ -210,7 +211,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
 static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
-      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor},
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
@@ -657,6 +658,7 @@ static void graph_free(bgnn_graph *g) {
   P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
   P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm); P.release(g->d_items2); P.release(g->d_items3);
+  P.release(g->d_atlas); P.release(g->d_atlas_tile); P.release(g->d_atlas_pos);
   delete g;
 }
 
@@ -743,6 +745,28 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
         for (int c0 = 0; c0 < g->h_tiles[t].w; c0 += 16) items3.push_back({t, r0, c0, 0});
     g->n_blocks3 = (int32_t)items3.size();
   }
+  // ragged batch: shelf-pack the grids (tallest first) onto a canvas for the fused layer kernels
+  std::vector<int32_t> atlas_pos;
+  BgnnTileMeta atlas_meta{};
+  if (!uniform && tiles->n_tiles >= 2 && ctx->opts.ragged_atlas) {
+    const int G = g->K == 16 ? 2 : 1;                                   // gutter = reach of the stencil
+    int aw = 64;
+    while ((int64_t)aw * aw < cells + cells / 3 && aw < 2048) aw += 64;
+    aw = std::max(aw, ((g->max_w + G + 15) / 16) * 16);
+    std::vector<int> order(tiles->n_tiles);
+    for (int t = 0; t < tiles->n_tiles; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return g->h_tiles[a].h > g->h_tiles[b].h; });
+    atlas_pos.assign((size_t)tiles->n_tiles * 2, 0);
+    int x = 0, y = 0, shelf = 0;
+    for (int t : order) {
+      const int h = g->h_tiles[t].h, w = g->h_tiles[t].w;
+      if (x + w > aw) { y += shelf + G; x = 0; shelf = 0; }
+      atlas_pos[2 * t] = y; atlas_pos[2 * t + 1] = x;
+      x += w + G; shelf = std::max(shelf, h);
+    }
+    g->atlas_w = aw; g->atlas_h = ((y + shelf + 7) / 8) * 8;
+    atlas_meta.h = g->atlas_h; atlas_meta.w = g->atlas_w; atlas_meta.cell_off = 0; atlas_meta.rx = 1.0; atlas_meta.ry = 1.0;
+  }
   g->total_cells = (int32_t)cells; g->row_capacity = (int32_t)cells; g->n_items = (int32_t)items.size();
   DevPool &P = ctx->pool;
   int rc = BGNN_OK;
@@ -790,9 +814,16 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
   GALLOC(g->d_local_std, float, cells)
   GALLOC(g->d_nbr, int32_t, cells * g->K)
   GALLOC(g->d_eattr, float, cells * g->K * g->ED)
+  if (g->atlas_h) {
+    GALLOC(g->d_atlas, int32_t, (size_t)g->atlas_h * g->atlas_w)
+    GALLOC(g->d_atlas_tile, BgnnTileMeta, 1)
+    GALLOC(g->d_atlas_pos, int32_t, atlas_pos.size())
+  }
   if (!uniform) GALLOC(g->d_items2, BgnnWorkItem, items2.size())
   if (!uniform) GALLOC(g->d_items3, BgnnWorkItem, items3.size())
 #undef GALLOC
+  if (rc == BGNN_OK && g->atlas_h) rc = ctx_upload(ctx, &atlas_meta, sizeof(atlas_meta), g->d_atlas_tile);
+  if (rc == BGNN_OK && g->atlas_h) rc = ctx_upload(ctx, atlas_pos.data(), sizeof(int32_t) * atlas_pos.size(), g->d_atlas_pos);
   if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items2.data(), sizeof(BgnnWorkItem) * items2.size(), g->d_items2);
   if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items3.data(), sizeof(BgnnWorkItem) * items3.size(), g->d_items3);
   if (rc == BGNN_OK && !hit) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
@@ -1128,6 +1159,12 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
     const bool try_fused = ctx->opts.fused && g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->ED == 3 &&
                            m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
+    if (try_fused && g->d_atlas) {          // the canvas walk writes valid cells only: clear the grids (fill 0.0) first
+      const size_t nb = (size_t)g->total_cells * sizeof(float);
+      if (classification) BGNN_HIP_CHECK(hipMemsetAsync(classification, 0, nb, ctx->stream));
+      if (confidence) BGNN_HIP_CHECK(hipMemsetAsync(confidence, 0, nb, ctx->stream));
+      if (correction) BGNN_HIP_CHECK(hipMemsetAsync(correction, 0, nb, ctx->stream));
+    }
     rc = forward_impl(ctx, m, g, thr_auto, thr_review, try_fused ? &none : &o, &go);
     if (rc == BGNN_OK && !go.done) {
       if (try_fused) rc = forward_impl(ctx, m, g, thr_auto, thr_review, &o, nullptr);   // (not reached in practice)

@@ -76,6 +76,7 @@ struct BgnnOpts {
   int matrix_path = 0;       // 0 exact f32, 1 bf16x3, 2 fp16x3 (opt-in operand-split matrix paths), 3 bf16 activation storage + bf16 MFMA
   int fused = 1;             // 0: K3 / K4 / K5 / K6 as separate kernels
   int fold_extractor = 1;    // 0: run the extractor's second Linear and lin of layer 0 unfolded
+  int ragged_atlas = 1;      // ragged batches: fused layers walk a shelf-packed canvas of the grids (0: per-grid 8x16 blocks)
   int fused_lds_pad_kb = 0;    // experiment: pad the fused kernel's LDS request (occupancy)
   int diag_mask = 0;         // BGNN_DIAG builds only: phase ablation bits of the fused kernel
   int diag_stamps = 0;       // BGNN_DIAG builds only: per-phase s_memtime sums
@@ -197,6 +198,13 @@ struct bgnn_graph {
   BgnnWorkItem *d_items3 = nullptr;
   int32_t n_blocks3 = 0, bh3 = 0, bw3 = 0;
   int32_t max_w = 0;
+  // Atlas of a RAGGED batch (refinement grids of 3..50 cells a side): the grids are shelf-packed, with a gutter of invalid cells
+  // as wide as the stencil's reach, into one canvas whose 8x16 blocks the fused layer kernels walk instead of per-grid blocks
+  // (which are 68 % full on config 4's grids; the canvas is ~85 % full).  d_atlas[canvas cell] = node id or -1.
+  int32_t *d_atlas = nullptr;
+  BgnnTileMeta *d_atlas_tile = nullptr;   // the canvas as ONE tile {h, w, cell_off = 0}
+  int32_t *d_atlas_pos = nullptr;         // [n_tiles][2] = (row, column) of each grid's origin on the canvas
+  int32_t atlas_h = 0, atlas_w = 0;
 };
 
 namespace bgnn {

@@ -58,6 +58,7 @@ enum { EPI_NEXT = 0, EPI_HEADS = 1 };
 struct FusedArgs {
   TileBlocks tb;
   const int32_t *node_id;
+  const int32_t *cell_map; // ragged-batch canvas: original cell of each node (the grids are written through it); else nullptr
   const void *xw;         // [rows][HC]   this layer's lin(x): f32, or bf16 with SP = 3
   const float *asd;       // [rows][2H]
   const float *eattr;     // [rows][K][3]
@@ -370,6 +371,12 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   if (!DBG(32)) {
     const int gr = pos.r0 + tr, gc = pos.c0 + tc;
     if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
+  }
+  if (a.cell_map) {                  // canvas walk (wave-uniform test): blocks that hold only gutter / free space leave here
+    if (!__syncthreads_or(my_pre >= 0)) {
+      __builtin_amdgcn_s_waitcnt(0);   // the W DMAs land in this WG's LDS: drain them before the LDS can be handed on
+      return;
+    }
   }
   int drow[NPIECE];
 #pragma unroll
@@ -769,8 +776,9 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       sr += __shfl_xor(sr, 32);
       const int gr = pos.r0 + mr, gc = pos.c0 + mc;
       const bool inside = gr < pos.h && gc < pos.w;
-      if (hl == 0 && inside) {
-        const int64_t cidx = pos.cell_off + (int64_t)gr * pos.w + gc;
+      if (hl == 0 && inside && (!a.cell_map || id >= 0)) {
+        // (canvas walk: only valid cells have an original position; the caller cleared the grids)
+        const int64_t cidx = a.cell_map ? (int64_t)a.cell_map[id] : pos.cell_off + (int64_t)gr * pos.w + gc;
         float fcls = 0.f, fconf = 0.f, fcorr = 0.f;
         if (id >= 0) {
           float mx = -__builtin_inff();
@@ -871,7 +879,13 @@ static bool fused_supported(const bgnn_graph *g, int C, int ED) {
 static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, const void *xw, const float *asd, int relu) {
   a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items3;
   a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
-  a.node_id = g->d_node_id; a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
+  a.node_id = g->d_node_id; a.cell_map = nullptr;
+  if (g->d_atlas) {                  // ragged batch: walk the shelf-packed canvas (one "tile") instead of per-grid blocks
+    a.tb.tiles = g->d_atlas_tile; a.tb.items2 = nullptr;
+    a.tb.bh = g->atlas_h / 8; a.tb.bw = g->atlas_w / 16; a.tb.n_blocks = a.tb.bh * a.tb.bw;
+    a.node_id = g->d_atlas; a.cell_map = g->d_cell_of_node;
+  }
+  a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
   a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
   a.dbg = BGNN_DIAG ? g->ctx->opts.diag_mask : 0;
   a.stamps = BGNN_DIAG && g->ctx->opts.diag_stamps ? g->ctx->stamps : nullptr;

@@ -719,6 +719,19 @@ static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_
   return BGNN_OK;
 }
 
+// canvas cell of every grid cell: atlas[(row0 + r) * AW + col0 + c] = node id (gutters / free space stay -1)
+__global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *pos, int atlas_w,
+                                                         const int32_t *node_id, int64_t cells, int32_t *atlas) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cells) return;
+  const int id = node_id[i];
+  if (id < 0) return;
+  const int t = find_tile(tiles, n_tiles, i);
+  const BgnnTileMeta tm = tiles[t];
+  const int rel = (int)(i - tm.cell_off), r = rel / tm.w, c = rel - r * tm.w;
+  atlas[(int64_t)(pos[2 * t] + r) * atlas_w + pos[2 * t + 1] + c] = id;
+}
+
 int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts) {
   const Stencil st = make_stencil(opts->connectivity);
   const int64_t cells = g->total_cells;
@@ -736,6 +749,11 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
       hipLaunchKernelGGL(scan_apply_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
                          block_off, g->d_node_id, g->d_cell_of_node);
     }
+  }
+  if (g->d_atlas) {
+    BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas, 0xff, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(atlas_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles, g->n_tiles,
+                       g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas);
   }
   // 2. box statistics
   double *vs, *vc, *vq;

@@ -753,3 +753,32 @@ def test_batches_dealt_over_two_contexts_give_the_same_grids(gpu_device):
         torch.cuda.synchronize()
         for o, r in zip(outs, ref):
             assert torch.equal(o, r)
+
+
+@pytest.mark.parametrize("connectivity,path", [("8-connected", "exact_f32"), ("4-connected", "exact_f32"), ("16-dilated", "exact_f32"), ("16-dilated", "bf16")])
+def test_ragged_batch_canvas_walk_equals_per_grid_blocks(connectivity, path, gpu_device):
+    """Ragged batches (VR refinement grids): the fused layers walk a shelf-packed canvas of the grids (option
+    ragged_atlas, default on).  Packing only changes which 8x16 block a node is computed in, so the grids must equal the
+    per-grid-block walk bit for bit -- every stencil, both storage types, grids down to 2x2 and wider than the default canvas."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    model = _model(synthetic.synthetic_state_dict(in_channels=8, seed=1234), in_channels=8)
+    gb = GraphBuilder(device=gpu_device, connectivity=connectivity)
+    eng = TileBatchEngine(model, gb, gpu_device)
+    rng = np.random.default_rng(5)
+    shapes = [(int(rng.integers(3, 51)), int(rng.integers(3, 51))) for _ in range(60)] + [(2, 2), (2, 90), (70, 3), (3, 300), (50, 50)]
+    grids = [synthetic.synthetic_tile(h, w, 300 + i, "V1" if min(h, w) >= 20 else "V0") for i, (h, w) in enumerate(shapes)]
+    depth = [g[0] for g in grids]; mask = [g[1] for g in grids]; unc = [np.abs(g[0]) * 0.01 for g in grids]
+    hw, res, d, m, u = gb.upload_tiles(depth, mask, unc, [(0.7, 0.9)] * len(grids))
+    ctx = rt.get_context(gpu_device)
+    _set_matrix_path(path)
+    try:
+        ctx.set_option("ragged_atlas", 1)
+        a = eng.infer_device(hw, res, d, m, u).clone()
+        ctx.set_option("ragged_atlas", 0)
+        b = eng.infer_device(hw, res, d, m, u).clone()
+    finally:
+        ctx.set_option("ragged_atlas", 1)
+    assert torch.equal(a, b)
+    assert set(np.unique(a[0].cpu().numpy())) <= {0.0, 1.0, 2.0} and float(a[1].max()) > 0
