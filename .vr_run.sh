@@ -1,7 +1,6 @@
-set -e
 cd /root/repo
-timeout -k 10 600 python -m pytest tests/test_gpu_forward.py tests/test_gpu_vr_bag.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -5
 for s in 1 4; do
-timeout -k 10 300 python bench.py --workload vr --vr-streams $s --no-extras 2>&1 | tail -1
-timeout -k 10 300 python bench.py --workload vr --vr-budget 1000000 --vr-streams $s --no-extras 2>&1 | tail -1
+timeout -k 10 300 python bench.py --workload vr --vr-streams $s --no-extras 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value']/1e6, j['ms_per_step'], j['config']['workload'][:120], {k:round(v['ms_per_step'],2) for k,v in j['kernels'].items()})"
+timeout -k 10 300 python bench.py --workload vr --vr-budget 1000000 --vr-streams $s --no-extras 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value']/1e6, j['ms_per_step'], j['config']['workload'][:120], {k:round(v['ms_per_step'],2) for k,v in j['kernels'].items()})"
 done
+timeout -k 10 300 python tools/vr_streams_probe.py

@@ -654,11 +654,12 @@ int bgnn_model_destroy(bgnn_model *m) {
 // ---- graph ------------------------------------------------------------------------------------
 static void graph_free(bgnn_graph *g) {
   DevPool &P = g->ctx->pool;
-  if (!g->tables_cached) { P.release(g->d_tiles); P.release(g->d_items); }
+  if (g->d_tables) P.release(g->d_tables);       // ragged batch: tiles / items / items2 / items3 / canvas tables live in this block
+  else if (!g->tables_cached) { P.release(g->d_tiles); P.release(g->d_items); }
   P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
-  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm); P.release(g->d_items2); P.release(g->d_items3);
-  P.release(g->d_atlas); P.release(g->d_atlas_tile); P.release(g->d_atlas_pos);
+  P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm);
+  P.release(g->d_atlas);
   delete g;
 }
 
@@ -803,7 +804,34 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
       cacheable = false;
     }
   }
-  if (!g->tables_cached) {
+  // ragged batches: every host-built table travels in ONE block (one staging copy, one H2D) -- with 50 000-node VR batches
+  // the per-batch host work is what bounds the stream
+  std::vector<char> blockh;
+  size_t o_tiles = 0, o_items = 0, o_items2 = 0, o_items3 = 0, o_atile = 0, o_apos = 0;
+  if (!uniform) {
+    auto put = [&](const void *p, size_t bytes) {
+      const size_t at = (blockh.size() + 255) & ~(size_t)255;
+      blockh.resize(at + bytes);
+      memcpy(blockh.data() + at, p, bytes);
+      return at;
+    };
+    o_tiles = put(g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles);
+    o_items = put(items.data(), sizeof(BgnnWorkItem) * items.size());
+    o_items2 = put(items2.data(), sizeof(BgnnWorkItem) * items2.size());
+    if (g->atlas_h) {
+      o_atile = put(&atlas_meta, sizeof(atlas_meta));
+      o_apos = put(atlas_pos.data(), sizeof(int32_t) * atlas_pos.size());
+    } else {
+      o_items3 = put(items3.data(), sizeof(BgnnWorkItem) * items3.size());
+    }
+    GALLOC(g->d_tables, char, blockh.size())
+    if (rc == BGNN_OK) {
+      g->d_tiles = (BgnnTileMeta *)(g->d_tables + o_tiles); g->d_items = (BgnnWorkItem *)(g->d_tables + o_items);
+      g->d_items2 = (BgnnWorkItem *)(g->d_tables + o_items2);
+      if (g->atlas_h) { g->d_atlas_tile = (BgnnTileMeta *)(g->d_tables + o_atile); g->d_atlas_pos = (int32_t *)(g->d_tables + o_apos); }
+      else g->d_items3 = (BgnnWorkItem *)(g->d_tables + o_items3);
+    }
+  } else if (!g->tables_cached) {
     GALLOC(g->d_tiles, BgnnTileMeta, g->n_tiles)
     GALLOC(g->d_items, BgnnWorkItem, g->n_items)
   }
@@ -814,20 +842,11 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
   GALLOC(g->d_local_std, float, cells)
   GALLOC(g->d_nbr, int32_t, cells * g->K)
   GALLOC(g->d_eattr, float, cells * g->K * g->ED)
-  if (g->atlas_h) {
-    GALLOC(g->d_atlas, int32_t, (size_t)g->atlas_h * g->atlas_w)
-    GALLOC(g->d_atlas_tile, BgnnTileMeta, 1)
-    GALLOC(g->d_atlas_pos, int32_t, atlas_pos.size())
-  }
-  if (!uniform) GALLOC(g->d_items2, BgnnWorkItem, items2.size())
-  if (!uniform) GALLOC(g->d_items3, BgnnWorkItem, items3.size())
+  if (g->atlas_h) GALLOC(g->d_atlas, int32_t, (size_t)g->atlas_h * g->atlas_w)
 #undef GALLOC
-  if (rc == BGNN_OK && g->atlas_h) rc = ctx_upload(ctx, &atlas_meta, sizeof(atlas_meta), g->d_atlas_tile);
-  if (rc == BGNN_OK && g->atlas_h) rc = ctx_upload(ctx, atlas_pos.data(), sizeof(int32_t) * atlas_pos.size(), g->d_atlas_pos);
-  if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items2.data(), sizeof(BgnnWorkItem) * items2.size(), g->d_items2);
-  if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, items3.data(), sizeof(BgnnWorkItem) * items3.size(), g->d_items3);
-  if (rc == BGNN_OK && !hit) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
-  if (rc == BGNN_OK && !hit) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
+  if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, blockh.data(), blockh.size(), g->d_tables);
+  if (rc == BGNN_OK && uniform && !hit) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);
+  if (rc == BGNN_OK && uniform && !hit) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
   if (rc == BGNN_OK) rc = launch_graph_build(ctx, g, tiles, opts);
   if (rc != BGNN_OK) { graph_free(g); return rc; }
   *out = g;
@@ -1161,9 +1180,13 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
                            m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
     if (try_fused && g->d_atlas) {          // the canvas walk writes valid cells only: clear the grids (fill 0.0) first
       const size_t nb = (size_t)g->total_cells * sizeof(float);
-      if (classification) BGNN_HIP_CHECK(hipMemsetAsync(classification, 0, nb, ctx->stream));
-      if (confidence) BGNN_HIP_CHECK(hipMemsetAsync(confidence, 0, nb, ctx->stream));
-      if (correction) BGNN_HIP_CHECK(hipMemsetAsync(correction, 0, nb, ctx->stream));
+      if (classification && confidence == classification + g->total_cells && correction == confidence + g->total_cells) {
+        BGNN_HIP_CHECK(hipMemsetAsync(classification, 0, 3 * nb, ctx->stream));      // one [3, cells] block: one fill
+      } else {
+        if (classification) BGNN_HIP_CHECK(hipMemsetAsync(classification, 0, nb, ctx->stream));
+        if (confidence) BGNN_HIP_CHECK(hipMemsetAsync(confidence, 0, nb, ctx->stream));
+        if (correction) BGNN_HIP_CHECK(hipMemsetAsync(correction, 0, nb, ctx->stream));
+      }
     }
     rc = forward_impl(ctx, m, g, thr_auto, thr_review, try_fused ? &none : &o, &go);
     if (rc == BGNN_OK && !go.done) {

@@ -202,6 +202,7 @@ struct bgnn_graph {
   // as wide as the stencil's reach, into one canvas whose 8x16 blocks the fused layer kernels walk instead of per-grid blocks
   // (which are 68 % full on config 4's grids; the canvas is ~85 % full).  d_atlas[canvas cell] = node id or -1.
   int32_t *d_atlas = nullptr;
+  char *d_tables = nullptr;               // ragged batch: ONE block with every host-built table (tiles, items*, canvas tables)
   BgnnTileMeta *d_atlas_tile = nullptr;   // the canvas as ONE tile {h, w, cell_off = 0}
   int32_t *d_atlas_pos = nullptr;         // [n_tiles][2] = (row, column) of each grid's origin on the canvas
   int32_t atlas_h = 0, atlas_w = 0;
