@@ -1,6 +1,3 @@
-cd /root/repo
-for s in 1 4; do
-timeout -k 10 300 python bench.py --workload vr --vr-streams $s --no-extras 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value']/1e6, j['ms_per_step'], j['config']['workload'][:120], {k:round(v['ms_per_step'],2) for k,v in j['kernels'].items()})"
-timeout -k 10 300 python bench.py --workload vr --vr-budget 1000000 --vr-streams $s --no-extras 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value']/1e6, j['ms_per_step'], j['config']['workload'][:120], {k:round(v['ms_per_step'],2) for k,v in j['kernels'].items()})"
-done
-timeout -k 10 300 python tools/vr_streams_probe.py
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_c3m -- python3 /root/repo/bench.py --workload c3 --no-extras --steps 6 --warmup 2 > /dev/null 2>&1
+find /root/repo/gpurun_out/prof_c3m -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-200

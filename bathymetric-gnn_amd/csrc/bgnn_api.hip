@@ -392,6 +392,20 @@ static void pack_bf16_image(const float *Wt, int D, int NC, float *dst_as_float)
             dst[(((size_t)hc * NT + t) * 2 + kg) * 256 + m * 8 + i] = bf16_rne(Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m]);
 }
 
+// the same image for the fused layer kernel's bf16 path, whose GEMM takes the aggregation MFMA's RESULT tile as its B operand:
+// element i of lane half kg then is k = 8 (i >> 2) + 4 kg + (i & 3) of the 16-k step, not 8 kg + i (gat_layer_fused.hip: AggWindow)
+static void pack_bf16_image_accop(const float *Wt, int D, int NC, float *dst_as_float) {
+  uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
+  const int NT = NC / 32;
+  for (int hc = 0; hc < D / 16; ++hc)
+    for (int t = 0; t < NT; ++t)
+      for (int kg = 0; kg < 2; ++kg)
+        for (int m = 0; m < 32; ++m)
+          for (int i = 0; i < 8; ++i)
+            dst[(((size_t)hc * NT + t) * 2 + kg) * 256 + m * 8 + i] =
+                bf16_rne(Wt[(size_t)(hc * 16 + 8 * (i >> 2) + 4 * kg + (i & 3)) * NC + t * 32 + m]);
+}
+
 // column-permuted f32 image for the fused exact-f32 kernel: column 32 t + r of a row goes to (t / TG) * 32 TG + r * TG + t % TG,
 // TG = 4 / 2 / 1 tiles per LDS read (gat_layer_fused.hip: WTileGroup)
 static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst) {
@@ -581,13 +595,13 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
       pack_split(src.data(), D, HC, pk.data() + o_wsp[l], false);
       if (!pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true)) f16_ok = false;
-      pack_bf16_image(src.data(), D, HC, pk.data() + o_wbf[l]);
+      pack_bf16_image_accop(src.data(), D, HC, pk.data() + o_wbf[l]);
       pack_tilegroup_image(src.data(), D, HC, pk.data() + o_wfp[l]);
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
     pack_split(src.data(), hid, HT, pk.data() + o_hW0sp, false);
     if (!pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true)) f16_ok = false;
-    pack_bf16_image(src.data(), hid, HT, pk.data() + o_hW0bf);
+    pack_bf16_image_accop(src.data(), hid, HT, pk.data() + o_hW0bf);
     pack_tilegroup_image(src.data(), hid, HT, pk.data() + o_hW0fp);
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);

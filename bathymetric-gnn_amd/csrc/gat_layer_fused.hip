@@ -292,6 +292,73 @@ struct FusedGeom {                                       // halo geometry of one
   static constexpr int HR = (FT_H + 2 * R) * HW;         // halo rows       (180 / 240)
 };
 
+// ---- bf16 storage path: the neighbourhood sum itself runs on the matrix pipe.
+// A wave's 32 cells (two block rows) only touch the halo rows of a WINDOW of 2 + 2R halo lines = 120 (k = 16) / 72 (k = 4, 8)
+// consecutive rows of the slab image.  With alpha[cell][window row] as a dense bf16 matrix (zero outside the stencil),
+//     agg[ch][cell] = sum_row X[row][ch] * alpha[cell][row]      is      NKB x v_mfma_f32_32x32x16_bf16
+// per 32-channel slab: A = X^T read straight from the [row][32 ch] slab image by ds_read_b64_tr_b16 (the hardware transpose), B =
+// the dense alpha rows (one ds_read_b128 per 16 window rows).  The result tile has the cell on the lane and the channels in the
+// 16 registers -- exactly what the next-layer GEMM wants as ITS B operand (k order 8(j>>2) + 4h + (j&3): the W image is packed
+// to match, bgnn_api.hip pack_bf16_image_accop).  Per slab and wave that replaces 17 x 3 LDS reads, 272 unpack and 144 FMA
+// instructions by 16 + 8 LDS reads and 8 MFMAs; 87 % of those MFMAs' products are zeros, on a pipe with 16x the vector rate.
+// alpha is rounded to bf16 for this (the activations it multiplies already are).  Rows without a node hold zeros and 0 x 0 = 0;
+// non-finite activations (which valid, finite depths cannot produce) would spread over the window instead of the stencil.
+template <int K>
+struct AggWindow {
+  using G = FusedGeom<K>;
+  static constexpr int ROWS = (2 + 2 * G::R) * G::HW;     // 120 / 72
+  static constexpr int NKB = (ROWS + 15) / 16;            // 8 / 5 MFMAs per slab
+  static constexpr int PAD = NKB * 16;                    // 128 / 80
+  __device__ static __forceinline__ int base(int wave) {  // first halo row of the wave's window (the last wave's is pulled inside)
+    const int b = wave * 2 * G::HW;
+    return b < G::HR - PAD ? b : G::HR - PAD;
+  }
+  static_assert((2 * G::HW) % 4 == 0 && (G::HR - PAD) % 4 == 0, "windows start on a 4-row boundary (uniform swizzle per read)");
+};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr(uint32_t addr) {      // EXEC must be all ones
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// one batch of NB window blocks: reads first (A: two transposed reads, B: one row read per block), then the MFMAs
+template <int KB0, int NB, bool ZERO>
+__device__ __forceinline__ void agg_blocks(f32x16 &d, uint32_t tr0, uint32_t tr1, uint32_t bq) {
+  u32x2 a0[NB], a1[NB];
+  u32x4 b[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    // (the immediate must be a literal: spell the blocks out)
+    if (KB0 + i == 0) { a0[i] = lds_read_tr<0>(tr0); a1[i] = lds_read_tr<0>(tr1); }
+    if (KB0 + i == 1) { a0[i] = lds_read_tr<1024>(tr0); a1[i] = lds_read_tr<1024>(tr1); }
+    if (KB0 + i == 2) { a0[i] = lds_read_tr<2048>(tr0); a1[i] = lds_read_tr<2048>(tr1); }
+    if (KB0 + i == 3) { a0[i] = lds_read_tr<3072>(tr0); a1[i] = lds_read_tr<3072>(tr1); }
+    if (KB0 + i == 4) { a0[i] = lds_read_tr<4096>(tr0); a1[i] = lds_read_tr<4096>(tr1); }
+    if (KB0 + i == 5) { a0[i] = lds_read_tr<5120>(tr0); a1[i] = lds_read_tr<5120>(tr1); }
+    if (KB0 + i == 6) { a0[i] = lds_read_tr<6144>(tr0); a1[i] = lds_read_tr<6144>(tr1); }
+    if (KB0 + i == 7) { a0[i] = lds_read_tr<7168>(tr0); a1[i] = lds_read_tr<7168>(tr1); }
+    b[i] = lds_read4u<0>(bq ^ ((uint32_t)(KB0 + i) << 5));
+  }
+  lds_reads_done();
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const u32x4 av = {a0[i].x, a0[i].y, a1[i].x, a1[i].y};
+    const bf16x8 A = __builtin_bit_cast(bf16x8, av), B = __builtin_bit_cast(bf16x8, b[i]);
+    if (ZERO && i == 0) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, z, 0, 0, 0);
+    } else {
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, d, 0, 0, 0);
+    }
+  }
+}
+
 template <int HC, int C, int K, int NT, int EPI, int SP>
 struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and launcher agree through this)
   static constexpr int H = HC / C, NC = NT * 32, HR = FusedGeom<K>::HR;
@@ -303,7 +370,12 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int RA = HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : 0);
   static constexpr int RSZ = RA > RB ? RA : RB;
   static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
-  static constexpr int FLOATS = SLAB + WBUF + PATCH_PAD + RSZ + HR + 4 + 128 * APITCH;
+  // attention coefficients: [128 cells][APITCH] f32 (sparse, every head); bf16 storage path: the CURRENT head's coefficients as
+  // four wave-private dense [32 cells][128 window rows] bf16 matrices (the aggregation's MFMA B operand) -- see AggWindow
+  static constexpr int ALPHA = SP == 3 ? 4 * 32 * 128 / 2 : 128 * APITCH;
+  static constexpr int PRE = SLAB + WBUF + PATCH_PAD + RSZ + HR + 4;
+  static constexpr int ALIGN = SP == 3 ? (64 - PRE % 64) % 64 : 0;       // the dense matrices start on a 256-byte boundary
+  static constexpr int FLOATS = PRE + ALIGN + ALPHA;
   static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
 };
 
@@ -333,7 +405,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   float *attr = has + 2 * HC;                          // [2][NC]   att_src | att_dst (epilogue, EPI_NEXT)
   int *hid = reinterpret_cast<int *>(has + RSZ);       // [HR]
   int *minid = hid + HR;                               // [4]
-  float *alx = reinterpret_cast<float *>(minid + 4);   // [128][APITCH]  alpha[cell][head][K+1]
+  float *alx = reinterpret_cast<float *>(minid + 4) + Lds::ALIGN;   // [128][APITCH]  alpha[cell][head][K+1]; bf16 path: dense (AggWindow)
 
 #if BGNN_DIAG
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -373,7 +445,11 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
   if (a.cell_map) {                  // canvas walk (wave-uniform test): blocks that hold only gutter / free space leave here
-    if (!__syncthreads_or(my_pre >= 0)) {
+    // (not __syncthreads_or: its library reduction brings 256 bytes of static LDS in front of the dynamic region)
+    const bool wave_any = __builtin_amdgcn_ballot_w64(my_pre >= 0) != 0;
+    if (lane == 0) minid[wave] = wave_any ? 1 : 0;
+    __syncthreads();
+    if ((minid[0] | minid[1] | minid[2] | minid[3]) == 0) {
       __builtin_amdgcn_s_waitcnt(0);   // the W DMAs land in this WG's LDS: drain them before the LDS can be handed on
       return;
     }
@@ -471,6 +547,11 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   BGNN_STAMP(1)   // round 2, halo tables in LDS
 
   // ---- phase A: attention coefficients -> LDS.  The two lanes that share a cell take the heads round-robin.
+  uint32_t apk[NHL][(K + 2) / 2];                       // bf16 storage path: this lane's heads, (K + 1) coefficients as bf16 pairs
+#pragma unroll
+  for (int i = 0; i < NHL; ++i)
+#pragma unroll
+    for (int b = 0; b < (K + 2) / 2; ++b) apk[i][b] = 0u;
   {
     const int my = DBG(32) ? -1 : hid[self_idx];
 #pragma unroll
@@ -481,8 +562,13 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
         for (int b = 0; b <= K; ++b) part[b] = 0.0f;
         if (my >= 0) attention_coefficients_head_pre<H, K, HW_>(self_idx, hh, hid, has, eraw, adv[i], vpre[i], part);
+        if constexpr (SP == 3) {      // kept in registers as bf16 pairs until this head's slabs come up (densified there)
 #pragma unroll
-        for (int b = 0; b <= K; ++b) alx[cell * APITCH + hh * (K + 1) + b] = part[b];
+          for (int b = 0; b <= K; b += 2) apk[i][b / 2] = pack_bf16x2(part[b], b + 1 <= K ? part[b + 1] : 0.0f);
+        } else {
+#pragma unroll
+          for (int b = 0; b <= K; ++b) alx[cell * APITCH + hh * (K + 1) + b] = part[b];
+        }
       }
     }
     // (consumers wait at the barrier at the top of the slab loop)
@@ -501,11 +587,27 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   const uint32_t wbuf0 = lds_addr(wbuf + 4 * hl * NC + r * WTileGroup<NT>::TG);   // (column-permuted image: WTileGroup)
   // chunk (16 B) ownership of lane (r, hl) inside a 32-channel slab: exact-f32 path channel chunks 2j + hl (k = 8j + 4hl + i
   // of f32 k-step j); 16-bit MFMA paths channels 8hl..8hl+7 for k-step 0 and 16+8hl.. for k-step 1 (k = 16 step + 8hl + i)
-  constexpr uint32_t CX1 = SP ? 16 : 32, CX2 = 64, CX3 = SP ? 80 : 96;
-  const uint32_t scsh0 = lds_addr(scsh) + (SP ? hl * 32 : hl * 16);
+  // (bf16 storage: the aggregation MFMA's result tile hands lane (r, hl) the exact path's channels, 8j + 4hl + i)
+  constexpr bool F32_CHUNKS = SP == 0 || SP == 3;
+  constexpr uint32_t CX1 = F32_CHUNKS ? 32 : 16, CX2 = 64, CX3 = F32_CHUNKS ? 96 : 80;
+  const uint32_t scsh0 = lds_addr(scsh) + (F32_CHUNKS ? hl * 16 : hl * 32);
   const uint32_t wsp0 = lds_addr(wbuf) + lane * 16;      // 16-bit MFMA paths: A fragments are stored in lane order
   const uint32_t alx0 = lds_addr(alx + cell * APITCH);
   constexpr uint32_t WHALF = WHalf<NT, SP>::BYTES;
+  // bf16 storage: addresses of the aggregation's operands (AggWindow)
+  using Win = AggWindow<K>;
+  const int wbase = Win::base(wave);
+  const uint32_t dn0 = lds_addr(alx) + wave * (32 * 256);                       // this wave's dense alpha [32][128] bf16
+  const uint32_t bq0 = dn0 + r * 256 + (((r & 15) >> 1) << 5) + ((hl ^ (r & 1)) << 4);   // chunk (2 kb + hl) ^ (r & 15): ^ (kb << 5)
+  uint32_t tr0 = 0, tr1 = 0;
+  if constexpr (SP == 3) {
+    // transposed read: lane 4q + p of a 16-lane group addresses row q, channels 4p..4p+3 of the group's 16 channels
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, cb = grp & 1;
+    const int row0 = wbase + 8 * hl + q;                  // + 4 part + 16 kb
+    const int c = 2 * cb + (p4 >> 1);
+    tr0 = slab0 + row0 * 64 + ((c ^ ((row0 >> 2) & 3)) << 4) + 8 * (p4 & 1);
+    tr1 = slab0 + (row0 + 4) * 64 + ((c ^ (((row0 + 4) >> 2) & 3)) << 4) + 8 * (p4 & 1);
+  }
 
   // ---- slabs.  Lane (r, hl) gathers exactly the 16 values it feeds to the MFMA as B operand -- no LDS round trip, no
   // lane exchange.
@@ -522,6 +624,30 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       // alone a narrow next stage (NQ = 2 or 3) waited for EVERYTHING at each of these points, the next slab included.
       constexpr int WREM = WHalf<NT, SP>::NQ % 4;
       const bool wextra = wave < WREM;
+      if constexpr (SP == 3) {
+        if (s % SPH == 0) {
+          // a new head: its coefficients become the wave's dense [32 cells][window rows] matrix.  Wave-private, and LDS
+          // operations of one wave complete in order: no barrier, the reads below simply follow the writes.
+          const int hd = s / SPH;
+          const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            asm volatile("ds_write_b128 %0, %1" ::"v"(dn0 + lane * 16 + i * 1024), "v"(z4) : "memory");
+          if (hl == (hd & 1)) {
+            const int wself = self_idx - wbase;
+            const uint32_t rowb = dn0 + r * 256;
+#pragma unroll
+            for (int b = 0; b <= K; ++b) {
+              const int off = b < K ? Off::dr[b < K ? b : 0] * HW_ + Off::dc[b < K ? b : 0] : 0;
+              const int wp = wself - off;
+              const uint32_t ad = rowb + ((((uint32_t)wp >> 3) ^ (uint32_t)(r & 15)) << 4) + ((uint32_t)wp & 7) * 2;
+              const uint32_t v = NHL > 1 && (hd >> 1) ? apk[NHL > 1 ? 1 : 0][b / 2] : apk[0][b / 2];
+              if (b & 1) asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(ad), "v"(v) : "memory");
+              else asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"(v) : "memory");
+            }
+          }
+        }
+      }
       if (s == 0) wait_vm_lgkm<0>();                    // (slab 0 was queued BEHIND its W rows: wait for everything)
       else if (WREM && wextra) wait_vm_lgkm<2 * (WH + 1)>();
       else wait_vm_lgkm<2 * WH>();
@@ -547,42 +673,20 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (!DBG(1)) {
-        // Software-pipelined gather: the LDS reads of neighbour b + 1 are issued BEFORE the wait for neighbour b (LDS returns
-        // in order, so a counted lgkmcnt leaves exactly the younger neighbour's reads in flight).  Only the first neighbour's
-        // read latency is exposed; without this every neighbour pays it (9 x ~120 cycles per slab while BOTH workgroups of a
-        // CU tend to sit in their gather phase at the same time, i.e. with the matrix pipe idle).  The row base addresses are
-        // kept (K + 1 registers); the three other chunk slots are re-derived by XOR, which frees the registers the second
-        // read buffer needs.
         auto nb_index = [&](int b) { return b >= K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0]; };
         if constexpr (SP == 3) {
-          // 64-byte rows of bf16: chunk hl (channels 8hl..8hl+7) and chunk 2 + hl (16+8hl..), swizzled by (row >> 2) & 3
-          auto rowbase = [&](int b) { const int nidx = nb_index(b); return slabs + nidx * 64 + ((((nidx >> 2) & 3) ^ hl) << 4); };
-          u32x4 xa[2], xb[2]; float al[2];
-          { const uint32_t rb = rowbase(0); al[0] = lds_read1<0>(ap); xa[0] = lds_read4u<0>(rb); xb[0] = lds_read4u<0>(rb ^ 32); }
-#pragma unroll
-          for (int b = 0; b <= K; ++b) {
-            const int cur = b & 1, nxt = cur ^ 1;
-            if (b < K) {
-              const uint32_t rb = rowbase(b + 1);
-              al[nxt] = lds_read1<0>(ap + 4 * (b + 1)); xa[nxt] = lds_read4u<0>(rb); xb[nxt] = lds_read4u<0>(rb ^ 32);
-              asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-            } else {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float alpha = al[cur];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {                   // dword j of a chunk = channels (2j, 2j+1) as (low, high) halves
-              const u32x4 &x = j == 0 ? xa[cur] : xb[cur];
-              g[2 * j].x += alpha * __uint_as_float(x.x << 16); g[2 * j].y += alpha * __uint_as_float(x.x & 0xffff0000u);
-              g[2 * j].z += alpha * __uint_as_float(x.y << 16); g[2 * j].w += alpha * __uint_as_float(x.y & 0xffff0000u);
-              g[2 * j + 1].x += alpha * __uint_as_float(x.z << 16); g[2 * j + 1].y += alpha * __uint_as_float(x.z & 0xffff0000u);
-              g[2 * j + 1].z += alpha * __uint_as_float(x.w << 16); g[2 * j + 1].w += alpha * __uint_as_float(x.w & 0xffff0000u);
-            }
-            // the sums are due HERE: without this the unpacked values of several neighbours are kept in registers and the
-            // FMAs sunk below the following reads (16 more live registers per neighbour -> spills)
-            asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
+          // the neighbourhood sum on the matrix pipe (AggWindow): result register i = channel 8 (i >> 2) + 4 hl + (i & 3)
+          f32x16 d;
+          if constexpr (Win::NKB == 8) {
+            agg_blocks<0, 4, true>(d, tr0, tr1, bq0);
+            agg_blocks<4, 4, false>(d, tr0, tr1, bq0);
+          } else {
+            static_assert(Win::NKB == 5, "window blocks");
+            agg_blocks<0, 3, true>(d, tr0, tr1, bq0);
+            agg_blocks<3, 2, false>(d, tr0, tr1, bq0);
           }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = (f32x4){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
         } else {
           // 128-byte rows of f32: slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5)).  (Not
           // software-pipelined: measured, it buys nothing on the f32 paths -- the stamps put the gather at 4.6 % of a

@@ -759,7 +759,8 @@ def test_batches_dealt_over_two_contexts_give_the_same_grids(gpu_device):
 def test_ragged_batch_canvas_walk_equals_per_grid_blocks(connectivity, path, gpu_device):
     """Ragged batches (VR refinement grids): the fused layers walk a shelf-packed canvas of the grids (option
     ragged_atlas, default on).  Packing only changes which 8x16 block a node is computed in, so the grids must equal the
-    per-grid-block walk bit for bit -- every stencil, both storage types, grids down to 2x2 and wider than the default canvas."""
+    per-grid-block walk bit for bit on the exact path (every stencil; grids down to 2x2 and wider than the default canvas) and
+    to rounding on the bf16 path."""
     from bathymetric_gnn_amd import runtime as rt, synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
@@ -780,5 +781,11 @@ def test_ragged_batch_canvas_walk_equals_per_grid_blocks(connectivity, path, gpu
         b = eng.infer_device(hw, res, d, m, u).clone()
     finally:
         ctx.set_option("ragged_atlas", 1)
-    assert torch.equal(a, b)
+    if path == "bf16":
+        # the bf16 path sums a neighbourhood inside MFMAs, 16 window rows per instruction: where a cell sits in its block decides
+        # which rows share an instruction, so the f32 rounding (not the terms) differs between the two walks
+        assert float((a[1] - b[1]).abs().max()) < 2e-3 and float((a[2] - b[2]).abs().max()) < 2e-3
+        assert float((a[0] != b[0]).float().mean()) < 2e-3
+    else:
+        assert torch.equal(a, b)
     assert set(np.unique(a[0].cpu().numpy())) <= {0.0, 1.0, 2.0} and float(a[1].max()) > 0

@@ -2,9 +2,10 @@
 switched off through the `diag_mask` context option.  Unlike the cycle stamps this does not perturb the kernel (no atomics
 in the counted waits).  Bits: 1 gather, 2 MFMAs, 4 slab DMA, 8 W DMA, 32 phase A (attention coefficients), 64 final epilogue.
 
-    python __graft_entry__.py --diag && BGNN_LIB=bathymetric-gnn_amd/libbgnn_hip_diag.so python tools/fused_ablation.py
+    python __graft_entry__.py --diag && BGNN_LIB=bathymetric-gnn_amd/libbgnn_hip_diag.so python tools/fused_ablation.py \
+        [--connectivity 16-dilated --matrix-path bf16]
 """
-import os, sys, time
+import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("BGNN_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bathymetric-gnn_amd", "libbgnn_hip_diag.so"))
 import numpy as np, torch
@@ -15,7 +16,11 @@ from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
 dev = torch.device("cuda:0")
 sd = synthetic.synthetic_state_dict(seed=1234)
 model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}); model.to(dev).eval()
-gb = GraphBuilder(device=dev); eng = TileBatchEngine(model, gb, dev)
+ap = argparse.ArgumentParser()
+ap.add_argument("--connectivity", default="8-connected"); ap.add_argument("--matrix-path", default="exact_f32")
+args = ap.parse_args()
+gb = GraphBuilder(device=dev, connectivity=args.connectivity); eng = TileBatchEngine(model, gb, dev)
+eng.ctx.set_option("matrix_path", args.matrix_path)
 B, S = 128, 256
 depth, mask, _ = synthetic.synthetic_tile_batch(8, S, S, 100, "V0"); depth = np.concatenate([depth] * 16); mask = np.concatenate([mask] * 16)
 d_t = torch.from_numpy(depth).to(dev).reshape(-1); m_t = torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
