@@ -1,3 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_c3m -- python3 /root/repo/bench.py --workload c3 --no-extras --steps 6 --warmup 2 > /dev/null 2>&1
-find /root/repo/gpurun_out/prof_c3m -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-200
+cd /root/repo
+timeout -k 10 900 python -m pytest tests/test_gpu_forward.py tests/test_gpu_model_golden.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -6
+timeout -k 10 300 python bench.py --no-extras 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value']/1e6, j['ms_per_step'], {k:round(v['ms_per_step'],2) for k,v in j['kernels'].items()})"
+timeout -k 10 300 python bench.py --workload c3 --no-extras 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value']/1e6, j['ms_per_step'], {k:round(v['ms_per_step'],2) for k,v in j['kernels'].items()})"

@@ -197,6 +197,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.fused = getenv("BGNN_NO_FUSED") ? 0 : 1;
     o.fold_extractor = getenv("BGNN_NO_FOLD") ? 0 : 1;
     o.ragged_atlas = getenv("BGNN_NO_ATLAS") ? 0 : 1;
+    o.fused_front = getenv("BGNN_NO_FUSED_FRONT") ? 0 : 1;
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
@@ -211,7 +212,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
 static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
-      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas},
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"fused_front", &o.fused_front},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
@@ -380,20 +381,10 @@ static bool pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool
   return true;
 }
 
-// bf16 (hi only) image for the bf16 storage path: [D/16 half-chunks][NC/32 tiles][1 KiB = k-group 2 x column 32 x k 8]
-static void pack_bf16_image(const float *Wt, int D, int NC, float *dst_as_float) {
-  uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
-  const int NT = NC / 32;
-  for (int hc = 0; hc < D / 16; ++hc)
-    for (int t = 0; t < NT; ++t)
-      for (int kg = 0; kg < 2; ++kg)
-        for (int m = 0; m < 32; ++m)
-          for (int i = 0; i < 8; ++i)
-            dst[(((size_t)hc * NT + t) * 2 + kg) * 256 + m * 8 + i] = bf16_rne(Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m]);
-}
-
-// the same image for the fused layer kernel's bf16 path, whose GEMM takes the aggregation MFMA's RESULT tile as its B operand:
-// element i of lane half kg then is k = 8 (i >> 2) + 4 kg + (i & 3) of the 16-k step, not 8 kg + i (gat_layer_fused.hip: AggWindow)
+// bf16 (hi only) image for the bf16 storage path: [D/16 half-chunks][NC/32 tiles][1 KiB = k-group 2 x column 32 x k 8] in MFMA
+// A-fragment lane order.  Every GEMM of that path takes an MFMA RESULT tile as its B operand (the aggregation's in the fused layer
+// kernel -- gat_layer_fused.hip AggWindow --, extractor layer 1's in the lin_0 GEMM), so element i of lane half kg is
+// k = 8 (i >> 2) + 4 kg + (i & 3) of the 16-k step, not 8 kg + i
 static void pack_bf16_image_accop(const float *Wt, int D, int NC, float *dst_as_float) {
   uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
   const int NT = NC / 32;
@@ -606,7 +597,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
     if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
-    pack_bf16_image(src0.data(), hid, HC0, pk.data() + o_l0fbf);
+    pack_bf16_image_accop(src0.data(), hid, HC0, pk.data() + o_l0fbf);
   }
 
   bgnn_model *m = new bgnn_model();
@@ -1044,11 +1035,16 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     const BgnnLayer &L0 = m->layers[0];
     if (ctx->opts.fold_extractor) {       // second extractor layer folded into lin_0 (see bgnn_model_create)
       const int sm = tr ? 0 : ctx->opts.matrix_path;   // training mode: exact float32 only (batch statistics amplify the split's error)
-      BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
-      BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid, L0.heads * hid, 0,
-                               L0.att_src, L0.att_dst, asdX, L0.heads, hid,
-                               sm == 3 ? m->l0f_Wbf : sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr,
-                               sm == 3 ? 3 : sm == 2 && m->l0f_Wsp16 ? 2 : sm ? 1 : 0));
+      const int smode = sm == 3 ? 3 : sm == 2 && m->l0f_Wsp16 ? 2 : sm ? 1 : 0;
+      const float *wsplit = sm == 3 ? m->l0f_Wbf : sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr;
+      // extractor layer 1 runs inside the lin_0 GEMM (same instructions, h1 never leaves the registers) wherever that GEMM takes
+      // its W-resident form; below 65 536 rows (exact path) it keeps its own launch -- the results are bit-identical either way
+      const bool front = hid == 64 && gemm_front_available(ctx, rows, L0.heads * hid, smode);
+      BGNN_REQUIRE(front || sm != 3, "matrix_path = bf16 needs fused_front = 1");
+      if (!front) BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
+      BGNN_TRY(launch_gemm_f32(ctx, front ? g->d_x8 : Y, front ? 8 : hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid,
+                               L0.heads * hid, 0, L0.att_src, L0.att_dst, asdX, L0.heads, hid, wsplit, smode,
+                               front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr));
     } else {
       BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));

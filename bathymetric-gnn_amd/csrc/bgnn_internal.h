@@ -76,6 +76,7 @@ struct BgnnOpts {
   int matrix_path = 0;       // 0 exact f32, 1 bf16x3, 2 fp16x3 (opt-in operand-split matrix paths), 3 bf16 activation storage + bf16 MFMA
   int fused = 1;             // 0: K3 / K4 / K5 / K6 as separate kernels
   int fold_extractor = 1;    // 0: run the extractor's second Linear and lin of layer 0 unfolded
+  int fused_front = 1;       // 1: extractor layer 1 runs inside the lin_0 GEMM where that GEMM's W-resident form is used (0: own launch)
   int ragged_atlas = 1;      // ragged batches: fused layers walk a shelf-packed canvas of the grids (0: per-grid 8x16 blocks)
   int fused_lds_pad_kb = 0;    // experiment: pad the fused kernel's LDS request (occupancy)
   int diag_mask = 0;         // BGNN_DIAG builds only: phase ablation bits of the fused kernel
@@ -237,7 +238,9 @@ int launch_generic_build(bgnn_ctx *ctx, bgnn_graph *g, int64_t n_nodes, int32_t 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y,
                     int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu,
                     const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
-                    int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0);
+                    int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0,
+                    const float *front_W0t = nullptr, const float *front_b0 = nullptr);
+bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                          const float *asd, float *out, int relu);
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,

@@ -41,6 +41,9 @@ struct GemmArgs {
   float *dump;            // >= 1 KiB scratch row for rows >= M (branch-free stores)
   int ldx, ldy, K, relu, H, C;
   int dbg;                // diagnostic ablations (BGNN_GEMM_DBG): 1 = no row stores, 2 = no MFMAs, 4 = no X loads
+  // W-resident form with the feature extractor's first Linear in front (FRONT): X is then the [M][8] node feature table and
+  const float *W0t;       // [8][64]  extractor layer 1 (transposed)
+  const float *b0;        // [64]
 };
 
 template <int NT>
@@ -233,8 +236,16 @@ __device__ __forceinline__ f32x16 mfma_lp(const f16x8 &a, const f16x8 &b, const 
 // is split in registers; lane (r, h) owns k = 16 step + 8h + i of every 16-wide k-step.
 // SP = 3 (bf16 activation storage, BASELINE config 3): Wt is the hi-only bf16 image, X is rounded to bf16 in registers, one
 // MFMA per tile and 16 k, and Y is written as bf16 (the attention dots are taken from the f32 accumulators).
-template <int NT, bool ATT, int SP = 0>
+// FRONT: the K = 64 input is not read from memory but made on the spot from the [M][8] node feature table:
+//   h1 = relu(x8 @ W0^T + b0)   (feature extractor layer 1; gnn.py LocalFeatureExtractor)
+// by the SAME eight v_mfma_f32_32x32x2_f32 per 32 rows (and the same k pairing, bias add and ReLU) as the stand-alone
+// gemm_f32_kernel<2, false> launch it replaces -- bit-identical h1, which never goes to HBM (256 B/node written + read back,
+// and one launch, less).  The result tile holds, on lane (r, h), channels 8s + 4h + i of row r: exactly this kernel's X fragment
+// order on the exact path; on the bf16 path it is the accumulator-as-operand order, for which the W image is packed
+// (bgnn_api.hip pack_bf16_image_accop).
+template <int NT, bool ATT, int SP = 0, bool FRONT = false>
 __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
+  static_assert(!FRONT || SP == 0 || SP == 3, "the fused front exists on the exact and the bf16 storage paths");
   constexpr int NC = NT * 32, K = 64;
   constexpr int WFLOATS = SP == 3 ? K * NC / 2 : K * NC;   // bytes of the weight image / 4
   extern __shared__ __attribute__((aligned(128))) float wres_lds[];
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   constexpr int PP = 68;                              // patch pitch: two 32-column tiles side by side + 4 pad
   float *patches = wl + WFLOATS;                     // [8][32 * PP]
   float *attl = patches + 8 * 32 * PP;               // [2][NC]
+  float *b0l = attl + 2 * NC;                        // [64]  (FRONT)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int NW = blockDim.x >> 6;                    // 8 (4 only in the occupancy experiment)
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     }
     if (ATT)
       for (int i = threadIdx.x; i < NC; i += blockDim.x) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
+    if (FRONT && threadIdx.x < 64) b0l[threadIdx.x] = a.b0[threadIdx.x];
   }
   __syncthreads();                                   // (vmcnt(0): W has landed)
   const int64_t M = *a.d_m;
@@ -264,15 +277,48 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   const int64_t stride = (int64_t)gridDim.x * NW * 32;
   int64_t row0 = (int64_t)blockIdx.x * NW * 32 + wave * 32;
   float4 ax[K / 8];
+  float4 xq;                                          // FRONT: features 4h..4h+3 of the lane's row
+  float w0[2][4];                                     // FRONT: W0^T[4h + i][32 t + r], resident
+  if constexpr (FRONT) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w0[t][i] = a.W0t[(4 * h + i) * 64 + t * 32 + r];
+  }
   auto load_x = [&](int64_t rb) {
     const int64_t row = rb + r;
-    const float *xp = a.X + (row < M ? row : M - 1) * a.ldx + (SP ? 8 * h : 4 * h);
+    if constexpr (FRONT) {
+      xq = *reinterpret_cast<const float4 *>(a.X + (row < M ? row : M - 1) * 8 + 4 * h);
+    } else {
+      const float *xp = a.X + (row < M ? row : M - 1) * a.ldx + (SP ? 8 * h : 4 * h);
 #pragma unroll
-    for (int s = 0; s < K / 8; ++s)                  // exact: k = 8s + 4h + i; split: k = 16 (s/2) + 8h + 4 (s&1) + i
-      ax[s] = *reinterpret_cast<const float4 *>(xp + (SP ? (s >> 1) * 16 + (s & 1) * 4 : s * 8));
+      for (int s = 0; s < K / 8; ++s)                  // exact: k = 8s + 4h + i; split: k = 16 (s/2) + 8h + 4 (s&1) + i
+        ax[s] = *reinterpret_cast<const float4 *>(xp + (SP ? (s >> 1) * 16 + (s & 1) * 4 : s * 8));
+    }
   };
   if (row0 < M) load_x(row0);
   for (; row0 < M; row0 += stride) {
+    if constexpr (FRONT) {
+      // extractor layer 1 on the spot: the instruction sequence of gemm_f32_kernel<2, false> (K = 8)
+      f32x16 a1[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a1[t][i] = 0.0f;
+      const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[t][i], xv[i], a1[t], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < K / 8; ++s) {               // channels 8s + 4h + i = tile s / 4, registers 4 (s % 4) + i
+        const float4 b = *reinterpret_cast<const float4 *>(b0l + 8 * s + 4 * h);
+        float4 v = make_float4(a1[s / 4][4 * (s % 4)] + b.x, a1[s / 4][4 * (s % 4) + 1] + b.y, a1[s / 4][4 * (s % 4) + 2] + b.z,
+                               a1[s / 4][4 * (s % 4) + 3] + b.w);
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        ax[s] = v;
+      }
+    }
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -415,11 +461,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   }
 }
 
-template <int NT, bool ATT, int SP = 0>
+template <int NT, bool ATT, int SP = 0, bool FRONT = false>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
-  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + 8 * 32 * 68 + 2 * NT * 32) * 4;
+  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + 8 * 32 * 68 + 2 * NT * 32 + 64) * 4;
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
-  auto kern = gemm_wres64_kernel<NT, ATT, SP>;
+  auto kern = gemm_wres64_kernel<NT, ATT, SP, FRONT>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
@@ -432,16 +478,26 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
 }
 
 // (split_mode 3: Y receives bf16 [M][ldy], see gemm_wres64_kernel)
+// Can the K = 64 attention GEMM of this shape take the feature extractor's first Linear in front (X = the [M][8] feature table)?
+bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode) {
+  if (!ctx->opts.fused_front || (NC != 64 && NC != 256)) return false;
+  if (split_mode == 3) return true;                                  // bf16 output: always the W-resident form
+  return split_mode == 0 && !ctx->opts.gemm_no_wres && max_rows >= 65536;
+}
+
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
-                    const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode) {
+                    const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode,
+                    const float *front_W0t, const float *front_b0) {
   BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0 && ldy % 4 == 0,
                "gemm_f32: unsupported shape K=%d NC=%d ldx=%d ldy=%d", K, NC, ldx, ldy);
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
   const int gemm_dbg = BGNN_DIAG ? ctx->opts.gemm_diag : 0;
-  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg};
+  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg, front_W0t, front_b0};
+  if (front_W0t) BGNN_REQUIRE(K == 64 && att_src && gemm_front_available(ctx, max_rows, NC, split_mode) && (split_mode != 3 || Wt_split),
+                              "gemm: the fused front needs the W-resident K = 64 attention form");
   const bool no_wres = ctx->opts.gemm_no_wres != 0;
   // the split image is only read by the W-resident ATT form (NC 64 or 256); with a split path switched on that form runs
   // at EVERY batch size, so that a node's result does not depend on how many other nodes share its batch
@@ -450,7 +506,8 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (K == 64 && (!no_wres || split_mode == 3) && (max_rows >= 65536 || Wt_split)) {    // W-resident persistent form
     switch (NC / 32) {
 #define BGNN_WRES_CASE(NT) case NT:                                                                                 \
-        if (Wt_split) { a.Wt = Wt_split; return split_mode == 3 ? launch_wres64<NT, true, 3>(ctx, a) : split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \
+        if (front_W0t) { if (split_mode == 3) a.Wt = Wt_split; return split_mode == 3 ? launch_wres64<NT, true, 3, true>(ctx, a) : launch_wres64<NT, true, 0, true>(ctx, a); } \
+        if (Wt_split) { BGNN_REQUIRE(split_mode != 3, "gemm: the bf16 image is packed for the fused front"); a.Wt = Wt_split; return split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \
         return att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
       BGNN_WRES_CASE(2) BGNN_WRES_CASE(8)
 #undef BGNN_WRES_CASE

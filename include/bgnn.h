@@ -60,6 +60,8 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
  *                     aggregation / accumulation (BASELINE config 3 "bf16 node features"; no 1e-4 contract) [BGNN_BF16]
  *   "fused"           1 (default): K4 fused with the next K3 / K5 + K6; 0: separate kernels           [BGNN_NO_FUSED]
  *   "fold_extractor"  1 (default): extractor layer 2 folded into lin of GAT layer 0; 0: unfolded chain [BGNN_NO_FOLD]
+ *   "fused_front"     1 (default): feature extractor layer 1 runs inside the lin_0 GEMM where that GEMM takes its W-resident form
+ *                     (same instructions, bit-identical, one launch and 512 B/node of traffic less); 0: own launch [BGNN_NO_FUSED_FRONT]
  *   "ragged_atlas"    1 (default): for ragged batches the fused layers walk a shelf-packed canvas of the grids (denser 8x16
  *                     blocks); 0: per-grid blocks                                                      [BGNN_NO_ATLAS]
  * plus experiment / diagnostic knobs ("fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",

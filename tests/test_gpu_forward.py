@@ -789,3 +789,28 @@ def test_ragged_batch_canvas_walk_equals_per_grid_blocks(connectivity, path, gpu
     else:
         assert torch.equal(a, b)
     assert set(np.unique(a[0].cpu().numpy())) <= {0.0, 1.0, 2.0} and float(a[1].max()) > 0
+
+
+def test_extractor_layer_inside_the_lin0_gemm_is_bit_identical(gpu_device):
+    """Option fused_front (default on): at >= 65 536 rows the exact path runs feature extractor layer 1 inside the lin_0 GEMM
+    (same MFMA sequence, h1 stays in registers) instead of as its own launch.  Every output must be bit-identical; the bf16
+    path always runs it that way and refuses to run without."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    model = _model(synthetic.synthetic_state_dict(seed=77))
+    gb = GraphBuilder(device=gpu_device)
+    tiles = [synthetic.synthetic_tile(256, 256, 900 + i, "V1") for i in range(2)]
+    g = gb.build_graphs([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 2)
+    assert g.num_nodes >= 65536
+    ctx = rt.get_context(gpu_device)
+    try:
+        a = model.predict(g)
+        ctx.set_option("fused_front", 0)
+        b = model.predict(g)
+        _set_matrix_path("bf16")
+        with pytest.raises(ValueError, match="fused_front"):
+            model.predict(g)
+    finally:
+        ctx.set_option("fused_front", 1)
+    for k in ("class_logits", "confidence", "correction", "class_probs"):
+        assert torch.equal(a[k], b[k]), k
