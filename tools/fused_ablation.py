@@ -18,6 +18,7 @@ sd = synthetic.synthetic_state_dict(seed=1234)
 model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}); model.to(dev).eval()
 ap = argparse.ArgumentParser()
 ap.add_argument("--connectivity", default="8-connected"); ap.add_argument("--matrix-path", default="exact_f32")
+ap.add_argument("--masks", default="", help="comma-separated diag_mask values instead of the standard ablation list")
 args = ap.parse_args()
 gb = GraphBuilder(device=dev, connectivity=args.connectivity); eng = TileBatchEngine(model, gb, dev)
 eng.ctx.set_option("matrix_path", args.matrix_path)
@@ -27,7 +28,9 @@ d_t = torch.from_numpy(depth).to(dev).reshape(-1); m_t = torch.from_numpy(mask.v
 hw = np.tile(np.array([[S, S]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
 out = torch.empty((3, d_t.numel()), device=dev)
 names = {1: "gather", 2: "mfma", 4: "slab-dma", 8: "w-dma", 32: "phaseA", 64: "epilogue"}
-for mask_bits in (0, 1, 2, 3, 4 + 8, 2 + 4 + 8, 1 + 2 + 4 + 8, 1 + 2 + 4 + 8 + 32, 1 + 2 + 4 + 8 + 32 + 64, 64, 32, 2 + 64, 1 + 2 + 64):
+masks = [int(x) for x in args.masks.split(",")] if args.masks else [0, 1, 2, 3, 4 + 8, 2 + 4 + 8, 1 + 2 + 4 + 8, 1 + 2 + 4 + 8 + 32,
+                                                                     1 + 2 + 4 + 8 + 32 + 64, 64, 32, 2 + 64, 1 + 2 + 64]
+for mask_bits in masks:
     eng.ctx.set_option("diag_mask", mask_bits)
     for _ in range(2):
         eng.infer_device(hw, res, d_t, m_t, None, out=out)
