@@ -344,7 +344,7 @@ def main():
                                            "K4 gather-softmax-aggregate fused with the next layer's exact-f32 MFMA GEMM (last: heads + scatter)")
             roofs["fused_hbm"] = roof("gat_layer_fused_kernel", "fused", "hbm", am["fused_bytes"],
                                       "same launches priced by compulsory HBM bytes (read xW + attrs, write next xW)")
-            roofs["front_gemm"] = roof("gemm_f32_kernel", "gemm", "mfma", am["front_flops"], "feature extractor layer 1, then extractor layer 2 folded into lin of layer 0 (executed flops)")
+            roofs["front_gemm"] = roof("gemm_f32_kernel", "gemm", "mfma", am["front_flops"], "gemm_wres64_kernel: feature extractor layer 1 in front of (extractor layer 2 folded into) lin of layer 0, one launch (executed flops)")
         else:
             roofs["aggregate_hbm"] = roof("gat_aggregate_tiled_kernel", "aggregate", "hbm", am["aggregate_bytes"],
                                           "standalone K4 (LDS-tiled gather-softmax-aggregate + BN + ReLU)")
