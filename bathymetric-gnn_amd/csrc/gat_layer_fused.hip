@@ -13,7 +13,7 @@
 // (4.3 KiB/node at HC = 256) to read xw (x1.4 halo, mostly L2) + write xw' (2.3 KiB/node); the kernel is
 // then bound by the exact-f32 matrix pipe.
 //
-// Per slab s:   wait slab | barrier | gather + BN/ReLU in registers | wait W rows 0-15 | barrier | DMA slab s+1 |
+// Per slab s:   wait slab | barrier | gather (bf16: 8 aggregation MFMAs) + BN/ReLU in registers | wait W rows 0-15 | barrier | DMA slab s+1 |
 //               16 x NT MFMAs | barrier | DMA W rows 0-15 of slab s+1 | 16 x NT MFMAs | barrier | DMA W rows 16-31
 // so every DMA has at least half a slab of matrix work (plus the next gather) to land.
 //
@@ -23,8 +23,9 @@
 // Matrix / storage modes (template SP):
 //   0  exact f32: activations f32 in HBM, v_mfma_f32_32x32x2_f32 (default; the parity path)
 //   1  bf16x3, 2 fp16x3: activations f32 in HBM, operands split hi + lo in registers, three 16-bit MFMAs (opt-in)
-//   3  bf16: activations (xw) stored as bf16 in HBM, one v_mfma_f32_32x32x16_bf16 per 16 k; softmax, aggregation, BatchNorm,
-//      attention dots and every accumulator stay f32 (BASELINE config 3 "bf16 node features"; not a parity path)
+//   3  bf16: activations (xw) stored as bf16 in HBM; the neighbourhood sum (alpha rounded to bf16, AggWindow below) and the GEMM
+//      (one v_mfma_f32_32x32x16_bf16 per 16 k) run on the bf16 matrix pipe; softmax, BatchNorm, attention dots and every
+//      accumulator stay f32 (BASELINE config 3 "bf16 node features"; not a parity path)
 //
 // Reference semantics: models/gnn.py:173-188 (conv -> norm -> relu), :392-406 (heads),
 // :427-449 (predict), models/pipeline.py:278-307 (grids); GATConv per SURVEY Appendix B.
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   const unsigned long long t_clk0 = t_prev, t_real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // in-kernel clock probe
 #endif
   const BlockPos pos = decode_block<FT_H>(a.tb);
+  // (static s_setprio by SIMD wave slot or by workgroup parity, so that co-resident waves differ: measured, 1-3 % slower)
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index as a SCALAR: LDS-DMA destinations (M0) and the "does this wave move piece q" tests then stay on the scalar
   // unit instead of costing a v_readfirstlane / exec-mask sequence per DMA in the slab loop
