@@ -198,6 +198,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.fold_extractor = getenv("BGNN_NO_FOLD") ? 0 : 1;
     o.ragged_atlas = getenv("BGNN_NO_ATLAS") ? 0 : 1;
     o.fused_front = getenv("BGNN_NO_FUSED_FRONT") ? 0 : 1;
+    o.fused_persistent = getenv("BGNN_PERSISTENT") ? 1 : 0;
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
@@ -212,7 +213,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
 static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
-      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"fused_front", &o.fused_front},
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
@@ -240,11 +241,12 @@ int bgnn_ctx_get_option(bgnn_ctx *ctx, const char *name, int *value) {
 }
 
 // diagnostic (not part of the documented ABI): read and clear the fused kernel's phase counters
-int bgnn_debug_stamps(bgnn_ctx *ctx, unsigned long long *out16) {
-  if (!ctx || !out16) return BGNN_ERR_INVALID;
+// (out32: counters 0..15 of the one-block-per-workgroup kernels, 16..31 of the persistent kernel)
+int bgnn_debug_stamps(bgnn_ctx *ctx, unsigned long long *out32) {
+  if (!ctx || !out32) return BGNN_ERR_INVALID;
   (void)hipStreamSynchronize(ctx->stream);
-  if (hipMemcpy(out16, ctx->stamps, 128, hipMemcpyDeviceToHost) != hipSuccess) return BGNN_ERR_HIP;
-  (void)hipMemset(ctx->stamps, 0, 128);
+  if (hipMemcpy(out32, ctx->stamps, 256, hipMemcpyDeviceToHost) != hipSuccess) return BGNN_ERR_HIP;
+  (void)hipMemset(ctx->stamps, 0, 256);
   return BGNN_OK;
 }
 

@@ -76,6 +76,8 @@ struct BgnnOpts {
   int matrix_path = 0;       // 0 exact f32, 1 bf16x3, 2 fp16x3 (opt-in operand-split matrix paths), 3 bf16 activation storage + bf16 MFMA
   int fused = 1;             // 0: K3 / K4 / K5 / K6 as separate kernels
   int fold_extractor = 1;    // 0: run the extractor's second Linear and lin of layer 0 unfolded
+  int fused_persistent = 0;  // 1 (opt-in experiment): big uniform batches run the 256 -> 256 exact-f32 fused layer in its persistent
+                             // one-workgroup-per-CU form (bit-identical; measured 11.4 ms per launch against 10.15: DESIGN.md)
   int fused_front = 1;       // 1: extractor layer 1 runs inside the lin_0 GEMM where that GEMM's W-resident form is used (0: own launch)
   int ragged_atlas = 1;      // ragged batches: fused layers walk a shelf-packed canvas of the grids (0: per-grid 8x16 blocks)
   int fused_lds_pad_kb = 0;    // experiment: pad the fused kernel's LDS request (occupancy)

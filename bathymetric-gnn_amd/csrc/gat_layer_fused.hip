@@ -184,6 +184,41 @@ struct MfmaGroups {
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t], g[M / 2][2 * (M & 1) + 1], acc[t], 0, 0, 0);
     if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::step(acc, g, wbuf0, na, nb);
   }
+  // the same sequence with a hook after every MFMA of each group's second k row: hook(integral_constant<M * NT + t>) issues ONE
+  // instruction whose issue time then passes under the 64-cycle MFMA before it (the persistent kernel's DMA requests for the next slab)
+  template <typename F>
+  __device__ static __forceinline__ void run_hooked(f32x16 (&acc)[NT], const f32x4 (&g)[4], uint32_t wbuf0, F &&hook) {
+    float wa[NT], wb[NT];
+    load(wa, wb, wbuf0);
+    step_hooked(acc, g, wbuf0, wa, wb, hook);
+  }
+  template <typename F>
+  __device__ static __forceinline__ void step_hooked(f32x16 (&acc)[NT], const f32x4 (&g)[4], uint32_t wbuf0, float (&wa)[NT],
+                                                    float (&wb)[NT], F &&hook) {
+    lds_reads_done();
+    float na[NT], nb[NT];
+    if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::load(na, nb, wbuf0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (ZC) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], z, 0, 0, 0);
+      } else {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], g[M / 2][2 * (M & 1)], acc[t], 0, 0, 0);
+      }
+    }
+    hook_each<0>(acc, g, wb, hook);
+    if constexpr (M + 1 < END) MfmaGroups<NT, NC, M + 1, END>::step_hooked(acc, g, wbuf0, na, nb, hook);
+  }
+  // second k row of the group, one hook call after every MFMA: hook(integral_constant<M * NT + t>)
+  template <int T, typename F>
+  __device__ static __forceinline__ void hook_each(f32x16 (&acc)[NT], const f32x4 (&g)[4], float (&wb)[NT], F &&hook) {
+    if constexpr (T < NT) {
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[T], g[M / 2][2 * (M & 1) + 1], acc[T], 0, 0, 0);
+      hook(std::integral_constant<int, M * NT + T>{});
+      hook_each<T + 1>(acc, g, wb, hook);
+    }
+  }
 };
 
 // ---- bf16x3 matrix path (opt-in): x = xh + xl, W = Wh + Wl (bf16 each), x W ~= xh Wh + xl Wh + xh Wl with float32
@@ -944,6 +979,431 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #endif
 }
 
+// ---- persistent form of the main exact-f32 instance (HC = 256 -> NC = 256, uniform tiles, big batches) -------------------------
+// On gfx950 a wave that streams f32 MFMAs leaves its SIMD neighbour no issue slot, so a second workgroup per CU buys latency
+// hiding only -- and the kernel above needs it, because a workgroup's life is a chain of exposed latencies (two dependent global
+// rounds in the prologue, four barriers per slab around single-buffered slab / half-buffered W staging, the store tail).  This
+// form spends the CU differently: ONE workgroup per CU (4 waves, 150 KB of LDS) that WALKS blocks (bid = blockIdx.x + i * gridDim.x)
+// with everything it will wait for requested a full step earlier, and with nothing but node ids ever waiting in registers:
+//   * slab s + 1 and the whole 32-row W chunk of slab s + 1 are DMA'd into the other halves of two rings at the top of slab s
+//     -> ONE barrier per slab (it both publishes slab s and retires slab s - 1's buffers) and every wait is for data requested
+//     ~9 000 cycles earlier; during the last slab the rings receive the NEXT block's slab 0 / W chunk 0;
+//   * the next block's halo ids are loaded during slab 1 (one register) and parked in the other half of a two-entry id table
+//     during slab 2; what they point at -- alpha_src of the halo rows, the cells' edge-attribute blocks and alpha_dst -- is
+//     DMA'd into LDS during slab 3 (no register results, so no compiler-placed wait); the prologue's two dependent global
+//     rounds are off the chain;
+//   * folded scale / shift and the next layer's att vectors go to LDS once per workgroup, not once per block;
+//   * the epilogue's stores are never waited for (the next wait that follows them is a whole slab later), and no LDS access of
+//     the steady state is compiler-visible (with a DMA in flight hipcc would put vmcnt(0) in front of each).
+// The arithmetic (attention coefficients, gather order, BN/ReLU, MFMA k order, epilogue) is the kernel above's, operation for
+// operation: results are bit-identical whichever form runs (tests/test_gpu_forward.py).
+template <int K>
+struct PersistLds {
+  static constexpr int HR = FusedGeom<K>::HR;
+  static constexpr int SLAB = HR * 32;                    // floats per slab buffer (f32)
+  static constexpr int WSL = 32 * 256;                    // floats per 32-row W chunk (the epilogue's store patches reuse chunk buffer 1)
+  static constexpr int APITCH = (4 * (K + 1) + 3) & ~3;
+  static constexpr int HIDP = (HR + 3) & ~3;
+  static constexpr int EAT = 128 * K * 3;                 // the cells' edge-attribute blocks
+  static constexpr int FLOATS = 2 * SLAB + 2 * WSL + 2 * 256 + 2 * 256 + 2 * HIDP + HR * 4 + EAT + 128 * 4 + 128 * APITCH;
+  static_assert(4 * 32 * TILED_PITCH <= WSL, "store patches fit a W chunk buffer");
+};
+
+__device__ __forceinline__ int lds_read_int(uint32_t addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 1) void gat_layer_persist_kernel(FusedArgs a, int uni_h, int uni_w) {
+  constexpr int HC = 256, C = 64, H = 4, NT = 8, NC = 256, NSLAB = 8, SPH = 2, NTH = 256;
+  using Geo = FusedGeom<K>;
+  using Lds = PersistLds<K>;
+  constexpr int HR = Geo::HR, HW_ = Geo::HW, RAD = Geo::R;
+  constexpr int ROWB = 128, CPR = 8;
+  constexpr int APITCH = Lds::APITCH;
+  using Off = StencilOffsets<K>;
+  static_assert(K == 4 || K == 8, "halo of one cell");
+  extern __shared__ __attribute__((aligned(128))) float lds[];
+  float *slabR = lds;                                  // [2][HR][32]
+  float *wR = slabR + 2 * Lds::SLAB;                   // [2][32][NC]   (column-permuted image, WTileGroup)
+  float *scsh = wR + 2 * Lds::WSL;                     // [2][HC]
+  float *attl = scsh + 2 * HC;                         // [2][NC]
+  int *hidR = reinterpret_cast<int *>(attl + 2 * NC);  // [2][HIDP]     halo node ids of the current / next block
+  float *hasL = reinterpret_cast<float *>(hidR + 2 * Lds::HIDP);   // [HR][H]       alpha_src of the halo rows
+  float *eatL = hasL + HR * 4;                         // [128][K][3]   edge attributes of the block's cells
+  float *advL = eatL + Lds::EAT;                       // [128][H]      alpha_dst of the block's cells
+  float *alx = advL + 128 * 4;                         // [128][APITCH]
+  float *patches = wR + Lds::WSL;                      // (epilogue only: W chunk buffer 1 is idle then)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hl = lane >> 5;
+  const int cell = wave * 32 + r;
+  const int tr = cell / TILE_W, tc = cell % TILE_W;
+  const int self_idx = (tr + RAD) * HW_ + tc + RAD;
+  constexpr int NHL = 2;
+  constexpr int NPIECE = (HR * CPR + NTH - 1) / NTH;
+  static_assert(HR <= NTH, "one halo row per thread");
+
+  // ---- once per workgroup: layer constants
+  for (int c = tid; c < HC; c += NTH) { scsh[c] = a.scale[c]; scsh[HC + c] = a.shift[c]; }
+  for (int c = tid; c < NC; c += NTH) { attl[c] = a.att_src[c]; attl[NC + c] = a.att_dst[c]; }
+  float vpre[NHL][3];
+#pragma unroll
+  for (int i = 0; i < NHL; ++i)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) vpre[i][f] = a.V[(hl + 2 * i) * 3 + f];
+  // (pin them here: left to the scheduler their wait lands inside the block loop, as a vmcnt(0) in front of phase A)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(vpre[0][0]), "+v"(vpre[0][1]), "+v"(vpre[0][2]), "+v"(vpre[1][0]), "+v"(vpre[1][1]), "+v"(vpre[1][2]));
+
+  auto swz = [](int row) { return (row >> 1) & 7; };
+  const char *zp = reinterpret_cast<const char *>(a.zero_page);
+  const int bpt = a.tb.bh * a.tb.bw;
+  const int64_t tile_cells = (int64_t)uni_h * uni_w;
+
+  // node id of this thread's halo row of block `bid` (uniform tiles: no table look-up on the way)
+  auto load_halo_id = [&](int bid) {
+    const int nb = a.tb.n_blocks, xcd = bid & 7, q = nb >> 3, rr = nb & 7;
+    const int wid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tile = wid / bpt, rem = wid - tile * bpt;
+    const int r0 = (rem / a.tb.bw) * FT_H, c0 = (rem % a.tb.bw) * TILE_W;
+    const int gr = r0 + tid / HW_ - RAD, gc = c0 + tid % HW_ - RAD;
+    int id = -1;
+    if (tid < HR && gr >= 0 && gr < uni_h && gc >= 0 && gc < uni_w) id = a.node_id[tile * tile_cells + (int64_t)gr * uni_w + gc];
+    return id;                                          // (raw: clamping here would make the caller wait for the load on the spot)
+  };
+  // what the ids of table `hidp` point at, straight into LDS: alpha_src of the halo rows, edge attributes and alpha_dst of the cells
+  auto issue_rows = [&](uint32_t hidp) {
+    {
+      const int id = tid < HR ? lds_read_int(hidp + 4 * tid) : -1;
+      constexpr int CHUNKS = K * 3 / 4;                                   // 16-byte chunks of one cell's attribute block
+      constexpr int NEP = (128 * CHUNKS + NTH - 1) / NTH;                 // ... of the block's cells, per thread
+      int cid[NEP];
+#pragma unroll
+      for (int p = 0; p < NEP; ++p) {
+        const int c = (p * NTH + tid) / CHUNKS;
+        cid[p] = c < 128 ? lds_read_int(hidp + 4 * ((c / TILE_W + RAD) * HW_ + c % TILE_W + RAD)) : -1;
+      }
+      const int own = tid < 128 ? lds_read_int(hidp + 4 * ((tid / TILE_W + RAD) * HW_ + tid % TILE_W + RAD)) : -1;
+      lds_reads_done();
+      if (tid < HR)
+        __builtin_amdgcn_global_load_lds(id >= 0 ? reinterpret_cast<const void *>(a.asd + (int64_t)id * 2 * H) : reinterpret_cast<const void *>(zp),
+                                         (__attribute__((address_space(3))) void *)(hasL + wave * 256), 16, 0, 0);
+#pragma unroll
+      for (int p = 0; p < NEP; ++p) {
+        const int idx = p * NTH + tid, ch = idx % CHUNKS;
+        const char *src = cid[p] >= 0 ? reinterpret_cast<const char *>(a.eattr) + ((int64_t)cid[p] * (K * 12) + ch * 16) : zp;
+        if ((p + 1) * NTH <= 128 * CHUNKS || idx < 128 * CHUNKS)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src),
+                                           (__attribute__((address_space(3))) void *)(eatL + (p * NTH + wave * 64) * 4), 16, 0, 0);
+      }
+      if (tid < 128)
+        __builtin_amdgcn_global_load_lds(own >= 0 ? reinterpret_cast<const void *>(a.asd + (int64_t)own * 2 * H + H) : reinterpret_cast<const void *>(zp),
+                                         (__attribute__((address_space(3))) void *)(advL + wave * 256), 16, 0, 0);
+    }
+  };
+  // DMA source bases of the slab pieces this thread moves, for the block whose ids sit in table `hidp` (rows without a node:
+  // the zero page, which is long enough to be advanced by ROWB per slab like a real row)
+  auto slab_bases = [&](uint32_t hidp, const char *(&dbase)[NPIECE]) {
+    int drow[NPIECE];
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      const int row = (p * NTH + tid) / CPR;
+      drow[p] = row < HR ? lds_read_int(hidp + 4 * row) : -1;
+    }
+    lds_reads_done();
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) if (drow[p] >= 0 && drow[p] < m) m = drow[p];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o));
+    const int id0 = __builtin_amdgcn_readfirstlane(m);
+    const char *xbase = reinterpret_cast<const char *>(a.xw) + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * (HC * 4);
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      const int idx = p * NTH + tid;
+      const int row = idx / CPR, c = (idx % CPR) ^ swz(row);
+      dbase[p] = drow[p] >= 0 ? xbase + ((uint32_t)(drow[p] - id0) * (uint32_t)(HC * 4) + (uint32_t)(c * 16)) : zp;
+    }
+  };
+  // one DMA piece of (slab s -> ring slot): pieces 0 .. NPIECE-1 the slab's, NPIECE .. NPIECE+7 the W chunk's
+  auto issue_piece = [&](const char *const (&dbase)[NPIECE], int s, int slot, auto pc) {
+    constexpr int p = decltype(pc)::value;
+    if constexpr (p < NPIECE) {
+      if ((p + 1) * NTH <= HR * CPR || p * NTH + tid < HR * CPR)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(dbase[p] + s * ROWB),
+                                         (__attribute__((address_space(3))) void *)(slabR + slot * Lds::SLAB + (p * NTH + wave * 64) * 4), 16, 0, 0);
+    } else if constexpr (p < NPIECE + 8) {
+      const int q = (p - NPIECE) * 4 + wave;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(reinterpret_cast<const char *>(a.Wt) + (int64_t)s * (Lds::WSL * 4) + q * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void *)(wR + slot * Lds::WSL + q * 256), 16, 0, 0);
+    }
+  };
+  auto issue_all = [&](const char *const (&dbase)[NPIECE], int s, int slot) {
+    issue_piece(dbase, s, slot, std::integral_constant<int, 0>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 1>{});
+    issue_piece(dbase, s, slot, std::integral_constant<int, 2>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 3>{});
+    issue_piece(dbase, s, slot, std::integral_constant<int, 4>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 5>{});
+    issue_piece(dbase, s, slot, std::integral_constant<int, 6>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 7>{});
+    issue_piece(dbase, s, slot, std::integral_constant<int, 8>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 9>{});
+    issue_piece(dbase, s, slot, std::integral_constant<int, 10>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 11>{});
+    issue_piece(dbase, s, slot, std::integral_constant<int, 12>{}); issue_piece(dbase, s, slot, std::integral_constant<int, 13>{});
+    static_assert(NPIECE + 8 <= 14, "piece list");
+  };
+
+  const int nblk = a.tb.n_blocks;
+  int bid = blockIdx.x;
+  if (bid >= nblk) return;                              // (uniform per workgroup)
+  const uint32_t hid_lds = lds_addr(hidR);
+  {
+    const int id = load_halo_id(bid);
+    if (tid < HR) hidR[tid] = id < 0 ? -1 : id;
+  }
+  __syncthreads();                                      // ids + layer constants visible
+  issue_rows(hid_lds);
+  const char *dcur[NPIECE], *dnxt[NPIECE];
+  slab_bases(hid_lds, dcur);
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) dnxt[p] = zp;
+  issue_all(dcur, 0, 0);
+
+  const uint32_t scsh0 = lds_addr(scsh) + hl * 16;
+  const uint32_t alx0 = lds_addr(alx + cell * APITCH);
+  const uint32_t has0 = lds_addr(hasL), eat0 = lds_addr(eatL + cell * K * 3), adv0 = lds_addr(advL + cell * 4);
+  float *patch = patches + wave * (32 * TILED_PITCH);
+  const uint32_t patch_w = lds_addr(patch + r * TILED_PITCH + 4 * hl);                      // + 32 g bytes: this lane's 4 columns of row r
+  const uint32_t patch_r = lds_addr(patch + (lane >> 3) * TILED_PITCH + (lane & 7) * 4);    // + 8 k rows: the store's row segment
+  const uint32_t asl = lds_addr(attl + 4 * hl);
+  int par = 0;                                          // which half of the id table belongs to the current block
+  int nid = -1;
+#if BGNN_DIAG
+  // phase timers (diagnostic build): s_memtime differences summed in scalar registers, ONE set of atomics per workgroup at the
+  // very end -- unlike the per-phase atomics of the kernel above they do not sit in front of any counted wait
+  unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = tl;
+#define PTICK(i) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); tq[i] += _t - tl; tl = _t; }
+#else
+#define PTICK(i)
+#endif
+
+  while (true) {
+    const int nbid = bid + gridDim.x;
+    const bool has_next = nbid < nblk;
+    const uint32_t hidc = hid_lds + par * (Lds::HIDP * 4), hidn = hid_lds + (par ^ 1) * (Lds::HIDP * 4);
+    // the rows of this block (alpha_src / attributes / alpha_dst) were requested during the previous block's slab 3
+    PTICK(7)
+    wait_vm_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    PTICK(0)
+    // ---- phase A: attention coefficients of heads hl, hl + 2 -> alx (attention_coefficients_head_pre's arithmetic, operands from LDS)
+    {
+      const int my = lds_read_int(hidc + 4 * self_idx);
+      f32x4 e4[K * 3 / 4];
+#pragma unroll
+      for (int i = 0; i < K * 3 / 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(e4[i]) : "v"(eat0 + 16 * i));
+      float adv[NHL];
+#pragma unroll
+      for (int i = 0; i < NHL; ++i) adv[i] = lds_read1<0>(adv0 + 4 * (hl + 2 * i));
+      int nb[K];
+      float hs[NHL][K + 1];
+#pragma unroll
+      for (int b = 0; b <= K; ++b) {
+        const int nidx = b >= K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
+        if (b < K) nb[b] = lds_read_int(hidc + 4 * nidx);
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) hs[i][b] = lds_read1<0>(has0 + 4 * (nidx * H + hl + 2 * i));
+      }
+      lds_reads_done();
+      float eraw[K * 3];
+#pragma unroll
+      for (int i = 0; i < K * 3 / 4; ++i) { eraw[4 * i] = e4[i].x; eraw[4 * i + 1] = e4[i].y; eraw[4 * i + 2] = e4[i].z; eraw[4 * i + 3] = e4[i].w; }
+#pragma unroll
+      for (int i = 0; i < NHL; ++i) {
+        float part[K + 1];
+#pragma unroll
+        for (int b = 0; b <= K; ++b) part[b] = 0.0f;
+        if (my >= 0) attention_coefficients_head_vals<K>(nb, hs[i], eraw, adv[i], vpre[i], part);
+#pragma unroll
+        for (int b = 0; b <= K; ++b)
+          asm volatile("ds_write_b32 %0, %1" ::"v"(alx0 + 4 * ((hl + 2 * i) * (K + 1) + b)), "v"(part[b]) : "memory");
+      }
+      // (alx rows are read back by the lane that wrote them: one wave's LDS operations complete in order)
+    }
+    f32x16 acc[NT];
+    PTICK(1)
+#pragma unroll 1
+    for (int s = 0; s < NSLAB; ++s) {
+      // slab s and W chunk s were requested a whole slab ago (s = 0: during the previous block's last slab)
+      wait_vm_lgkm<0>();
+      __builtin_amdgcn_s_barrier();     // publishes slab s / W s; retires the buffers of slab s - 1 (and what phase A read)
+      if (has_next) {
+        if (s == 1) nid = load_halo_id(nbid);
+        if (s == 2 && tid < HR) asm volatile("ds_write_b32 %0, %1" ::"v"(hidn + 4 * tid), "v"(nid < 0 ? -1 : nid) : "memory");
+        if (s == 3) issue_rows(hidn);
+      }
+      if (has_next && s == 6) slab_bases(hidn, dnxt);
+      // (the DMA requests for slab s + 1 -- or the next block's slab 0 -- are issued from inside the MFMA phase below)
+
+      PTICK(2)
+      const uint32_t slabs = lds_addr(slabR + (s & 1) * Lds::SLAB);
+      const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
+      f32x4 g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // gather, every neighbour's reads in flight at once (registers are not scarce here); same summation order as the kernel above
+      constexpr int GB = K + 1;
+#pragma unroll
+      for (int b0 = 0; b0 <= K; b0 += GB) {
+        f32x4 x[GB][4];
+        float al[GB];
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+          const int b = b0 + j;
+          if (b <= K) {
+            const int nidx = b >= K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
+            const uint32_t rb = slabs + nidx * 128 + ((((nidx >> 1) & 7) ^ hl) << 4);
+            al[j] = lds_read1<0>(ap + 4 * b);
+            x[j][0] = lds_read4<0>(rb); x[j][1] = lds_read4<0>(rb ^ 32); x[j][2] = lds_read4<0>(rb ^ 64); x[j][3] = lds_read4<0>(rb ^ 96);
+          }
+        }
+        lds_reads_done();
+#pragma unroll
+        for (int j = 0; j < GB; ++j)
+          if (b0 + j <= K) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[c] += al[j] * x[j][c];
+          }
+      }
+      {
+        const uint32_t cp = scsh0 + s * 128;
+        f32x4 sc[4], sh[4];
+        sc[0] = lds_read4<0>(cp); sc[1] = lds_read4<32>(cp); sc[2] = lds_read4<64>(cp); sc[3] = lds_read4<96>(cp);
+        sh[0] = lds_read4<HC * 4>(cp); sh[1] = lds_read4<HC * 4 + 32>(cp); sh[2] = lds_read4<HC * 4 + 64>(cp); sh[3] = lds_read4<HC * 4 + 96>(cp);
+        lds_reads_done();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = g[j] * sc[j] + sh[j];
+        if (a.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm("v_max_f32 %0, 0, %0" : "+v"(g[j].x)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].y));
+            asm("v_max_f32 %0, 0, %0" : "+v"(g[j].z)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].w));
+          }
+        }
+      }
+      PTICK(3)
+      const uint32_t wb0 = lds_addr(wR + (s & 1) * Lds::WSL + 4 * hl * NC + r * WTileGroup<NT>::TG);
+      // one DMA piece behind each of the first 14 second-row MFMAs (groups 0 and 1): a request's issue time passes under the
+      // 64-cycle MFMA in front of it, and the data has the rest of the phase and the next gather to land
+      const bool dma_own = s + 1 < NSLAB, dma_any = dma_own || has_next;
+      const int ds = dma_own ? s + 1 : 0, dslot = dma_own ? (s + 1) & 1 : 0;
+      auto hook = [&](auto nc) {
+        constexpr int n = decltype(nc)::value;            // MFMA slot: group * 8 + tile
+        if constexpr (n < NPIECE + 8) {
+          if (dma_any) {
+            if (dma_own) issue_piece(dcur, ds, dslot, std::integral_constant<int, n>{});
+            else issue_piece(dnxt, ds, dslot, std::integral_constant<int, n>{});
+          }
+        }
+      };
+      if (s == 0) MfmaGroups<NT, NC, 0, 8, true>::run_hooked(acc, g, wb0, hook);
+      else MfmaGroups<NT, NC, 0, 8>::run_hooked(acc, g, wb0, hook);
+      PTICK(4)
+    }
+
+    // ---- epilogue: xw_{l+1} rows + attention dots.  The store patches live in W chunk buffer 1: every wave must be past its
+    // last W fragment read.  (The next block's slab 0 / W chunk 0 are in flight into the OTHER buffers.)
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    PTICK(5)
+    {
+      constexpr int TPH = C / 32, H2 = NT / TPH;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 ps[H2], pd[H2];
+#pragma unroll
+      for (int hd = 0; hd < H2; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
+      int rid[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = wave * 32 + (lane >> 3) + 8 * k;
+        rid[k] = lds_read_int(hidc + 4 * ((c / TILE_W + RAD) * HW_ + c % TILE_W + RAD));
+      }
+      const int id = lds_read_int(hidc + 4 * self_idx);
+      lds_reads_done();
+      char *prow[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        prow[k] = (rid[k] >= 0 ? reinterpret_cast<char *>(a.out) + (int64_t)rid[k] * (NC * 4) : reinterpret_cast<char *>(a.dump)) + (lane & 7) * 16;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4 s4[4], d4[4];
+        s4[0] = lds_read4<0>(asl + t * 128); s4[1] = lds_read4<32>(asl + t * 128);
+        s4[2] = lds_read4<64>(asl + t * 128); s4[3] = lds_read4<96>(asl + t * 128);
+        d4[0] = lds_read4<NC * 4>(asl + t * 128); d4[1] = lds_read4<NC * 4 + 32>(asl + t * 128);
+        d4[2] = lds_read4<NC * 4 + 64>(asl + t * 128); d4[3] = lds_read4<NC * 4 + 96>(asl + t * 128);
+        lds_reads_done();
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 v = {acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
+          const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+          ps[t / TPH] += vlo * (f32x2){s4[gq].x, s4[gq].y}; ps[t / TPH] += vhi * (f32x2){s4[gq].z, s4[gq].w};
+          pd[t / TPH] += vlo * (f32x2){d4[gq].x, d4[gq].y}; pd[t / TPH] += vhi * (f32x2){d4[gq].z, d4[gq].w};
+          asm volatile("ds_write_b128 %0, %1" ::"v"(patch_w + gq * 32), "v"(v) : "memory");
+        }
+        asm volatile("" : "+v"(ps[t / TPH]), "+v"(pd[t / TPH]));
+        f32x4 o4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("ds_read_b128 %0, %1" : "=v"(o4[k]) : "v"(patch_r + k * (8 * TILED_PITCH * 4)));
+        lds_reads_done();                                 // (one wave's LDS operations complete in order: the reads see the writes)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(prow[k] + t * 128) = o4[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int hd = 0; hd < H2; ++hd) {
+        const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
+        const float s_ = sl + __shfl_xor(sl, 32);
+        const float d_ = dl + __shfl_xor(dl, 32);
+        if (id >= 0 && hl == 0) {
+          a.asd_out[(int64_t)id * 2 * H2 + hd] = s_;
+          a.asd_out[(int64_t)id * 2 * H2 + H2 + hd] = d_;
+        }
+      }
+    }
+    PTICK(6)
+    if (!has_next) break;
+    bid = nbid;
+    par ^= 1;
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) dcur[p] = dnxt[p];
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+#if BGNN_DIAG
+  if (a.stamps && tid == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + 16 + i, tq[i]);
+    atomicAdd(a.stamps + 16 + 13, __builtin_amdgcn_s_memtime() - t_begin);
+    atomicAdd(a.stamps + 16 + 15, (unsigned long long)((nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x));
+  }
+#endif
+#undef PTICK
+}
+
+template <int K>
+static int launch_persist(bgnn_ctx *ctx, const FusedArgs &a, int uni_h, int uni_w) {
+  constexpr size_t lds_bytes = (size_t)PersistLds<K>::FLOATS * 4;
+  static_assert(lds_bytes <= 160 * 1024, "one workgroup fits the CU's LDS");
+  static std::atomic<uint64_t> configured{0};
+  auto kern = gat_layer_persist_kernel<K>;
+  if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
+    BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
+  }
+  const int grid = (ctx->num_cus / 8) * 8;              // a multiple of 8: a workgroup stays on its XCD's range of work items
+  hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(256), lds_bytes, ctx->stream, a, uni_h, uni_w);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
 template <int HC, int C, int K, int NT, int EPI, int SP = 0>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI, SP>::FLOATS * 4;
@@ -1015,6 +1475,10 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   const bool main_shape = (HC == 256 && NC == 256) || (HC == 256 && NC == 64);
   if (split == 3 && !main_shape) return BGNN_ERR_UNSUPPORTED;          // bf16 storage: the default model's shapes only
   if ((split == 1 || split == 2) && (!main_shape || g->K == 16)) { split = 0; a.Wt = Ln.Wfp; }   // other shapes: exact-f32 instances only
+  // big uniform batches on the exact path: the persistent form of the 256 -> 256 instance (bit-identical results)
+  if (split == 0 && HC == 256 && NC == 256 && C == 64 && (g->K == 8 || g->K == 4) && g->uni_h && !g->d_atlas && ctx->opts.fused_persistent &&
+      a.tb.n_blocks >= 8 * ctx->num_cus)
+    return g->K == 8 ? launch_persist<8>(ctx, a, g->uni_h, g->uni_w) : launch_persist<4>(ctx, a, g->uni_h, g->uni_w);
 #define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
   BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
 #undef BGNN_FUSED_CASE

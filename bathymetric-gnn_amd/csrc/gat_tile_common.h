@@ -53,9 +53,15 @@ struct BlockPos {
 // XCD-aware block order: consecutive work items (adjacent cell blocks, which share halo rows) run on
 // the same XCD and hit its L2.  Bijective for any n_blocks.
 template <int TH = TILE_H>
-__device__ __forceinline__ BlockPos decode_block(const TileBlocks &tb) {
+__device__ __forceinline__ BlockPos decode_block_at(const TileBlocks &tb, int bid);
+template <int TH = TILE_H>
+__device__ __forceinline__ BlockPos decode_block(const TileBlocks &tb) { return decode_block_at<TH>(tb, blockIdx.x); }
+// (explicit index: a persistent workgroup walks bid = blockIdx.x + i * gridDim.x; with a grid that is a multiple of 8 it stays on
+//  its XCD's contiguous range of work items and the workgroups of an XCD process adjacent items at the same time)
+template <int TH>
+__device__ __forceinline__ BlockPos decode_block_at(const TileBlocks &tb, int bid) {
   const int nb = tb.n_blocks;
-  const int bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
   const int wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   BlockPos p;
   if (tb.items2) {
@@ -235,11 +241,13 @@ __device__ __forceinline__ void attention_coefficients_head(int my, int self_idx
 // attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
 // edge-attribute block, `ad` = its alpha_dst for head hh, `v` = V[hh][0..2].  Lets the caller issue those global loads before the
 // halo ids are known (one latency less on the workgroup's critical path).
-template <int H, int K, int HWID = HALO_W>
-__device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, int hh, const int *hid, const float *has,
-                                                                const float (&eraw)[K * 3], float ad, const float (&v)[3],
-                                                                float *out) {
-  using Off = StencilOffsets<K>;
+// The arithmetic of one head's attention coefficients, with every operand already in registers: `nb` = node ids of the K stencil
+// sources (< 0: absent), `hs` = alpha_src of the K sources and (slot K) of the node itself, `eraw` = the node's [K][3] edge
+// attributes, `ad` = its alpha_dst, `v` = V[head][0..2].  Shared by every caller so that they agree bit for bit.
+template <int K>
+__device__ __forceinline__ void attention_coefficients_head_vals(const int (&nb)[K], const float (&hs)[K + 1],
+                                                                 const float (&eraw)[K * 3], float ad, const float (&v)[3],
+                                                                 float *out) {
   float ea_sum[3] = {0.f, 0.f, 0.f};
   int deg = 0;
   float mx = -__builtin_inff();
@@ -247,8 +255,7 @@ __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, in
   bool present[K];
 #pragma unroll
   for (int b = 0; b < K; ++b) {
-    const int nidx = self_idx - Off::dr[b] * HWID - Off::dc[b];
-    present[b] = hid[nidx] >= 0;
+    present[b] = nb[b] >= 0;
     float dot = 0.0f;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
@@ -256,7 +263,7 @@ __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, in
       ea_sum[f] += e;
       dot += e * v[f];
     }
-    float x = has[nidx * H + hh] + ad + dot;
+    float x = hs[b] + ad + dot;
     x = x > 0.0f ? x : 0.2f * x;
     lg[b] = x;
     if (present[b]) { mx = fmaxf(mx, x); ++deg; }
@@ -266,7 +273,7 @@ __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, in
     float dot = 0.0f;
 #pragma unroll
     for (int f = 0; f < 3; ++f) dot += (ea_sum[f] / cnt) * v[f];
-    float x = has[self_idx * H + hh] + ad + dot;
+    float x = hs[K] + ad + dot;
     x = x > 0.0f ? x : 0.2f * x;
     lg[K] = x;
     mx = fmaxf(mx, x);
@@ -287,6 +294,26 @@ __device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, in
   const float rden = __builtin_amdgcn_rcpf(den);
 #pragma unroll
   for (int b = 0; b <= K; ++b) out[b] = lg[b] * rden;
+}
+
+// attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
+// edge-attribute block, `ad` = its alpha_dst for head hh, `v` = V[hh][0..2].  Lets the caller issue those global loads before the
+// halo ids are known (one latency less on the workgroup's critical path).
+template <int H, int K, int HWID = HALO_W>
+__device__ __forceinline__ void attention_coefficients_head_pre(int self_idx, int hh, const int *hid, const float *has,
+                                                                const float (&eraw)[K * 3], float ad, const float (&v)[3],
+                                                                float *out) {
+  using Off = StencilOffsets<K>;
+  int nb[K];
+  float hs[K + 1];
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    const int nidx = self_idx - Off::dr[b] * HWID - Off::dc[b];
+    nb[b] = hid[nidx];
+    hs[b] = has[nidx * H + hh];
+  }
+  hs[K] = has[self_idx * H + hh];
+  attention_coefficients_head_vals<K>(nb, hs, eraw, ad, v, out);
 }
 
 }  // namespace bgnn

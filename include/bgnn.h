@@ -62,6 +62,8 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
  *   "fold_extractor"  1 (default): extractor layer 2 folded into lin of GAT layer 0; 0: unfolded chain [BGNN_NO_FOLD]
  *   "fused_front"     1 (default): feature extractor layer 1 runs inside the lin_0 GEMM where that GEMM takes its W-resident form
  *                     (same instructions, bit-identical, one launch and 512 B/node of traffic less); 0: own launch [BGNN_NO_FUSED_FRONT]
+ *   "fused_persistent" 0 (default) / 1: opt-in experiment -- big uniform batches on the exact path run the 256 -> 256 fused layer as
+ *                     one persistent workgroup per CU (bit-identical results, currently slower)            [BGNN_PERSISTENT]
  *   "ragged_atlas"    1 (default): for ragged batches the fused layers walk a shelf-packed canvas of the grids (denser 8x16
  *                     blocks); 0: per-grid blocks                                                      [BGNN_NO_ATLAS]
  * plus experiment / diagnostic knobs ("fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",

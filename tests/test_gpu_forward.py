@@ -814,3 +814,32 @@ def test_extractor_layer_inside_the_lin0_gemm_is_bit_identical(gpu_device):
         ctx.set_option("fused_front", 1)
     for k in ("class_logits", "confidence", "correction", "class_probs"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("connectivity,shape,n", [("8-connected", (250, 250), 5), ("4-connected", (256, 256), 4), ("8-connected", (64, 512), 9)])
+def test_persistent_fused_layer_is_bit_identical(connectivity, shape, n, gpu_device):
+    """Option fused_persistent (opt-in): big uniform batches on the exact path run the 256 -> 256 fused layer in its persistent
+    form (one workgroup per CU walking blocks).  Same arithmetic, so every output must equal the one-block-per-workgroup form bit for bit:
+    ragged edge blocks, holes, an all-invalid tile, block counts that do not divide by the grid, both reference stencils."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    model = _model(synthetic.synthetic_state_dict(seed=4321))
+    gb = GraphBuilder(device=gpu_device, connectivity=connectivity)
+    eng = TileBatchEngine(model, gb, gpu_device)
+    tiles = [synthetic.synthetic_tile(shape[0], shape[1], 700 + i, "V1") for i in range(n)]
+    depth = [t[0] for t in tiles]; mask = [t[1].copy() for t in tiles]
+    mask[1][:] = False; mask[1][3, 5] = True                       # one node in an otherwise empty tile
+    mask[2][: shape[0] // 2] = False
+    hw, res, d, m, u = gb.upload_tiles(depth, mask, None, [(0.5, 0.5)] * n)
+    ctx = rt.get_context(gpu_device)
+    assert ((shape[0] + 7) // 8) * ((shape[1] + 15) // 16) * n >= 8 * 256
+    try:
+        ctx.set_option("fused_persistent", 1)
+        a = eng.infer_device(hw, res, d, m, u).clone()
+        ctx.set_option("fused_persistent", 0)
+        b = eng.infer_device(hw, res, d, m, u).clone()
+    finally:
+        ctx.set_option("fused_persistent", 0)
+    assert torch.equal(a, b)
+    assert float(a[1].max()) > 0

@@ -18,10 +18,13 @@ sd = synthetic.synthetic_state_dict(seed=1234)
 model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}); model.to(dev).eval()
 ap = argparse.ArgumentParser()
 ap.add_argument("--connectivity", default="8-connected"); ap.add_argument("--matrix-path", default="exact_f32")
+ap.add_argument("--lds-pad-kb", type=int, default=0, help="pad the fused kernels' LDS request (occupancy experiment: > 80 -> one workgroup per CU)")
 ap.add_argument("--masks", default="", help="comma-separated diag_mask values instead of the standard ablation list")
 args = ap.parse_args()
 gb = GraphBuilder(device=dev, connectivity=args.connectivity); eng = TileBatchEngine(model, gb, dev)
 eng.ctx.set_option("matrix_path", args.matrix_path)
+if args.lds_pad_kb:
+    eng.ctx.set_option("fused_lds_pad_kb", args.lds_pad_kb)
 B, S = 128, 256
 depth, mask, _ = synthetic.synthetic_tile_batch(8, S, S, 100, "V0"); depth = np.concatenate([depth] * 16); mask = np.concatenate([mask] * 16)
 d_t = torch.from_numpy(depth).to(dev).reshape(-1); m_t = torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)

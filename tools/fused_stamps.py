@@ -19,7 +19,7 @@ d_t=torch.from_numpy(depth).to(dev).reshape(-1); m_t=torch.from_numpy(mask.view(
 hw=np.tile(np.array([[S,S]],np.int32),(B,1)); res=np.full((B,2),0.5)
 eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
 lib=rt.load_library(); lib.bgnn_debug_stamps.argtypes=[C.c_void_p, C.POINTER(C.c_uint64)]
-buf=(C.c_uint64*16)(); lib.bgnn_debug_stamps(eng.ctx.handle, buf)
+buf=(C.c_uint64*32)(); lib.bgnn_debug_stamps(eng.ctx.handle, buf)
 eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
 lib.bgnn_debug_stamps(eng.ctx.handle, buf)
 n=buf[15]; names=["prologue ids","dma offs+issue","phase A","wait slab+bar","gather","wait W+bar","MFMA(+slab issue)","bar+W issue","final epilogue"]
@@ -29,3 +29,12 @@ for i,nm in enumerate(names): print("%-20s %10.0f cycles/block  %5.1f%%"%(nm, bu
 if buf[14]:
     print("in-kernel clock: %.0f MHz (s_memtime / s_memrealtime x 100 MHz over every workgroup's lifetime)" % (100.0 * buf[13] / buf[14]))
     print("workgroup lifetime: %.1f us" % (buf[14] / n / 100.0))
+
+if buf[31]:
+    # the persistent form of the 256 -> 256 instance: timers summed in registers, one set of atomics per workgroup (unperturbed)
+    pn = buf[31]; pnames = ["block-start wait + barrier", "phase A", "slab wait + barrier", "prefetch hooks", "gather + BN/ReLU", "MFMA (+ DMA requests)", "pre-epilogue barrier", "epilogue"]
+    order = [0, 1, 2, 3, 4, 5, 6] ; vals = [buf[16 + 0], buf[16 + 1], buf[16 + 2] , buf[16 + 3], buf[16 + 4], buf[16 + 5], buf[16 + 6], buf[16 + 7]]
+    lab = {0: "block-start wait + barrier", 1: "phase A", 2: "slab wait + barrier + prefetch hooks", 3: "gather + BN/ReLU", 4: "MFMA (+ DMA requests)", 5: "pre-epilogue wait + barrier", 6: "epilogue", 7: "loop bookkeeping"}
+    ptot = sum(vals)
+    print("persistent kernel: blocks", pn, "cycles/block", ptot / pn)
+    for i in range(8): print("  %-40s %10.0f cycles/block  %5.1f%%" % (lab[i], vals[i] / pn, 100 * vals[i] / ptot))
