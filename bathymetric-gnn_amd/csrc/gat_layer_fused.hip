@@ -45,10 +45,12 @@ enum { EPI_NEXT = 0, EPI_HEADS = 1 };
 // so neither the tests inside the slab loop nor the live t_prev register pair exist.
 #if BGNN_DIAG
 #define DBG(bit) (a.dbg & (bit))
+// (summed in scalar registers, written out by ONE set of atomics at the very end of the workgroup: an atomic per phase would
+//  sit in the VM queue in front of the kernel's counted waits and lengthen them -- the first version did, and measured itself)
 #define BGNN_STAMP(slot)                                                                   \
-  if (a.stamps && threadIdx.x == 0) {                                                      \
+  if (a.stamps) {                                                                          \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                            \
-    atomicAdd(a.stamps + (slot), _t - t_prev);                                             \
+    t_sum[slot] += _t - t_prev;                                                            \
     t_prev = _t;                                                                           \
   }
 #else
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   float *alx = reinterpret_cast<float *>(minid + 4) + Lds::ALIGN;   // [128][APITCH]  alpha[cell][head][K+1]; bf16 path: dense (AggWindow)
 
 #if BGNN_DIAG
+  unsigned long long t_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_clk0 = t_prev, t_real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // in-kernel clock probe
 #endif
@@ -971,6 +974,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   BGNN_STAMP(8)   // final epilogue
 #if BGNN_DIAG
   if (a.stamps && threadIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) atomicAdd(a.stamps + i, t_sum[i]);
     atomicAdd(a.stamps + 15, 1ull);
     // shader cycles and 100 MHz reference ticks of this workgroup's lifetime: clock = cycles / ticks x 100 MHz
     atomicAdd(a.stamps + 13, __builtin_amdgcn_s_memtime() - t_clk0);
