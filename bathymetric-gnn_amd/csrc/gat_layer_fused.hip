@@ -500,6 +500,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     const int row = (p * NTH + tid) / CPR;
     const int gr = pos.r0 + row / HW_ - RAD, gc = pos.c0 + row % HW_ - RAD;
     drow[p] = -1;
+    // (measured with ids COMPUTED instead of loaded, all-valid tiles: 0.3 % (exact) / 2 % (bf16) -- the id round is already hidden)
     if (row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) drow[p] = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
   }
   constexpr int NSC = (HC + NTH - 1) / NTH;
