@@ -772,8 +772,13 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
       atlas_pos[2 * t] = y; atlas_pos[2 * t + 1] = x;
       x += w + G; shelf = std::max(shelf, h);
     }
-    g->atlas_w = aw; g->atlas_h = ((y + shelf + 7) / 8) * 8;
-    atlas_meta.h = g->atlas_h; atlas_meta.w = g->atlas_w; atlas_meta.cell_off = 0; atlas_meta.rx = 1.0; atlas_meta.ry = 1.0;
+    const int ah = ((y + shelf + 7) / 8) * 8;
+    // worth it only if the canvas has fewer blocks than the grids have on their own (refinement grids: yes; two big tiles of
+    // different size: no -- they fill their own blocks already and would leave half a canvas empty)
+    if ((int64_t)(ah / 8) * (aw / 16) < (int64_t)items3.size()) {
+      g->atlas_w = aw; g->atlas_h = ah;
+      atlas_meta.h = g->atlas_h; atlas_meta.w = g->atlas_w; atlas_meta.cell_off = 0; atlas_meta.rx = 1.0; atlas_meta.ry = 1.0;
+    }
   }
   g->total_cells = (int32_t)cells; g->row_capacity = (int32_t)cells; g->n_items = (int32_t)items.size();
   DevPool &P = ctx->pool;
