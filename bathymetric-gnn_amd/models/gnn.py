@@ -211,7 +211,7 @@ class BathymetricGNN(nn.Module):
         self.classification_head = ClassificationHead(hidden_channels, hidden_channels // 2, num_classes, dropout)
         self.confidence_head = ConfidenceHead(hidden_channels, hidden_channels // 2, dropout)
         self.correction_head = CorrectionHead(hidden_channels, hidden_channels // 2, dropout) if predict_correction else None
-        self._native = {}            # id(ctx) -> (ctx, handle)
+        self._native = {}            # id(ctx) -> (weakref to ctx, handle): a model does not keep extra contexts alive
         self._native_key = None
         for sub in (self.feature_extractor, self.classification_head, self.confidence_head, self.correction_head):
             if sub is not None:
@@ -255,13 +255,20 @@ class BathymetricGNN(nn.Module):
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
-    def _drop_native(self):
-        for ctx, h in (self._native or {}).values():
+    def _drop_native(self, only_ctx_id=None):
+        """Destroy the packed copies (all, or the one on the context with this id -- called when that context closes)."""
+        for cid, (wctx, h) in list((self._native or {}).items()):
+            if only_ctx_id is not None and cid != only_ctx_id:
+                continue
+            ctx = wctx()
             try:
-                ctx.lib.bgnn_model_destroy(h)
+                if ctx is not None and (ctx.handle is not None or only_ctx_id is not None):
+                    ctx.lib.bgnn_model_destroy(h)
             except Exception:
                 pass
-        self._native, self._native_key = {}, None
+            del self._native[cid]
+        if only_ctx_id is None:
+            self._native, self._native_key = {}, None
 
     def native(self, ctx: rt.Context):
         """The packed model on ``ctx`` (one per library context; rebuilt when a weight changes)."""
@@ -279,7 +286,9 @@ class BathymetricGNN(nn.Module):
             h = C.c_void_p()
             rt.check(ctx.lib.bgnn_model_create(ctx.handle, C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)),
                                                blob.size, C.byref(h)))
-            ent = self._native[id(ctx)] = (ctx, h)
+            ent = self._native[id(ctx)] = (weakref.ref(ctx), h)
+            me, cid = weakref.ref(self), id(ctx)
+            ctx.on_close(lambda: me() is not None and me()._drop_native(cid))
         return ent[1]
 
     def __del__(self):

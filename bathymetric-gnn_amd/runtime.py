@@ -159,6 +159,25 @@ class Context:
         h = C.c_void_p()
         check(self.lib.bgnn_ctx_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.handle = h
+        self._closers = []                 # run by close() before the context goes: packed models that live on it
+
+    def on_close(self, fn):
+        """``fn()`` is called when this context is closed (objects that hold library handles created on it)."""
+        self._closers.append(fn)
+
+    def close(self):
+        """Release the context (stream-synchronised): first whatever registered through ``on_close`` (packed models), then the
+        library context with its arenas.  Graph objects built on it must not be used afterwards.  Idempotent."""
+        if getattr(self, "handle", None) is None:
+            return
+        for fn in reversed(getattr(self, "_closers", [])):
+            try:
+                fn()
+            except Exception:
+                pass
+        self._closers = []
+        h, self.handle = self.handle, None
+        self.lib.bgnn_ctx_destroy(h)
 
     # -- ordering against the caller's current torch stream ------------------------------------
     def begin(self):
@@ -213,9 +232,7 @@ class Context:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                self.lib.bgnn_ctx_destroy(self.handle)
-                self.handle = None
+            self.close()
         except Exception:
             pass
 
@@ -251,7 +268,8 @@ def get_context(device=None) -> Context:
 def new_context(device=None) -> Context:
     """An ADDITIONAL library context on ``device`` (own HIP stream, own arenas): batches submitted to different contexts
     overlap on the GPU -- the tail of one small batch's kernels runs beside the head of the next one's.  The caller keeps
-    it alive; ``get_context`` keeps returning the device's default context."""
+    it alive (models only hold weak references to the contexts they are packed on) and may ``close()`` it; ``get_context`` keeps
+    returning the device's default context."""
     return Context(resolve_device(device))
 
 

@@ -843,3 +843,33 @@ def test_persistent_fused_layer_is_bit_identical(connectivity, shape, n, gpu_dev
         ctx.set_option("fused_persistent", 0)
     assert torch.equal(a, b)
     assert float(a[1].max()) > 0
+
+
+def test_extra_contexts_are_released(gpu_device):
+    """Library contexts made with rt.new_context own device arenas; a model only holds weak references to them, so dropping (or
+    closing) one gives its memory back -- 40 contexts in a row must not accumulate (tools/stress_ragged_canvas.py did)."""
+    import gc
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    model = _model(synthetic.synthetic_state_dict(seed=3))
+    gb = GraphBuilder(device=gpu_device)
+    tiles = [synthetic.synthetic_tile(128, 128, 50 + i, "V1") for i in range(8)]
+    hw, res, d, m, u = gb.upload_tiles([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 8)
+    ref = TileBatchEngine(model, gb, gpu_device).infer_device(hw, res, d, m, u).clone()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(gpu_device)[0]
+    for i in range(40):
+        ctx = rt.new_context(gpu_device)
+        eng = TileBatchEngine(model, gb, gpu_device, ctx=ctx)
+        assert torch.equal(eng.infer_device(hw, res, d, m, u), ref)
+        torch.cuda.synchronize()
+        if i % 2:
+            ctx.close()
+            assert ctx.handle is None
+        del eng, ctx
+        gc.collect()
+    assert len(model._native) == 1                       # only the default context's copy is left
+    free1 = torch.cuda.mem_get_info(gpu_device)[0]
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB not returned"
+    assert torch.equal(TileBatchEngine(model, gb, gpu_device).infer_device(hw, res, d, m, u), ref)
