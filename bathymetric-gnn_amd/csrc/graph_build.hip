@@ -475,6 +475,14 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
   const BgnnTileMeta t = a.tiles[it.tile];
   const int h = t.h, w = t.w;
   const int ncell = it.nr * w;
+  // the length of stencil offset b depends on the tile's resolution only: once per workgroup instead of a float64 sqrt per edge
+  __shared__ double s_dist[16];
+  if ((int)threadIdx.x < st.K && threadIdx.x < 16) {
+    const double dx = (double)st.dc[threadIdx.x] * t.rx;       // (tgt_c - src_c) * res_x
+    const double dy = (double)st.dr[threadIdx.x] * t.ry;
+    s_dist[threadIdx.x] = sqrt(dx * dx + dy * dy);
+  }
+  __syncthreads();
   for (int li = threadIdx.x; li < ncell; li += blockDim.x) {
     const int r = it.r0 + li / w, c = li % w;
     const int64_t tb = t.cell_off;
@@ -546,9 +554,7 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
       }
       ev[0] = ev[1] = ev[2] = ev[3] = 0.0f;
       if (sid >= 0) {
-        const double dx = (double)st.dc[b] * t.rx;       // (tgt_c - src_c) * res_x
-        const double dy = (double)st.dr[b] * t.ry;
-        const double dist = sqrt(dx * dx + dy * dy);
+        const double dist = s_dist[b];
         const float dz = dz_tgt - a.depth[sidx];          // float32 subtract
         double slope = 0.0;
         if (dist > 0.0) slope = atan((double)dz / dist) * 57.29577951308232;   // np.degrees
@@ -564,22 +570,26 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
     };
     // the usual shapes (3 edge features, K = 8 or 16): the node's stencil row (K ids) and attribute block (K x 3 floats) leave as
     // whole 16-byte stores instead of 4 K scattered dwords (at K = 16 the scattered form wrote 5x the bytes)
+    // (eight slots at a time: at K = 16 a single pass kept 64 table values live -- 177 VGPRs, two waves per SIMD)
     auto emit_rows = [&](auto kk) {
       constexpr int KK = decltype(kk)::value;
-      int sids[KK];
-      float evs[3 * KK];
-#pragma unroll
-      for (int b = 0; b < KK; ++b) {
-        float ev[4];
-        edge_slot(b, sids[b], ev);
-        evs[3 * b] = ev[0]; evs[3 * b + 1] = ev[1]; evs[3 * b + 2] = ev[2];
-      }
       int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * KK);
-#pragma unroll
-      for (int q = 0; q < KK / 4; ++q) np[q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
       float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * (3 * KK));
+#pragma unroll 1
+      for (int half = 0; half < KK / 8; ++half) {
+        int sids[8];
+        float evs[24];
 #pragma unroll
-      for (int q = 0; q < 3 * KK / 4; ++q) ep[q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+        for (int b = 0; b < 8; ++b) {
+          float ev[4];
+          edge_slot(half * 8 + b, sids[b], ev);
+          evs[3 * b] = ev[0]; evs[3 * b + 1] = ev[1]; evs[3 * b + 2] = ev[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+      }
     };
     if constexpr (KV != 0) {
       emit_rows(std::integral_constant<int, KV>{});
