@@ -241,12 +241,13 @@ int bgnn_ctx_get_option(bgnn_ctx *ctx, const char *name, int *value) {
 }
 
 // diagnostic (not part of the documented ABI): read and clear the fused kernel's phase counters
-// (out32: counters 0..15 of the one-block-per-workgroup kernels, 16..31 of the persistent kernel)
+// (out: 64 counters -- 0..15 the one-block-per-workgroup kernels together, 16..31 the persistent kernel, 32..47 the 256 -> 64
+//  instance, 48..63 the heads instance)
 int bgnn_debug_stamps(bgnn_ctx *ctx, unsigned long long *out32) {
   if (!ctx || !out32) return BGNN_ERR_INVALID;
   (void)hipStreamSynchronize(ctx->stream);
-  if (hipMemcpy(out32, ctx->stamps, 256, hipMemcpyDeviceToHost) != hipSuccess) return BGNN_ERR_HIP;
-  (void)hipMemset(ctx->stamps, 0, 256);
+  if (hipMemcpy(out32, ctx->stamps, 512, hipMemcpyDeviceToHost) != hipSuccess) return BGNN_ERR_HIP;
+  (void)hipMemset(ctx->stamps, 0, 512);
   return BGNN_OK;
 }
 

@@ -405,7 +405,8 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int WBUF = 2 * WHalf<NT, SP>::BYTES / 4;
   // the epilogue's four wave-private 32 x 36 store patches reuse slab (+ wbuf)
   static constexpr int PATCH_PAD = EPI == EPI_NEXT && SLAB + WBUF < 4 * 32 * TILED_PITCH ? 4 * 32 * TILED_PITCH - SLAB - WBUF : 0;
-  static constexpr int RA = HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : 0);
+  static constexpr int HEADW = 96 + 6 * 32 + 8;          // heads: first-layer biases | second-layer rows (<= 4 classes + 2) | their biases
+  static constexpr int RA = HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : HEADW);
   static constexpr int RSZ = RA > RB ? RA : RB;
   static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
   // attention coefficients: [128 cells][APITCH] f32 (sparse, every head); bf16 storage path: the CURRENT head's coefficients as
@@ -517,7 +518,6 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
     for (int f = 0; f < 3; ++f) vpre[i][f] = hh < H ? a.V[hh * 3 + f] : 0.0f;
   }
-
   // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 64 / CPR rows x ROWB bytes;
   // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk p ^ swz(row), with
   // swz(row) = (row >> 1) & 7 for 128-byte rows and (row >> 2) & 3 for 64-byte rows (16 consecutive rows then cover the
@@ -561,6 +561,20 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   };
   issue_slab(0);
   BGNN_STAMP(0)   // round 1, slab 0 issued
+
+  // heads: the small second-stage weights go the same way (registers now -- with the second load round, behind the id round -- LDS at slab 0).  Read straight from global memory in the
+  // final epilogue they were 28 dependent float4 loads per lane behind runtime class tests: 41 % of that instance's lifetime.
+  float hwv[2] = {0.0f, 0.0f};
+  if constexpr (EPI == EPI_HEADS) {
+    const int nrow = a.classes + 1 + (a.has_corr ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * NTH;
+      if (idx < 96) hwv[i] = a.hd_b0[idx];
+      else if (idx < 96 + nrow * 32) hwv[i] = a.hd_W1[idx - 96];
+      else if (idx >= 288 && idx < 288 + nrow) hwv[i] = a.hd_b1[idx - 288];
+    }
+  }
 
   if (hid_v < 0) hid_v = -1;
   float eraw[K * 3], adv[NHL], hasv[H];
@@ -701,6 +715,11 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         for (int i = 0; i < NSC; ++i) {
           const int c = tid + i * NTH;
           if (c < HC) { scsh[c] = scv[i]; scsh[HC + c] = shv[i]; }
+        }
+        if constexpr (EPI == EPI_HEADS) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (tid + i * NTH < Lds::HEADW) attr[tid + i * NTH] = hwv[i];
         }
         if (EPI == EPI_NEXT && wave < 2 && lane * 4 < NC)
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>((wave == 0 ? a.att_src : a.att_dst) + lane * 4),
@@ -894,7 +913,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c0 = 8 * g + 4 * hl;                 // unit index within the head
-          const float4 b4 = *reinterpret_cast<const float4 *>(a.hd_b0 + t * 32 + c0);
+          const float4 b4 = *reinterpret_cast<const float4 *>(attl + t * 32 + c0);
           float v[4] = {acc[t][4 * g] + b4.x, acc[t][4 * g + 1] + b4.y, acc[t][4 * g + 2] + b4.z,
                         acc[t][4 * g + 3] + b4.w};
 #pragma unroll
@@ -903,15 +922,15 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (k < ncls) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(a.hd_W1 + k * 32 + c0);
+                const float4 w4 = *reinterpret_cast<const float4 *>(attl + 96 + k * 32 + c0);
                 lg[k] += v[0] * w4.x + v[1] * w4.y + v[2] * w4.z + v[3] * w4.w;
               }
             }
           } else if (t == 1) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(a.hd_W1 + ncls * 32 + c0);
+            const float4 w4 = *reinterpret_cast<const float4 *>(attl + 96 + ncls * 32 + c0);
             sc += v[0] * w4.x + v[1] * w4.y + v[2] * w4.z + v[3] * w4.w;
           } else if (a.has_corr) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(a.hd_W1 + (ncls + 1) * 32 + c0);
+            const float4 w4 = *reinterpret_cast<const float4 *>(attl + 96 + (ncls + 1) * 32 + c0);
             sr += v[0] * w4.x + v[1] * w4.y + v[2] * w4.z + v[3] * w4.w;
           }
         }
@@ -929,7 +948,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         if (id >= 0) {
           float mx = -__builtin_inff();
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < ncls) { lg[k] += a.hd_b1[k]; mx = fmaxf(mx, lg[k]); }
+          for (int k = 0; k < 4; ++k) if (k < ncls) { lg[k] += attl[288 + k]; mx = fmaxf(mx, lg[k]); }
           float pr[4], den = 0.0f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) { pr[k] = k < ncls ? expf(lg[k] - mx) : 0.0f; den += pr[k]; }
@@ -940,8 +959,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
             pr[k] = pr[k] / den;
             if (k < ncls && pr[k] > best) { best = pr[k]; arg = k; }
           }
-          const float conf = 1.0f / (1.0f + expf(-(sc + a.hd_b1[ncls])));
-          const float corr = sr + a.hd_b1[ncls + 1];
+          const float conf = 1.0f / (1.0f + expf(-(sc + attl[288 + ncls])));
+          const float corr = sr + attl[288 + ncls + 1];
           const int64_t n = id;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -975,7 +994,13 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   BGNN_STAMP(8)   // final epilogue
 #if BGNN_DIAG
   if (a.stamps && threadIdx.x == 0) {
+    // counters 0..15: every instance; 32..47: the 256 -> 64 instance; 48..63: the heads instance (16..31: the persistent kernel)
+    unsigned long long *own = a.stamps + (EPI == EPI_HEADS ? 48 : NT == 2 ? 32 : 0);
     for (int i = 0; i < 9; ++i) atomicAdd(a.stamps + i, t_sum[i]);
+    if (own != a.stamps) {
+      for (int i = 0; i < 9; ++i) atomicAdd(own + i, t_sum[i]);
+      atomicAdd(own + 15, 1ull);
+    }
     atomicAdd(a.stamps + 15, 1ull);
     // shader cycles and 100 MHz reference ticks of this workgroup's lifetime: clock = cycles / ticks x 100 MHz
     atomicAdd(a.stamps + 13, __builtin_amdgcn_s_memtime() - t_clk0);

@@ -19,7 +19,7 @@ d_t=torch.from_numpy(depth).to(dev).reshape(-1); m_t=torch.from_numpy(mask.view(
 hw=np.tile(np.array([[S,S]],np.int32),(B,1)); res=np.full((B,2),0.5)
 eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
 lib=rt.load_library(); lib.bgnn_debug_stamps.argtypes=[C.c_void_p, C.POINTER(C.c_uint64)]
-buf=(C.c_uint64*32)(); lib.bgnn_debug_stamps(eng.ctx.handle, buf)
+buf=(C.c_uint64*64)(); lib.bgnn_debug_stamps(eng.ctx.handle, buf)
 eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
 lib.bgnn_debug_stamps(eng.ctx.handle, buf)
 n=buf[15]; names=["prologue ids","dma offs+issue","phase A","wait slab+bar","gather","wait W+bar","MFMA(+slab issue)","bar+W issue","final epilogue"]
@@ -38,3 +38,9 @@ if buf[31]:
     ptot = sum(vals)
     print("persistent kernel: blocks", pn, "cycles/block", ptot / pn)
     for i in range(8): print("  %-40s %10.0f cycles/block  %5.1f%%" % (lab[i], vals[i] / pn, 100 * vals[i] / ptot))
+
+for base, title in ((32, "256 -> 64 instance"), (48, "heads instance")):
+    if buf[base + 15]:
+        nb = buf[base + 15]; tt = sum(buf[base + i] for i in range(9))
+        print(title, "blocks", nb, "cycles/block", tt / nb)
+        for i, nm in enumerate(names): print("  %-20s %10.0f cycles/block  %5.1f%%" % (nm, buf[base + i] / nb, 100 * buf[base + i] / tt))
