@@ -1,6 +1,6 @@
 """Per-phase cycle sums of the fused layer kernel.  Needs the diagnostic build of the library:
     python __graft_entry__.py --diag && BGNN_LIB=bathymetric-gnn_amd/libbgnn_hip_diag.so python tools/fused_stamps.py"""
-import os, sys, ctypes as C
+import argparse, os, sys, ctypes as C
 os.environ.setdefault("BGNN_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bathymetric-gnn_amd", "libbgnn_hip_diag.so"))
 os.environ["BGNN_FUSED_STAMPS"]="1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,14 @@ from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
 dev=torch.device("cuda:0")
 sd = synthetic.synthetic_state_dict(seed=1234)
 model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); model.load_state_dict({k: torch.as_tensor(v) for k,v in sd.items()}); model.to(dev).eval()
-gb=GraphBuilder(device=dev); eng=TileBatchEngine(model, gb, dev)
+ap = argparse.ArgumentParser()
+ap.add_argument("--connectivity", default="8-connected"); ap.add_argument("--matrix-path", default="exact_f32")
+ap.add_argument("--persistent", action="store_true", help="the 256 -> 256 exact instance in its persistent form (own counters)")
+args = ap.parse_args()
+gb=GraphBuilder(device=dev, connectivity=args.connectivity); eng=TileBatchEngine(model, gb, dev)
+eng.ctx.set_option("matrix_path", args.matrix_path)
+if args.persistent:
+    eng.ctx.set_option("fused_persistent", 1)
 B,S=128,256
 depth,mask,_=synthetic.synthetic_tile_batch(8,S,S,100,"V0"); depth=np.concatenate([depth]*16); mask=np.concatenate([mask]*16)
 d_t=torch.from_numpy(depth).to(dev).reshape(-1); m_t=torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
@@ -44,3 +51,8 @@ for base, title in ((32, "256 -> 64 instance"), (48, "heads instance")):
         nb = buf[base + 15]; tt = sum(buf[base + i] for i in range(9))
         print(title, "blocks", nb, "cycles/block", tt / nb)
         for i, nm in enumerate(names): print("  %-20s %10.0f cycles/block  %5.1f%%" % (nm, buf[base + i] / nb, 100 * buf[base + i] / tt))
+
+if buf[15] > buf[47] + buf[63]:
+    nb = buf[15] - buf[47] - buf[63]; vals = [buf[i] - buf[32 + i] - buf[48 + i] for i in range(9)]; tt = sum(vals)
+    print("256 -> 256 instances (by difference) blocks", nb, "cycles/block", tt / nb)
+    for i, nm in enumerate(names): print("  %-20s %10.0f cycles/block  %5.1f%%" % (nm, vals[i] / nb, 100 * vals[i] / tt))
