@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Race hunt for the uniform-batch paths: random tile sizes / masks / batch sizes; every option pair that must not change a bit
+(fused_persistent, fused_front) is toggled and compared, every configuration is run twice (run-to-run equality), and the bf16 path
+is checked for finiteness and distance to the exact path."""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bathymetric_gnn_amd import runtime as rt, synthetic
+from bathymetric_gnn_amd.data import GraphBuilder
+from bathymetric_gnn_amd.models import BathymetricGNN
+from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+
+ap = argparse.ArgumentParser(); ap.add_argument("--rounds", type=int, default=60); ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+sd = synthetic.synthetic_state_dict(seed=1234)
+model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0); model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}); model.to(dev).eval()
+rng = np.random.default_rng(args.seed)
+ctx = rt.get_context(dev)
+bad = 0; t0 = time.time(); nodes = 0
+for rnd in range(args.rounds):
+    conn = ["8-connected", "4-connected", "16-dilated"][rnd % 3]
+    gb = GraphBuilder(device=dev, connectivity=conn); eng = TileBatchEngine(model, gb, dev)
+    h, w = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+    n = int(rng.integers(1, max(2, (3 << 20) // (h * w))))
+    tiles = [synthetic.synthetic_tile(h, w, int(rng.integers(1 << 30)), "V1" if rng.random() < 0.7 else "V0") for _ in range(n)]
+    mask = [t[1] & (rng.random(t[1].shape) > rng.choice([0.0, 0.05, 0.5])) for t in tiles]
+    hw, res, d, m, u = gb.upload_tiles([t[0] for t in tiles], mask, None, [(0.5, 0.5)] * n)
+    outs = []
+    for pers in (0, 1):
+        for front in (1, 0):
+            ctx.set_option("fused_persistent", pers); ctx.set_option("fused_front", front)
+            a = eng.infer_device(hw, res, d, m, u).clone(); b = eng.infer_device(hw, res, d, m, u).clone()
+            outs += [a, b]
+    ctx.set_option("fused_persistent", 0); ctx.set_option("fused_front", 1)
+    ok = all(torch.equal(o, outs[0]) for o in outs[1:])
+    ctx.set_option("matrix_path", "bf16")
+    bf = eng.infer_device(hw, res, d, m, u).clone(); bf2 = eng.infer_device(hw, res, d, m, u).clone()
+    ctx.set_option("matrix_path", "exact_f32")
+    err = float((bf[1] - outs[0][1]).abs().max())
+    ok = ok and torch.equal(bf, bf2) and err < 5e-2 and bool(torch.isfinite(bf).all())
+    nodes += int(sum(int(x.sum()) for x in mask))
+    if not ok:
+        bad += 1
+        print("MISMATCH round", rnd, conn, (h, w), n, "bf16 conf err", err, [bool(torch.equal(o, outs[0])) for o in outs])
+print(f"{args.rounds} rounds, {nodes} nodes, {bad} mismatches, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
