@@ -251,10 +251,14 @@ int bgnn_debug_stamps(bgnn_ctx *ctx, unsigned long long *out32) {
   return BGNN_OK;
 }
 
+static void graph_free(bgnn_graph *g);
+
 int bgnn_ctx_destroy(bgnn_ctx *ctx) {
   if (!ctx) return BGNN_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  // graphs still alive on this context go with it: their handles are invalid from here on (bgnn.h: bgnn_ctx_destroy)
+  while (!ctx->live_graphs.empty()) graph_free(*ctx->live_graphs.begin());
   for (auto &r : ctx->prof_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto &st : ctx->staging) { (void)hipEventDestroy(st.ev); (void)hipHostFree(st.p); }
@@ -662,8 +666,12 @@ int bgnn_model_destroy(bgnn_model *m) {
 // ---- graph ------------------------------------------------------------------------------------
 static void graph_free(bgnn_graph *g) {
   DevPool &P = g->ctx->pool;
+  g->ctx->live_graphs.erase(g);
   if (g->d_tables) P.release(g->d_tables);       // ragged batch: tiles / items / items2 / items3 / canvas tables live in this block
   else if (!g->tables_cached) { P.release(g->d_tiles); P.release(g->d_items); }
+  else
+    for (auto &e : g->ctx->table_cache)          // drop this graph's reference on its cache entry (evictable at 0)
+      if (e.id == g->table_cache_id) { if (e.refs > 0) --e.refs; break; }
   P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
   P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm);
@@ -795,26 +803,33 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
       if (e.n_tiles == g->n_tiles && e.h == g->uni_h && e.w == g->uni_w && e.item_cells == item_cells &&
           e.rx == tiles->resolution[0] && e.ry == tiles->resolution[1]) { hit = &e; break; }
   if (hit) {
-    g->d_tiles = hit->d_tiles; g->d_items = hit->d_items; g->tables_cached = true;
+    g->d_tiles = hit->d_tiles; g->d_items = hit->d_items; g->tables_cached = true; g->table_cache_id = hit->id;
+    ++hit->refs;
     hit->stamp = ++ctx->table_stamp;
   } else if (cacheable) {
-    if (ctx->table_cache.size() >= 8) {                    // evict the least recently used entry (nothing in flight reads it
-      size_t lru = 0;                                      //  after a stream sync)
-      for (size_t i = 1; i < ctx->table_cache.size(); ++i) if (ctx->table_cache[i].stamp < ctx->table_cache[lru].stamp) lru = i;
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipFree(ctx->table_cache[lru].d_tiles); (void)hipFree(ctx->table_cache[lru].d_items);
-      ctx->table_cache.erase(ctx->table_cache.begin() + lru);
+    if (ctx->table_cache.size() >= 8) {                    // evict the least recently used entry NO LIVE GRAPH points into
+      size_t lru = ctx->table_cache.size();                // (nothing in flight reads it after a stream sync)
+      for (size_t i = 0; i < ctx->table_cache.size(); ++i)
+        if (ctx->table_cache[i].refs == 0 && (lru == ctx->table_cache.size() || ctx->table_cache[i].stamp < ctx->table_cache[lru].stamp)) lru = i;
+      if (lru == ctx->table_cache.size()) cacheable = false;          // every entry is pinned: this graph keeps private tables
+      else {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->table_cache[lru].d_tiles); (void)hipFree(ctx->table_cache[lru].d_items);
+        ctx->table_cache.erase(ctx->table_cache.begin() + lru);
+      }
     }
-    bgnn_ctx::TableCache e{g->n_tiles, g->uni_h, g->uni_w, item_cells, tiles->resolution[0], tiles->resolution[1], nullptr, nullptr,
-                           g->n_items, ++ctx->table_stamp};
-    if (hipMalloc((void **)&e.d_tiles, sizeof(BgnnTileMeta) * g->n_tiles) == hipSuccess &&
-        hipMalloc((void **)&e.d_items, sizeof(BgnnWorkItem) * g->n_items) == hipSuccess) {
-      ctx->table_cache.push_back(e);
-      g->d_tiles = e.d_tiles; g->d_items = e.d_items; g->tables_cached = true;
-    } else {
-      (void)hipGetLastError();
-      if (e.d_tiles) (void)hipFree(e.d_tiles);
-      cacheable = false;
+    if (cacheable) {
+      bgnn_ctx::TableCache e{g->n_tiles, g->uni_h, g->uni_w, item_cells, tiles->resolution[0], tiles->resolution[1], nullptr, nullptr,
+                             g->n_items, ++ctx->table_stamp, ctx->table_next_id++, 1};
+      if (hipMalloc((void **)&e.d_tiles, sizeof(BgnnTileMeta) * g->n_tiles) == hipSuccess &&
+          hipMalloc((void **)&e.d_items, sizeof(BgnnWorkItem) * g->n_items) == hipSuccess) {
+        ctx->table_cache.push_back(e);
+        g->d_tiles = e.d_tiles; g->d_items = e.d_items; g->tables_cached = true; g->table_cache_id = e.id;
+      } else {
+        (void)hipGetLastError();
+        if (e.d_tiles) (void)hipFree(e.d_tiles);
+        cacheable = false;
+      }
     }
   }
   // ragged batches: every host-built table travels in ONE block (one staging copy, one H2D) -- with 50 000-node VR batches
@@ -862,6 +877,7 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
   if (rc == BGNN_OK && uniform && !hit) rc = ctx_upload(ctx, items.data(), sizeof(BgnnWorkItem) * items.size(), g->d_items);
   if (rc == BGNN_OK) rc = launch_graph_build(ctx, g, tiles, opts);
   if (rc != BGNN_OK) { graph_free(g); return rc; }
+  ctx->live_graphs.insert(g);
   *out = g;
   return BGNN_OK;
 }
@@ -880,6 +896,7 @@ int bgnn_graph_from_edges(bgnn_ctx *ctx, int64_t n_nodes, int32_t n_feat, const 
   g->total_cells = (int32_t)n_nodes; g->row_capacity = (int32_t)n_nodes; g->generic_E = n_edges;
   int rc = launch_generic_build(ctx, g, n_nodes, n_feat, x, n_edges, edge_index, edge_dim, edge_attr);
   if (rc != BGNN_OK) { graph_free(g); return rc; }
+  ctx->live_graphs.insert(g);
   *out = g;
   return BGNN_OK;
 }

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <map>
+#include <set>
 #include <atomic>
 
 #include "../../include/bgnn.h"
@@ -112,9 +113,13 @@ struct bgnn_ctx {
   std::vector<Staging> staging;
   // tile / work-item tables of uniform batches, kept on the device across calls: a pipeline cuts thousands of batches of one
   // shape, and a single-tile call should not pay two host->device copies for 4 KiB of tables
-  struct TableCache { int32_t n_tiles, h, w, item_cells; double rx, ry; BgnnTileMeta *d_tiles; BgnnWorkItem *d_items; int32_t n_items; uint64_t stamp; };
+  // Entries are reference-counted by the graphs that point into them (bgnn_graph::table_cache_id): an entry is evicted only
+  // when no live graph uses it; a graph that finds the cache full of pinned entries gets private pool tables instead.
+  struct TableCache { int32_t n_tiles, h, w, item_cells; double rx, ry; BgnnTileMeta *d_tiles; BgnnWorkItem *d_items; int32_t n_items; uint64_t stamp; uint64_t id; int32_t refs; };
   std::vector<TableCache> table_cache;
-  uint64_t table_stamp = 0;
+  uint64_t table_stamp = 0, table_next_id = 1;
+  // graphs built on this context and not yet destroyed: bgnn_ctx_destroy releases them (their handles die with the context)
+  std::set<struct bgnn_graph *> live_graphs;
   int num_cus = 256;
   float *zero_page = nullptr;   // 16 KiB: [0,4K) zeros, [4K,4K+128) diagnostic counters, [8K,16K) dump rows
   unsigned long long *stamps = nullptr;   // 16 diagnostic counters (inside the zero page allocation)
@@ -182,6 +187,7 @@ struct bgnn_graph {
   int64_t *d_counts = nullptr;        // [0]=n_nodes [1]=n_edges(valid after export scan)
   int64_t *d_n_nodes_copy = nullptr;  // caller's copy of the node count (bgnn_infer_tiles: written by the compaction scan itself)
   bool tables_cached = false;         // d_tiles / d_items belong to the context's table cache (uniform batches)
+  uint64_t table_cache_id = 0;        // ... the entry this graph holds a reference on (0: none)
   float *d_x8 = nullptr;              // [rows][8]
   float *d_local_std = nullptr;       // [rows]
   int32_t *d_nbr = nullptr;           // grid: [rows][K] ; generic: col[E]

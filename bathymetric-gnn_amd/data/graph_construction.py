@@ -59,7 +59,7 @@ class GraphData:
 
     def __init__(self, ctx: rt.Context, handle, hw: np.ndarray, n_feat: int, edge_dim: int):
         self._ctx = ctx
-        self._handle = handle
+        self._h = handle
         self._hw = hw                      # int32 [T,2]
         self._cache = {}
         self._sizes = None
@@ -67,6 +67,14 @@ class GraphData:
         self.edge_dim = edge_dim
         if hw.shape[0] == 1:
             self.grid_shape = (int(hw[0, 0]), int(hw[0, 1]))   # graph_construction.py:158
+
+    @property
+    def _handle(self):
+        """The library's graph handle.  It dies with the context it was built on (``bgnn_ctx_destroy`` releases the graphs
+        still alive on it), so a graph of a closed context refuses to run instead of handing out a dangling pointer."""
+        if self._ctx.handle is None:
+            raise rt.BgnnError("this graph's library context has been closed; build the graph again on a live context")
+        return self._h
 
     # ---- sizes ---------------------------------------------------------------------------
     def _counts(self):
@@ -164,9 +172,10 @@ class GraphData:
 
     def __del__(self):
         try:
-            if self._handle:
-                self._ctx.lib.bgnn_graph_destroy(self._handle)
-                self._handle = None
+            # a closed context has already released its graphs (bgnn_ctx_destroy): nothing to free, and nothing to touch
+            if self._h and self._ctx.handle is not None:
+                self._ctx.lib.bgnn_graph_destroy(self._h)
+            self._h = None
         except Exception:
             pass
 
@@ -254,9 +263,10 @@ class GraphBuilder:
         return hw, res, depth_t, mask_t, unc_t
 
     def build_from_device(self, hw: np.ndarray, res: np.ndarray, depth_t: torch.Tensor, mask_t: torch.Tensor,
-                          unc_t: Optional[torch.Tensor]) -> GraphData:
-        """Batch entry on device-resident tiles (flat, concatenated row-major)."""
-        ctx = self._ctx()
+                          unc_t: Optional[torch.Tensor], ctx: Optional[rt.Context] = None) -> GraphData:
+        """Batch entry on device-resident tiles (flat, concatenated row-major).  ``ctx``: build on this library context
+        (``rt.new_context``) instead of the device's default one; the graph lives and dies with it."""
+        ctx = ctx if ctx is not None else self._ctx()
         cells = int((hw[:, 0].astype(np.int64) * hw[:, 1]).sum())
         if depth_t.numel() != cells or mask_t.numel() != cells or (unc_t is not None and unc_t.numel() != cells):
             raise ValueError("tile table and device buffers disagree on the number of cells")

@@ -34,6 +34,10 @@ def shard_info():
     return 0, 1
 
 
+# Channel order of a packed tile-result block: ONE order on every rank, whether or not the rank holds tiles.
+TILE_RESULT_CHANNELS = ("classification", "cleaned_depth", "confidence", "correction")
+
+
 def exchange_tile_results(mine: dict) -> dict:
     """Union of every rank's {tile index: result dict} for the host-stitch path (every rank merges, so every rank needs
     every tile).  The grids travel as ONE float32 tensor per rank (``all_gather`` of [count, channels, h, w] blocks padded
@@ -45,7 +49,10 @@ def exchange_tile_results(mine: dict) -> dict:
         return mine
     world = dist.get_world_size()
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    keys = sorted(next(iter(mine.values())).keys()) if mine else []
+    keys = []
+    if mine:
+        have = set(next(iter(mine.values())).keys())
+        keys = [k for k in TILE_RESULT_CHANNELS if k in have] + sorted(have - set(TILE_RESULT_CHANNELS))
     shape = tuple(next(iter(mine.values()))[keys[0]].shape) if mine else (0, 0)
     # agree on (channel names are fixed by the caller) count, tile shape
     meta = torch.tensor([len(mine), len(keys), shape[0], shape[1]], dtype=torch.int64, device=dev)
@@ -57,8 +64,9 @@ def exchange_tile_results(mine: dict) -> dict:
     if nmax == 0:
         return mine
     assert all(m[0] == 0 or (m[1], m[2], m[3]) == (nk, th, tw) for m in metas), "tiles of one survey share one shape"
-    if not keys:                                           # this rank holds no tile: it still takes part in the collective
-        keys = ["cleaned_depth", "classification", "confidence", "correction"][:nk]
+    if not keys:                                           # this rank holds no tile: it still takes part in the collective,
+        keys = list(TILE_RESULT_CHANNELS)[:nk]             # and unpacks in the same channel order the packing ranks used
+        assert nk <= len(TILE_RESULT_CHANNELS), "a rank without tiles can only name the standard result channels"
     idx = torch.full((nmax,), -1, dtype=torch.int64)
     blk = torch.zeros((nmax, nk, th, tw), dtype=torch.float32)
     for j, (i, r) in enumerate(sorted(mine.items())):
@@ -79,7 +87,7 @@ def exchange_tile_results(mine: dict) -> dict:
     return out
 
 
-def gather_bands_to_rank0(plan, rank: int, band: Optional[torch.Tensor], width: int, channels: int = 4):
+def gather_bands_to_rank0(plan, rank: int, band: Optional[torch.Tensor], width: int, channels: int = 4, device=None):
     """The sharded survey path's last step: every rank's stitched band [channels, rows, width] (float32) goes to rank 0 by
     point-to-point ``send`` / ``recv`` of the tensor itself (RCCL under ``nccl``; staged through the host under ``gloo``),
     one message per band -- not an all-gather of pickled arrays to everybody.  Rank 0 returns the assembled
@@ -97,11 +105,19 @@ def gather_bands_to_rank0(plan, rank: int, band: Optional[torch.Tensor], width: 
     R0, R1 = plan[0]["cell_rows"]
     if R1 > R0:
         host[:, R0:R1] = band.cpu().numpy()
+    if via_host:
+        recv_dev = torch.device("cpu")
+    elif device is not None:
+        recv_dev = torch.device(device)
+    elif band is not None:
+        recv_dev = band.device
+    else:
+        recv_dev = torch.device("cuda", torch.cuda.current_device())
     for k in range(1, len(plan)):
         R0, R1 = plan[k]["cell_rows"]
         if R1 == R0:
             continue
-        buf = torch.empty((channels, R1 - R0, width), dtype=torch.float32, device="cpu" if via_host else band.device)
+        buf = torch.empty((channels, R1 - R0, width), dtype=torch.float32, device=recv_dev)
         dist.recv(buf, src=k)
         host[:, R0:R1] = buf.cpu().numpy()
     return host
@@ -570,7 +586,7 @@ class BathymetricPipeline:
                 unc_t = up(grid.uncertainty, lo, hi, np.float32) if use_unc else None
                 _, _, band = self.process_survey_device(depth_t, valid_t, unc_t, grid.resolution, shard=(rank, world),
                                                         survey_shape=(H, W), row_offset=lo)
-            host = gather_bands_to_rank0(plan, rank, band, W)
+            host = gather_bands_to_rank0(plan, rank, band, W, device=dev)
             if host is None:
                 return None
         return {"cleaned_depth": host[3], "classification": host[0], "confidence": host[1], "correction": host[2],
@@ -583,7 +599,7 @@ class BathymetricPipeline:
         initialised ``torch.distributed`` job.  With ``host_stitch = True`` (or without a device engine) the
         reference-shaped host merge below runs instead: the tiles that pass the ``min_valid_ratio`` filter are
         dealt round-robin by index to the ranks, each rank classifies its share, the per-tile grids are
-        exchanged once (``all_gather_object``; tiles are independent, so there is no collective inside the
+        exchanged once (``exchange_tile_results``: tensors, no pickling; tiles are independent, so there is no collective inside the
         data path) and EVERY rank stitches them in ascending spec order -- the float32 blend sums and the
         ``>`` tie rule of the discrete channel therefore do not depend on the number of GPUs."""
         if self.model is None:

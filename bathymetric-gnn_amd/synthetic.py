@@ -59,25 +59,31 @@ def synthetic_tile_batch(n: int, h: int, w: int, seed0: int, variant: str = "V0"
     return depth, mask, unc
 
 
-def synthetic_survey_device(size: int, device, seed: int = 0, band: int = 4096, nodata_corner: bool = True):
+def synthetic_survey_device(size: int, device, seed: int = 0, band: int = 4096, nodata_corner: bool = True, rows=None):
     """BASELINE config 5's survey, generated ON the device (numpy would need minutes for 3.6 G cells): a ``size`` x ``size``
     float32 depth field by the SURVEY 8(d) formula (noise from torch's generator), in row bands so that no survey-sized
     temporary exists; ``nodata_corner`` writes 1e6 into the top-left tenth x eighth (tiles skipped by ``min_valid_ratio``,
-    a ragged edge).  Returns (depth [S,S] f32, valid [S,S] bool), both resident in HBM."""
+    a ragged edge).  The field is procedural in the ABSOLUTE row band (one generator seed per band of ``band`` rows), so
+    ``rows=(lo, hi)`` returns exactly the rows ``[lo, hi)`` of the full survey without generating the rest -- what a rank of
+    a row-band sharded run holds.  Returns (depth [hi-lo, S] f32, valid [hi-lo, S] bool), both resident in HBM."""
     import torch
     S = int(size)
-    g = torch.Generator(device=device); g.manual_seed(seed)
-    depth = torch.empty((S, S), dtype=torch.float32, device=device)
+    lo, hi = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
+    assert 0 <= lo <= hi <= S
+    g = torch.Generator(device=device)
+    depth = torch.empty((hi - lo, S), dtype=torch.float32, device=device)
     c = torch.arange(S, dtype=torch.float32, device=device)[None, :]
-    for r0 in range(0, S, band):
-        r1 = min(S, r0 + band)
+    for b in range(lo // band, (hi + band - 1) // band if hi > lo else 0):
+        r0, r1 = b * band, min(S, (b + 1) * band)
+        g.manual_seed(seed * 1000003 + b)
         r = torch.arange(r0, r1, dtype=torch.float32, device=device)[:, None]
         d = -20 - 0.01 * c - 0.005 * r + 0.5 * torch.sin(2 * np.pi * r / 37) * torch.cos(2 * np.pi * c / 53)
         d += 0.05 * torch.randn((r1 - r0, S), generator=g, device=device)
-        depth[r0:r1] = d
+        a, e = max(r0, lo), min(r1, hi)
+        depth[a - lo:e - lo] = d[a - r0:e - r0]
         del d
-    if nodata_corner:
-        depth[: S // 10, : S // 8] = NODATA
+    if nodata_corner and lo < S // 10:
+        depth[: min(hi, S // 10) - lo, : S // 8] = NODATA
     valid = (depth != NODATA) & torch.isfinite(depth)
     return depth, valid
 

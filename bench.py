@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: classified tile-nodes/s of the fused hot path on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--tiles B] [--tile-size S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tiles|c3|vr|survey] ...
 
-A step = one pass of the hot path over one batch of synthetic tiles already resident in HBM:
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM:
 ``bgnn_infer_tiles`` = graph build (compaction, 5x5 stats, node features, stencil table, edge
-attributes) -> 4-layer GAT forward -> heads -> node-to-grid scatter.  Workload at every N: per GPU
-a batch of B=128 tiles of 256x256 (BASELINE config[1]'s tile: k=8 / 8-connected, fp32, 4 layers,
-all-valid synthetic depth; batched as the metric's "tile-batch").  Tiles are independent, so ranks
-share nothing: weak scaling, no data-path collective (only the timing barrier / max).
+attributes) -> 4-layer GAT forward -> heads -> node-to-grid scatter.
 
-Prints ONE JSON line (rank 0).  Extra objects: ``roofline`` (dominant kernel, HIP-event timed on the
-library's stream during the timed steps), ``kernels`` (all kernel classes), ``cpu_baseline`` (the CPU
-oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+Workloads (BASELINE.json ``configs``):
+
+* ``tiles`` (default, the headline; configs[1]'s tile batched as the metric's "tile-batch"): per GPU a batch of B = 128
+  tiles of 256 x 256, k = 8 (8-connected), fp32, 4 layers, all-valid synthetic depth.
+* ``c3`` (configs[2]): the same batch with k = 16 (the '16-dilated' stencil) and bf16 node features.
+* ``vr`` (configs[3]): a stream of 4096 ragged refinement grids (3x3 .. 50x50, in = 8) packed by the reference's
+  50 000-node batch budget (``scripts/inference_native.py:128``), on one library context or dealt over several.
+* ``survey`` (configs[4]): one synthetic survey resident in HBM, overlapping 512 x 512 tiles (overlap 128) cut, classified
+  and stitched on the device (``BathymetricPipeline.process_survey_device``).  Under ``--gpus N`` the ONE survey is split
+  into row bands (strong scaling, point-to-point halo tile rows); every other workload is weak scaling, no collective.
+
+Prints ONE JSON line (rank 0).  Extra objects: ``roofline`` (dominant kernel, HIP-event timed on the library's stream
+during the timed steps), ``rooflines`` / ``kernels`` (all kernel classes), ``cpu_baseline`` (the CPU oracle timed on this
+box's host cores on a bounded sample; rank 0, N = 1 only) and -- in the default run at N = 1 -- ``config3``, ``config4``,
+``config5``: the other single-GPU BASELINE configs measured with the same protocol, each with its own ``roofline``.
 """
 import argparse
 import json
@@ -31,12 +40,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA (= vector fp32 peak)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
+DEG = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}
 
 
 def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3, act_bytes=4):
     """SURVEY.md 8(d) per-node figures (compulsory traffic: each tensor read once + written once).  ``act_bytes``: bytes per
     stored layer activation (4 = fp32, the reference's dtype; 2 = bf16 storage of BASELINE config 3).  ``fused_bytes``
-    prices the fused launches (xW in / next xW out at ``act_bytes``; attention dots and edge attributes stay f32)."""
+    prices the fused launches (xW in / next xW out at ``act_bytes``; attention dots and edge attributes stay f32);
+    ``front_bytes`` the front GEMM launch (32-byte feature row in, xW_0 + attention dots out)."""
     agg_bytes = 0
     gemm_flops = 2 * (in_ch * hidden)                              # feature extractor layer 1 (layer 2 is folded into lin_0: executed flops)
     gemm_bytes = 4 * (8 + hidden) + 4 * (hidden + hidden)
@@ -58,7 +69,9 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
     fused_flops, fused_bytes = 0, 0
     # executed flops: the extractor's second Linear is folded into lin of layer 0 (no activation between them), so the
     # hidden x hidden product of the reference is not run
-    front_flops = 2 * (in_ch * hidden + hidden * (hidden * (heads if num_layers > 1 else 1)))
+    H0 = heads if num_layers > 1 else 1
+    front_flops = 2 * (in_ch * hidden + hidden * (hidden * H0))
+    front_bytes = 32 + act_bytes * hidden * H0 + 4 * 2 * H0
     for l in range(num_layers):
         last = l == num_layers - 1
         H = 1 if last else heads
@@ -72,38 +85,76 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
             fused_flops += 2 * hidden * nh * (hidden // 2)
             fused_bytes += act_bytes * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * 3
     return {"aggregate_bytes": agg_bytes, "gemm_flops": gemm_flops, "gemm_bytes": gemm_bytes, "build_bytes": build_bytes,
-            "fused_flops": fused_flops, "fused_bytes": fused_bytes, "front_flops": front_flops}
+            "fused_flops": fused_flops, "fused_bytes": fused_bytes, "front_flops": front_flops, "front_bytes": front_bytes}
 
 
-def cpu_baseline(n_tiles, tile, sd, seed0, connectivity="8-connected"):
-    """The CPU oracle (vectorised numpy graph build + fp32 torch forward issuing torch_geometric's op
-    sequence + scatter) on `n_tiles` tiles of the same workload.  kind = "port"."""
+def cpu_baseline(n_runs, tile, sd, seed0, connectivity="8-connected"):
+    """The CPU oracle (vectorised numpy graph build + fp32 torch forward issuing torch_geometric's op sequence + scatter)
+    on ONE tile of the headline workload per run: one untimed warm-up run, then the MEDIAN of ``n_runs`` timed runs
+    (warm-up 1, median of >= 5), with the spread.  kind = "port"."""
     from bathymetric_gnn_amd import synthetic
     from oracle import gat_cpu, graph_cpu
-    tiles = [synthetic.synthetic_tile(tile, tile, seed0 + i, "V0") for i in range(n_tiles)]
-    # warm-up on a small tile (thread pools, allocator)
-    d, m, _ = synthetic.synthetic_tile(64, 64, 1, "V0")
-    gat_cpu.process_tile(sd, graph_cpu.build_graph(d, m, None, (0.5, 0.5)))
-    nodes = 0
-    t0 = time.perf_counter()
-    tg = 0.0
-    k = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}[connectivity]
-    for d, m, _ in tiles:
+    k = DEG[connectivity]
+
+    def one(seed):
+        d, m, _ = synthetic.synthetic_tile(tile, tile, seed, "V0")
         a = time.perf_counter()
         g = graph_cpu.build_graph(d, m, None, (0.5, 0.5), connectivity=connectivity)
-        tg += time.perf_counter() - a
+        b = time.perf_counter()
         gat_cpu.process_tile(sd, g)
-        nodes += g.num_nodes
-    dt = time.perf_counter() - t0
-    return {"value": nodes / dt, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_tiles} tiles of {tile}x{tile} (k={k}, 4-layer GAT, fp32): numpy graph build + torch CPU forward "
-                      f"+ scatter, {dt:.1f} s wall ({tg:.1f} s of it graph build); os.cpu_count()={os.cpu_count()}"}
+        c = time.perf_counter()
+        return g.num_nodes, c - a, b - a
+
+    one(seed0)                                                       # warm-up: thread pools, allocator, first-touch
+    t0 = time.perf_counter()
+    runs = [one(seed0 + 1 + i) for i in range(n_runs)]
+    wall = time.perf_counter() - t0
+    rates = sorted(n / t for n, t, _ in runs)
+    med = float(np.median(rates))
+    return {"value": med, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "min": rates[0], "max": rates[-1], "runs": n_runs,
+            "sample": f"median of {n_runs} runs (after 1 warm-up run) of one {tile}x{tile} tile each (k={k}, 4-layer GAT, fp32): "
+                      f"numpy graph build + torch CPU forward + scatter; {wall:.1f} s wall for the timed runs "
+                      f"({sum(r[2] for r in runs):.1f} s of it graph build); spread {rates[0]:.0f} .. {rates[-1]:.0f} nodes/s; "
+                      f"os.cpu_count()={os.cpu_count()}"}
+
+
+# ---- launching ------------------------------------------------------------------------------------------------------------
+def visible_gpu_count(env=None, sysfs="/sys/class/kfd/kfd/topology/nodes", dev_dir="/dev/dri"):
+    """GPUs this process could open, counted WITHOUT touching the HIP runtime (the parent of a multi-rank run must not
+    initialise it): KFD topology nodes with SIMDs (CPU nodes have simd_count 0) whose render node is accessible (a
+    container's device cgroup hides the others), capped by ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES when set."""
+    env = os.environ if env is None else env
+    n = 0
+    try:
+        nodes = sorted(os.listdir(sysfs))
+    except OSError:
+        nodes = []
+    for node in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(sysfs, node, "properties")) if " " in line.strip())
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+        except ValueError:
+            continue
+        if dev_dir and minor >= 0 and not os.access(os.path.join(dev_dir, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in env:
+            n = min(n, len([x for x in env[var].split(",") if x.strip()]))
+    return n
 
 
 def launch_plan(gpus, env, n_devices):
     """What `bench.py --gpus N` does with its process: ("worker", None) when a launcher (torch.distributed.run, or this
     file's own spawn) already set WORLD_SIZE; ("single", None) for N = 1; ("spawn", None) when N > 1 ranks must be
-    started from here; ("error", reason) when that cannot work.  Pure function (unit-tested on CPU)."""
+    started from here; ("error", reason) when that cannot work.  Pure function (unit-tested on CPU).  ``n_devices`` may be
+    a callable (only evaluated when ranks would have to be spawned)."""
     if gpus < 1:
         return "error", f"--gpus {gpus}: need at least one GPU"
     if "WORLD_SIZE" in env:
@@ -113,15 +164,19 @@ def launch_plan(gpus, env, n_devices):
         return ("worker" if world > 1 else "single"), None
     if gpus == 1:
         return "single", None
+    if callable(n_devices):
+        n_devices = n_devices()
     if n_devices < gpus:
         return "error", f"--gpus {gpus} but only {n_devices} GPU(s) visible on this node"
     return "spawn", None
 
 
-def spawn_ranks(n, argv, env=None, python=None):
+def spawn_ranks(n, argv, env=None, python=None, poll_s=0.2):
     """Start `n` child processes of `argv` (one per GPU: RANK = LOCAL_RANK = i, WORLD_SIZE = n, rendezvous on
-    127.0.0.1 at a free port), wait for all of them and return the worst exit status.  The parent never touches the
-    GPU, so nothing is exec'd or forked from a process that has initialised HIP."""
+    127.0.0.1 at a free port) and return the first non-zero exit status (0 if all succeed).  All children are polled
+    together: as soon as one rank fails the others -- which may sit in a barrier or a collective waiting for it -- are
+    killed, so the command fails loudly instead of hanging.  The parent never touches the GPU, so nothing is exec'd or
+    forked from a process that has initialised HIP."""
     env = dict(os.environ if env is None else env)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -133,137 +188,113 @@ def spawn_ranks(n, argv, env=None, python=None):
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([python or sys.executable] + list(argv), env=e))
     rc = 0
-    for p in procs:
-        r = p.wait()
-        if r != 0 and rc == 0:
-            rc = r if r > 0 else 1
-    if rc != 0:                                            # one rank failed: do not leave the others waiting in a barrier
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+        if live and rc == 0:
+            time.sleep(poll_s)
+    for p in live:                                             # a rank failed: the survivors are fresh processes of ours
+        p.kill()
+    for p in live:
+        p.wait()
     return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=128, help="tiles per batch per GPU")
-    ap.add_argument("--tile-size", type=int, default=256)
-    ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
-    ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="only the timed steps (no PCIe-inclusive / split-path / single-tile side measurements, no CPU baseline): "
-                         "what the rocprofv3 passes run, so that a kernel's average duration in the trace is the full-batch one")
-    ap.add_argument("--split-f16", action="store_true",
-                    help="opt-in matrix path: float16 hi/lo operand split (fp16x3), float32 accumulation (|activations| < 65504)")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="opt-in matrix path: bf16 hi/lo operand split (bf16x3) with float32 accumulation instead of exact-f32 MFMAs")
-    ap.add_argument("--unfused", action="store_true",
-                    help="run K3 / K4 / K5 / K6 as separate kernels (standalone gather-aggregate roofline)")
-    ap.add_argument("--cpu-tiles", type=int, default=4)
-    ap.add_argument("--workload", default="tiles", choices=["tiles", "vr", "c3"],
-                    help="tiles: B uniform tiles per step (headline). vr: BASELINE config 4 -- a stream of 4096 ragged "
-                         "refinement grids (3x3..50x50, in=8) packed by the reference's 50 000-node batch budget. "
-                         "c3: BASELINE configs[2] -- B tiles of 256x256 with k=16 (the '16-dilated' stencil, a build-side "
-                         "extension) and bf16 node features (layer activations stored as bf16, bf16 MFMA, f32 accumulate)")
-    ap.add_argument("--connectivity", default=None, choices=["4-connected", "8-connected", "16-dilated"])
-    ap.add_argument("--bf16", action="store_true", help="matrix_path = bf16 (bf16 activation storage + bf16 MFMA)")
-    ap.add_argument("--vr-grids", type=int, default=4096)
-    ap.add_argument("--vr-budget", type=int, default=50000)
-    ap.add_argument("--vr-streams", type=int, default=4,
-                    help="vr workload: library contexts (HIP streams) the batches are dealt over: the tail of one 50 000-node "
-                         "batch's kernels overlaps the head of the next one's")
-    args = ap.parse_args()
+# ---- workloads ------------------------------------------------------------------------------------------------------------
+class Bench:
+    """Model, graph builders and engines of one rank; builds the workloads and times them with one protocol."""
 
-    # N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (device_count() does not
-    # initialise HIP on this image), wait for them and leave with their status.
-    mode, why = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
-    if mode == "error":
-        raise SystemExit(f"bench.py: {why}")
-    if mode == "spawn":
-        raise SystemExit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # RCCL; used only for the timing barrier / max
+    def __init__(self, dev, rank, world, layers, dist=None):
+        from bathymetric_gnn_amd import runtime as rt, synthetic
+        self.rt, self.syn = rt, synthetic
+        self.dev, self.rank, self.world, self.layers, self.dist = dev, rank, world, layers, dist
+        self._models = {}
+        self.ctx = rt.get_context(dev)
+        self.nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    from bathymetric_gnn_amd import runtime as rt, synthetic
-    from bathymetric_gnn_amd.data import GraphBuilder
-    from bathymetric_gnn_amd.models import BathymetricGNN
-    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    def model(self, in_ch):
+        from bathymetric_gnn_amd.models import BathymetricGNN
+        if in_ch not in self._models:
+            sd = self.syn.synthetic_state_dict(in_channels=in_ch, num_layers=self.layers, seed=1234)
+            m = BathymetricGNN(in_channels=in_ch, num_gnn_layers=self.layers, edge_dim=3, dropout=0.0)
+            m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            self._models[in_ch] = (m.to(self.dev).eval(), sd)
+        return self._models[in_ch]
 
-    B, S = args.tiles, args.tile_size
-    in_ch = 8 if args.workload == "vr" else 7
-    sd = synthetic.synthetic_state_dict(in_channels=in_ch, num_layers=args.layers, seed=1234)
-    model = BathymetricGNN(in_channels=in_ch, num_gnn_layers=args.layers, edge_dim=3, dropout=0.0)
-    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-    model.to(dev).eval()
-    c3 = args.workload == "c3"
-    conn = args.connectivity or ("16-dilated" if c3 else "8-connected")
-    deg = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}[conn]
-    if c3:
-        args.workload, args.bf16 = "tiles", True
-    gb = GraphBuilder(connectivity=conn, device=dev)
-    eng = TileBatchEngine(model, gb, dev)
-    ctx = eng.ctx
-    # run-time switches of the library context (the environment is only read when a context is created)
-    if args.unfused:
-        ctx.set_option("fused", 0)
-    if args.split_f16 or args.split_bf16 or args.bf16:
-        ctx.set_option("matrix_path", "bf16" if args.bf16 else "fp16x3" if args.split_f16 else "bf16x3")
-    split_main = {0: None, 1: "bf16x3", 2: "fp16x3", 3: "bf16"}[ctx.get_option("matrix_path")]
-    bf16 = split_main == "bf16"
-    unfused = not ctx.get_option("fused")
-    nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize(self.dev)
 
-    if args.workload == "tiles":
-        # synthetic batch, resident in HBM before the timed region (a few distinct tiles, tiled to B)
+    # -- uniform tile batches: the headline (k = 8, f32) and configs[2] (k = 16, bf16 storage) ---------------------------
+    def tiles(self, B, S, variant, conn, matrix_path=None, unfused=False):
+        from bathymetric_gnn_amd.data import GraphBuilder
+        from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+        model, sd = self.model(7)
+        gb = GraphBuilder(connectivity=conn, device=self.dev)
+        eng = TileBatchEngine(model, gb, self.dev)
+        ctx = eng.ctx
         n_distinct = min(B, 8)
-        depth, mask, _ = synthetic.synthetic_tile_batch(n_distinct, S, S, 100 + 1000 * rank, args.variant)
+        depth, mask, _ = self.syn.synthetic_tile_batch(n_distinct, S, S, 100 + 1000 * self.rank, variant)
         reps = (B + n_distinct - 1) // n_distinct
         depth = np.concatenate([depth] * reps)[:B]; mask = np.concatenate([mask] * reps)[:B]
-        d_t = torch.from_numpy(depth).to(dev).reshape(-1)
-        m_t = torch.from_numpy(mask.view(np.uint8)).to(dev).reshape(-1)
+        d_t = torch.from_numpy(depth).to(self.dev).reshape(-1)
+        m_t = torch.from_numpy(mask.view(np.uint8)).to(self.dev).reshape(-1)
         hw = np.tile(np.array([[S, S]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
-        out = torch.empty((3, d_t.numel()), dtype=torch.float32, device=dev)
-        nodes_per_step = int(mask.sum())
-        workload_name = (f"{B} tiles of {S}x{S} per GPU per step, {conn} (k={deg}), {args.layers}-layer GAT "
-                         f"(hidden 64, heads 4), mask {args.variant}, inputs resident in HBM"
-                         + (", layer activations stored as bf16 (bf16 MFMA, f32 softmax / aggregation / accumulation)" if bf16 else ""))
+        out = torch.empty((3, d_t.numel()), dtype=torch.float32, device=self.dev)
+        opts = {}
+        if matrix_path:
+            opts["matrix_path"] = matrix_path
+        if unfused:
+            opts["fused"] = 0
+        bf16 = matrix_path == "bf16"
+        nodes = int(mask.sum())
 
         def step():
-            eng.infer_device(hw, res, d_t, m_t, None, out=out, n_nodes_out=nn_dev)
-    else:
-        # config 4: ragged refinement grids, packed greedily in stream order until the node budget is reached
-        grids = synthetic.vr_grid_stream(args.vr_grids, seed0=1000 + 100000 * rank)
-        batches, cur, cur_nodes, nodes_per_step = [], [], 0, 0
+            eng.infer_device(hw, res, d_t, m_t, None, out=out, n_nodes_out=self.nn_dev)
+
+        def check():
+            assert int(self.nn_dev.item()) == nodes
+
+        return {"kind": "tiles", "step": step, "check": check, "nodes_per_step": nodes, "contexts": [ctx], "options": opts,
+                "deg": DEG[conn], "conn": conn, "bf16": bf16, "split": matrix_path if matrix_path in ("bf16x3", "fp16x3") else None,
+                "unfused": unfused, "B": B, "S": S, "eng": eng, "gb": gb, "host": (depth, mask), "dev_in": (d_t, m_t),
+                "events_in_timed_region": True, "scaling": "weak",
+                "name": (f"{B} tiles of {S}x{S} per GPU per step, {conn} (k={DEG[conn]}), {self.layers}-layer GAT "
+                         f"(hidden 64, heads 4), mask {variant}, inputs resident in HBM"
+                         + (", layer activations stored as bf16 (bf16 MFMA, f32 softmax / aggregation / accumulation)" if bf16 else ""))}
+
+    # -- configs[3]: ragged refinement grids, packed greedily in stream order until the node budget is reached -----------
+    def vr(self, n_grids, budget, streams, grids=None):
+        from bathymetric_gnn_amd.data import GraphBuilder
+        from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+        rt = self.rt
+        model, sd = self.model(8)
+        gb = GraphBuilder(connectivity="8-connected", device=self.dev)
+        if grids is None:
+            grids = self.syn.vr_grid_stream(n_grids, seed0=1000 + 100000 * self.rank)
+        batches, cur, cur_nodes, nodes = [], [], 0, 0
         for d, u, r in grids:
-            m = (d != synthetic.NODATA) & np.isfinite(d)
+            m = (d != self.syn.NODATA) & np.isfinite(d)
             cur.append((d, m, u, r)); cur_nodes += int(m.sum())
-            if cur_nodes >= args.vr_budget:
-                batches.append(cur); nodes_per_step += cur_nodes; cur, cur_nodes = [], 0
+            if cur_nodes >= budget:
+                batches.append(cur); nodes += cur_nodes; cur, cur_nodes = [], 0
         if cur:
-            batches.append(cur); nodes_per_step += cur_nodes
+            batches.append(cur); nodes += cur_nodes
         dev_batches = []
         for b in batches:
             hw_b, res_b, d_b, m_b, u_b = gb.upload_tiles([x[0] for x in b], [x[1] for x in b], [x[2] for x in b], [x[3] for x in b])
-            dev_batches.append((hw_b, res_b, d_b, m_b, u_b, torch.empty((3, d_b.numel()), dtype=torch.float32, device=dev)))
-        workload_name = (f"{args.vr_grids} ragged refinement grids (3x3..50x50, in=8) per GPU per step in {len(batches)} batches "
-                         f"of >= {args.vr_budget} nodes dealt over {max(1, args.vr_streams)} HIP stream(s), 8-connected, {args.layers}-layer GAT, "
-                         f"inputs resident in HBM")
-
-        engines = [eng] + [TileBatchEngine(model, gb, dev, ctx=rt.new_context(dev)) for _ in range(max(1, args.vr_streams) - 1)]
-        for e in engines[1:]:
-            for k in ("fused", "matrix_path"):
-                e.ctx.set_option(k, ctx.get_option(k))
+            dev_batches.append((hw_b, res_b, d_b, m_b, u_b, torch.empty((3, d_b.numel()), dtype=torch.float32, device=self.dev)))
+        streams = max(1, streams)
+        engines = [TileBatchEngine(model, gb, self.dev)]
+        extra = [rt.new_context(self.dev) for _ in range(streams - 1)]
+        engines += [TileBatchEngine(model, gb, self.dev, ctx=c) for c in extra]
 
         def step():
             for i, (hw_b, res_b, d_b, m_b, u_b, o_b) in enumerate(dev_batches):
@@ -271,57 +302,125 @@ def main():
             for e in engines:
                 e.ctx.end()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def close():
+            for c in extra:
+                c.close()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    all_ctx = [ctx] + ([e.ctx for e in engines[1:]] if args.workload == "vr" else [])
-    # HIP events around every kernel class, recorded inside the timed region.  The vr workload issues ~700 small launches per
-    # step over several streams: there the event pairs (1 400 records a step) are host work that slows the stream itself
-    # down, so its timed steps run bare and the same K steps are repeated with events for the kernel breakdown.
-    events_in_timed_region = args.workload != "vr"
-    if events_in_timed_region:
-        for c in all_ctx:
-            c.profile(rt.K_NAMES)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if not events_in_timed_region:
-        for c in all_ctx:
-            c.profile(rt.K_NAMES)
-        for _ in range(args.steps):
-            step()
-        barrier()
-    prof = {k: {"ms": 0.0, "launches": 0} for k in rt.K_NAMES}
-    for c in all_ctx:
-        for k, v in c.profile_read().items():
-            prof[k]["ms"] += v["ms"]; prof[k]["launches"] += v["launches"]
-        c.profile([])
-    if args.workload == "tiles":
-        assert int(nn_dev.item()) == nodes_per_step
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return {"kind": "vr", "step": step, "check": lambda: None, "close": close, "nodes_per_step": nodes,
+                "contexts": [e.ctx for e in engines], "options": {}, "deg": 8, "conn": "8-connected", "bf16": False, "split": None,
+                "unfused": False, "n_grids": len(grids), "batches": len(batches), "budget": budget, "streams": streams,
+                "events_in_timed_region": False, "scaling": "weak",
+                "name": (f"{len(grids)} ragged refinement grids (3x3..50x50, in=8) per GPU per step in {len(batches)} batches "
+                         f"of >= {budget} nodes on {streams} library context(s) / HIP stream(s), 8-connected, "
+                         f"{self.layers}-layer GAT, inputs resident in HBM")}
 
-    if rank == 0:
-        am = algorithmic_model(num_layers=args.layers, deg=deg, act_bytes=2 if bf16 else 4)
-        nodes_total = nodes_per_step * args.steps * world
-        value = nodes_total / elapsed
-        kernels = {}
-        for k, v in prof.items():
-            if v["launches"]:
-                kernels[k] = {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps}
-        n_local = nodes_per_step * args.steps
+    # -- configs[4]: a survey resident in HBM, cut into overlapping tiles, classified, stitched on the device --------------
+    def survey(self, size, tile=512, overlap=128, tile_batch=32):
+        from bathymetric_gnn_amd.config import Config
+        from bathymetric_gnn_amd.models import BathymetricPipeline
+        from bathymetric_gnn_amd.models.pipeline import survey_shard_plan
+        model, sd = self.model(7)
+        cfg = Config(); cfg.tile.tile_size, cfg.tile.overlap = tile, overlap
+        pipe = BathymetricPipeline(cfg, tile_batch=tile_batch)
+        pipe.set_model(model)
+        S = int(size)
+        rank, world = self.rank, self.world
+        if world == 1:
+            depth, valid = self.syn.synthetic_survey_device(S, self.dev, seed=0)
+            lo, hi, shard = 0, S, None
+        else:       # row bands: the rank generates (procedurally, by absolute row) only the rows its own tile rows span
+            (lo, hi), plan = pipe.survey_rows_of_rank((S, S), rank, world)
+            depth, valid = self.syn.synthetic_survey_device(S, self.dev, seed=0, rows=(lo, hi))
+            shard = (rank, world)
+        state = {}
+
+        def step():
+            if hi <= lo:              # a rank without tile rows (more ranks than tile rows): nothing to classify, nothing to exchange
+                return
+            if shard is None:
+                state["out"] = pipe.process_survey_device(depth, valid, None, (0.5, 0.5))
+            else:
+                state["out"] = pipe.process_survey_device(depth, valid, None, (0.5, 0.5), shard=shard, survey_shape=(S, S),
+                                                          row_offset=lo)
+
+        # tiles processed per step by this rank (the min_valid_ratio filter is data dependent): one untimed pass
+        step()
+        torch.cuda.synchronize(self.dev)
+        n_proc, n_skip = pipe.last_tile_counts if hi > lo else (0, 0)
+        ntr, ntc, _ = pipe.tile_manager.compute_tile_grid((S, S))
+        halo = 0
+        if world > 1:                # every halo tile row travels as [3][ntc][cells] results + ntc keep flags, float32
+            halo = sum(len(p["need"]) for p in plan) * (3 * ntc * tile * tile + ntc) * 4
+        return {"kind": "survey", "step": step, "check": lambda: None, "nodes_per_step": n_proc * tile * tile,
+                "contexts": [pipe._engine.ctx], "options": {}, "deg": 8, "conn": "8-connected", "bf16": False, "split": None,
+                "unfused": False, "size": S, "tiles_total": ntr * ntc, "tiles_processed": n_proc, "tiles_skipped": n_skip,
+                "halo_bytes_all_ranks": halo, "events_in_timed_region": True, "scaling": "strong" if world > 1 else "weak",
+                "name": (f"{S}x{S} synthetic survey @0.5 m resident in HBM, {ntr * ntc} overlapping {tile}x{tile} tiles (overlap "
+                         f"{overlap}) cut / classified in batches of {tile_batch} / stitched on the device "
+                         f"(process_survey_device), 8-connected, {self.layers}-layer GAT; node evaluations = cells of processed tiles"
+                         + (f"; ONE survey row-band sharded over {world} GPUs, halo tile rows point-to-point" if world > 1 else ""))}
+
+    # -- one timing protocol for all of them ------------------------------------------------------------------------------------
+    def measure(self, wl, steps, warmup):
+        """W untimed steps, barrier + synchronize, K timed steps, barrier + synchronize; MAX over ranks.  HIP events around
+        every kernel class are recorded inside the timed region -- except for the vr workload, which issues ~700 small launches
+        per step: there the event pairs (1 400 records a step) are host work that slows the stream itself down, so its timed
+        steps run bare and the same K steps are repeated with events for the kernel breakdown."""
+        rt = self.rt
+        ctxs = wl["contexts"]
+        old = [{k: c.get_option(k) for k in wl["options"]} for c in ctxs]
+        for c in ctxs:
+            for k, v in wl["options"].items():
+                c.set_option(k, v)
+        try:
+            for _ in range(warmup):
+                wl["step"]()
+            self.barrier()
+            if wl["events_in_timed_region"]:
+                for c in ctxs:
+                    c.profile(rt.K_NAMES)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wl["step"]()
+            self.barrier()
+            elapsed = time.perf_counter() - t0
+            if not wl["events_in_timed_region"]:
+                for c in ctxs:
+                    c.profile(rt.K_NAMES)
+                for _ in range(steps):
+                    wl["step"]()
+                self.barrier()
+            prof = {k: {"ms": 0.0, "launches": 0} for k in rt.K_NAMES}
+            for c in ctxs:
+                for k, v in c.profile_read().items():
+                    prof[k]["ms"] += v["ms"]; prof[k]["launches"] += v["launches"]
+                c.profile([])
+            wl["check"]()
+        finally:
+            for c, o in zip(ctxs, old):
+                for k, v in o.items():
+                    c.set_option(k, v)
+        nodes_all = wl["nodes_per_step"]
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            n = torch.tensor([wl["nodes_per_step"]], dtype=torch.int64, device=self.dev)
+            self.dist.all_reduce(n, op=self.dist.ReduceOp.SUM)
+            nodes_all = int(n.item())
+        return {"elapsed": elapsed, "prof": prof, "steps": steps, "warmup": warmup, "nodes_all_ranks_per_step": nodes_all}
+
+    def report(self, wl, m):
+        """value / ms_per_step / rooflines / kernels of one measured workload (rank 0's kernel events)."""
+        steps, prof = m["steps"], m["prof"]
+        am = algorithmic_model(num_layers=self.layers, deg=wl["deg"], act_bytes=2 if wl["bf16"] else 4,
+                               in_ch=8 if wl["kind"] == "vr" else 7)
+        n_local = wl["nodes_per_step"] * steps
+        kernels = {k: {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps} for k, v in prof.items() if v["launches"]}
+
         def roof(kernel, key, bound, work_per_node, note):
             t = prof[key]["ms"] / 1e3
-            if t <= 0:
+            if t <= 0 or n_local <= 0:
                 return None
             unit, peak, scale = ("GB/s", HBM_PEAK_GBS, 1e9) if bound == "hbm" else ("TFLOP/s", MFMA_F32_PEAK_TFLOPS, 1e12)
             if bound == "mfma_bf16":
@@ -329,32 +428,46 @@ def main():
             ach = work_per_node * n_local / t / scale
             return {"kernel": kernel, "bound": bound, "unit": unit, "peak": peak, "achieved": ach, "frac": ach / peak,
                     "avg_launch_ms": prof[key]["ms"] / max(prof[key]["launches"], 1),
-                    "launches_per_step": prof[key]["launches"] / args.steps,
+                    "launches_per_step": prof[key]["launches"] / steps,
                     "algorithmic_work_per_node_per_forward": work_per_node, "traffic": None, "note": note}
+
+        bf16, split = wl["bf16"], wl["split"]
         roofs = {}
         if prof["fused"]["launches"]:
             if bf16:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", am["fused_flops"],
                                            "bf16 MFMA, f32 accumulate: priced against the dense bf16 MFMA peak (the kernel is not matrix-bound)")
-            elif split_main:
+            elif split:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", 3 * am["fused_flops"],
-                                           f"{split_main}: executed flops = 3 x algorithmic, priced against the dense bf16 / f16 MFMA peak")
+                                           f"{split}: executed flops = 3 x algorithmic, priced against the dense bf16 / f16 MFMA peak")
             else:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma", am["fused_flops"],
                                            "K4 gather-softmax-aggregate fused with the next layer's exact-f32 MFMA GEMM (last: heads + scatter)")
             roofs["fused_hbm"] = roof("gat_layer_fused_kernel", "fused", "hbm", am["fused_bytes"],
                                       "same launches priced by compulsory HBM bytes (read xW + attrs, write next xW)")
-            roofs["front_gemm"] = roof("gemm_f32_kernel", "gemm", "mfma", am["front_flops"], "gemm_wres64_kernel: feature extractor layer 1 in front of (extractor layer 2 folded into) lin of layer 0, one launch (executed flops)")
+            if bf16 or split:
+                # bf16 / 16-bit split MFMAs: the front GEMM's matrix work is negligible against that pipe -- it is a streaming
+                # kernel (32-byte feature row in, xW_0 + attention dots out) and is priced by its bytes
+                roofs["front_gemm"] = roof("gemm_wres64_kernel", "gemm", "hbm", am["front_bytes"],
+                                           "front GEMM on 16-bit MFMA: HBM-bound, priced by compulsory bytes (feature row in, xW_0 + attention dots out)")
+            else:
+                roofs["front_gemm"] = roof("gemm_wres64_kernel", "gemm", "mfma", am["front_flops"],
+                                           "feature extractor layer 1 in front of (extractor layer 2 folded into) lin of layer 0, one launch (executed flops, exact f32 MFMA)")
+                roofs["front_gemm_hbm"] = roof("gemm_wres64_kernel", "gemm", "hbm", am["front_bytes"], "same launch priced by compulsory HBM bytes")
+            if prof["features"]["launches"]:
+                roofs["features_hbm"] = roof("features_kernel", "features", "hbm", am["build_bytes"],
+                                             "K1b + K2: node features, stencil table, edge attributes (native-internal graph form)")
         else:
             roofs["aggregate_hbm"] = roof("gat_aggregate_tiled_kernel", "aggregate", "hbm", am["aggregate_bytes"],
                                           "standalone K4 (LDS-tiled gather-softmax-aggregate + BN + ReLU)")
             roofs["gemm_mfma"] = roof("gemm_f32_kernel", "gemm", "mfma", am["gemm_flops"], "all K3 GEMMs, exact f32 MFMA")
         roofs = {k: v for k, v in roofs.items() if v}
-        # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach if present
+        # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach to the workload it was collected on
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # (the counters were collected on the default workload only: 128 tiles of 256 x 256, 4 layers)
-        pmc_key = (":c3" if (deg == 16 and bf16) else None if (deg != 8 or bf16) else ":split" if split_main else "")
-        if os.path.exists(pmc) and args.workload == "tiles" and (B, S, args.layers) == (128, 256, 4) and pmc_key is not None:
+        pmc_key = None
+        if wl["kind"] == "tiles" and (wl["B"], wl["S"], self.layers) == (128, 256, 4):
+            pmc_key = ":c3" if (wl["deg"] == 16 and bf16) else None if (wl["deg"] != 8 or bf16) else ":split" if split else ""
+        if os.path.exists(pmc) and pmc_key is not None:
             try:
                 t = json.load(open(pmc))
                 for v in roofs.values():
@@ -368,30 +481,124 @@ def main():
             except Exception:
                 pass
         if "fused_mfma" in roofs:
-            dominant = roofs["fused_hbm"] if split_main else roofs["fused_mfma"]    # bf16x3: the fused kernel is memory-side bound
-        else:
+            dominant = roofs["fused_hbm"] if (split or bf16) else roofs["fused_mfma"]   # 16-bit MFMA paths: memory-side bound
+        elif roofs:
             dominant = max(roofs.values(), key=lambda v: v["avg_launch_ms"] * v["launches_per_step"])
+        else:
+            dominant = {}
+        for v in roofs.values():
+            assert v["frac"] <= 1.0, f"roofline fraction above 1 for {v['kernel']}: mis-priced"
+        nodes_all = m["nodes_all_ranks_per_step"]
+        return {"value": nodes_all * steps / m["elapsed"], "unit": "nodes/s", "ms_per_step": m["elapsed"] / steps * 1e3,
+                "steps": steps, "warmup": m["warmup"], "workload": wl["name"], "nodes_per_step_per_gpu": wl["nodes_per_step"],
+                "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                           "kernel", "avg_launch_ms")},
+                "rooflines": roofs, "kernels": kernels,
+                "kernel_events": "inside the timed region" if wl["events_in_timed_region"] else "separate pass of the same steps (timed steps ran bare)"}
+
+
+def dtype_name(wl):
+    if wl["bf16"]:
+        return "bf16 (layer activations stored as bf16, bf16 MFMA; f32 softmax / aggregation / accumulation / outputs)"
+    if wl["split"]:
+        return f"f32 ({wl['split']} split-operand MFMA, f32 accumulate)"
+    return "f32"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tiles", type=int, default=128, help="tiles per batch per GPU")
+    ap.add_argument("--tile-size", type=int, default=256)
+    ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (no config3 / config4 / config5 / PCIe-inclusive / split-path / single-tile side "
+                         "measurements, no CPU baseline): what the rocprofv3 passes run, so that a kernel's average duration in the "
+                         "trace is the full-batch one")
+    ap.add_argument("--split-f16", action="store_true",
+                    help="opt-in matrix path: float16 hi/lo operand split (fp16x3), float32 accumulation (|activations| < 65504)")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="opt-in matrix path: bf16 hi/lo operand split (bf16x3) with float32 accumulation instead of exact-f32 MFMAs")
+    ap.add_argument("--unfused", action="store_true",
+                    help="run K3 / K4 / K5 / K6 as separate kernels (standalone gather-aggregate roofline)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="CPU baseline: timed single-tile runs (median reported)")
+    ap.add_argument("--workload", default="tiles", choices=["tiles", "vr", "c3", "survey"],
+                    help="tiles: B uniform tiles per step (headline). c3: BASELINE configs[2] -- B tiles of 256x256 with k=16 (the "
+                         "'16-dilated' stencil, a build-side extension) and bf16 node features. vr: configs[3] -- 4096 ragged refinement "
+                         "grids packed by the reference's 50 000-node batch budget. survey: configs[4] -- one survey resident in HBM, "
+                         "overlapping 512x512 tiles cut, classified and stitched on the device (row-band sharded under --gpus N)")
+    ap.add_argument("--connectivity", default=None, choices=["4-connected", "8-connected", "16-dilated"])
+    ap.add_argument("--bf16", action="store_true", help="matrix_path = bf16 (bf16 activation storage + bf16 MFMA)")
+    ap.add_argument("--vr-grids", type=int, default=4096)
+    ap.add_argument("--vr-budget", type=int, default=50000)
+    ap.add_argument("--vr-streams", type=int, default=4,
+                    help="vr workload: library contexts (HIP streams) the batches are dealt over: the tail of one 50 000-node "
+                         "batch's kernels overlaps the head of the next one's")
+    ap.add_argument("--survey-size", type=int, default=20000, help="survey workload: side of the square survey in cells (config 5: 60000)")
+    ap.add_argument("--extras-survey-size", type=int, default=20000, help="side of the config5 survey measured beside the default headline")
+    args = ap.parse_args()
+
+    # N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (the device count comes from the KFD
+    # topology in sysfs, not from the HIP runtime), wait for them and leave with their status.
+    mode, why = launch_plan(args.gpus, os.environ, visible_gpu_count)
+    if mode == "error":
+        raise SystemExit(f"bench.py: {why}")
+    if mode == "spawn":
+        raise SystemExit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # RCCL: the timing barrier / max; the survey workload's halo rows
+
+    bench = Bench(dev, rank, world, args.layers, dist)
+    S, B = args.tile_size, args.tiles
+    mp = "bf16" if (args.bf16 or args.workload == "c3") else "fp16x3" if args.split_f16 else "bf16x3" if args.split_bf16 else None
+    if args.workload in ("tiles", "c3"):
+        conn = args.connectivity or ("16-dilated" if args.workload == "c3" else "8-connected")
+        wl = bench.tiles(B, S, args.variant, conn, matrix_path=mp, unfused=args.unfused)
+    elif args.workload == "vr":
+        wl = bench.vr(args.vr_grids, args.vr_budget, args.vr_streams)
+    else:
+        wl = bench.survey(args.survey_size)
+    m = bench.measure(wl, args.steps, args.warmup)
+
+    if rank == 0:
+        rep = bench.report(wl, m)
         line = {
-            "metric": "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)",
-            "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": ("bf16 (layer activations stored as bf16, bf16 MFMA; f32 softmax / aggregation / accumulation / outputs)" if bf16
-                      else f"f32 ({split_main} split-operand MFMA, f32 accumulate)" if split_main else "f32"),
-            "data": "synthetic",
-            "config": {"workload": workload_name,
-                       "tiles_per_gpu": B if args.workload == "tiles" else args.vr_grids, "tile": S if args.workload == "tiles" else "3..50",
-                       "nodes_per_step_per_gpu": nodes_per_step,
-                       "parallelism": f"tile-sharded x{world}, no collective"},
-            "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                       "kernel", "avg_launch_ms")},
-            "rooflines": roofs, "kernels": kernels,
-            "kernel_events": "inside the timed region" if events_in_timed_region else "separate pass of the same steps (timed steps ran bare)",
-            "path": "unfused" if unfused else "fused",
-            "matrix_path": "bf16 storage + bf16 MFMA (BASELINE configs[2])" if bf16 else f"{split_main} split (opt-in)" if split_main else "exact f32",
+            "metric": ("classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)" if wl["kind"] != "survey" else
+                       "classified tile-nodes/s (node evaluations of the survey's overlapping tiles: cut + graph build + GAT forward + stitch)"),
+            "value": rep["value"], "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": wl["scaling"],
+            "vs_baseline": None, "dtype": dtype_name(wl), "data": "synthetic",
+            "config": {"workload": wl["name"],
+                       "tiles_per_gpu": B if wl["kind"] == "tiles" else wl.get("n_grids", wl.get("tiles_processed")),
+                       "tile": S if wl["kind"] == "tiles" else "3..50" if wl["kind"] == "vr" else 512,
+                       "nodes_per_step_per_gpu": wl["nodes_per_step"],
+                       "parallelism": (f"tile-sharded x{world}, no collective" if wl["kind"] != "survey" else
+                                       f"row bands x{world}, halo tile rows point-to-point ({wl['halo_bytes_all_ranks'] / 1e9:.2f} GB per step), no collective")},
+            "roofline": rep["roofline"], "rooflines": rep["rooflines"], "kernels": rep["kernels"],
+            "kernel_events": rep["kernel_events"],
+            "path": "unfused" if wl["unfused"] else "fused",
+            "matrix_path": "bf16 storage + bf16 MFMA (BASELINE configs[2])" if wl["bf16"] else f"{wl['split']} split (opt-in)" if wl["split"] else "exact f32",
         }
-        extras = not args.no_extras
-        if extras and world == 1 and args.workload == "tiles" and not unfused:
+        if wl["kind"] == "survey":
+            line["survey"] = {k: wl[k] for k in ("size", "tiles_total", "tiles_processed", "tiles_skipped", "halo_bytes_all_ranks")}
+        extras = not args.no_extras and world == 1
+        default_headline = wl["kind"] == "tiles" and not wl["unfused"] and not wl["bf16"] and not wl["split"]
+        if extras and wl["kind"] == "tiles" and not wl["unfused"]:
+            eng, (depth, mask), (d_t, m_t) = wl["eng"], wl["host"], wl["dev_in"]
+            ctx = eng.ctx
+            scope = ctx.options(**wl["options"])
+            scope.__enter__()
             # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
             # D2H on three streams, two slots in flight.  Reported beside `value`, never as it.
             from bathymetric_gnn_amd.models.pipeline import HostTilePipeline
@@ -407,16 +614,34 @@ def main():
             got += len(list(hp.drain()))
             t_pc = time.perf_counter() - t1
             assert got == n_pc
-            line["pcie_inclusive"] = {"value": nodes_per_step * n_pc / t_pc, "unit": "nodes/s", "ms_per_step": t_pc / n_pc * 1e3,
+            line["pcie_inclusive"] = {"value": wl["nodes_per_step"] * n_pc / t_pc, "unit": "nodes/s", "ms_per_step": t_pc / n_pc * 1e3,
                                       "steps": n_pc, "bytes_per_cell": {"h2d": 5, "d2h": 12},
                                       "note": "host numpy tiles in, host grids out: pinned double-buffered staging, H2D / "
                                               "compute / D2H overlapped on three streams (HostTilePipeline)"}
-        if extras and world == 1 and args.workload == "tiles" and not unfused and not split_main:
-            # Opt-in matrix path, reported BESIDE the headline (never as it): bf16 hi/lo operand split (bf16x3) on the bf16
-            # matrix cores with float32 accumulation.  Same inputs, same timing protocol; the distance of its class logits
-            # to the exact-f32 path is measured on one tile of the batch.
+            del hp
+            if B > 1:
+                # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
+                d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
+                hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)
+                out1 = torch.empty((3, S * S), dtype=torch.float32, device=dev)
+                for _ in range(5):
+                    eng.infer_device(hw1, res1, d1, m1, None, out=out1)
+                torch.cuda.synchronize(dev); t3 = time.perf_counter()
+                n_one = 50
+                for _ in range(n_one):
+                    eng.infer_device(hw1, res1, d1, m1, None, out=out1)
+                torch.cuda.synchronize(dev); t_one = (time.perf_counter() - t3) / n_one
+                line["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
+                                       "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
+            scope.__exit__(None, None, None)
+        if extras and default_headline:
+            # Opt-in matrix paths, reported BESIDE the headline (never as it): hi/lo operand splits on the 16-bit matrix cores with
+            # float32 accumulation.  Same inputs, same timing protocol; the distance of their class logits to the exact-f32 path
+            # is measured on one tile of the batch.
             from bathymetric_gnn_amd.data import GraphBuilder as _GB
-            g1 = _GB(device=dev).build_graph(depth[0], mask[0], None, (0.5, 0.5))
+            model = bench.model(7)[0]
+            ctx = wl["eng"].ctx
+            g1 = _GB(device=dev).build_graph(wl["host"][0][0], wl["host"][1][0], None, (0.5, 0.5))
             lg_exact = model.predict(g1)["class_logits"].clone()
             for key, env, instr in (("split_bf16x3", "bf16x3", "v_mfma_f32_32x32x16_bf16"),
                                     ("split_fp16x3", "fp16x3", "v_mfma_f32_32x32x16_f16")):
@@ -424,35 +649,57 @@ def main():
                 try:
                     lg_split = model.predict(g1)["class_logits"]
                     for _ in range(2):
-                        step()
+                        wl["step"]()
                     n_sp = max(4, min(args.steps, 10))
                     torch.cuda.synchronize(dev); t2 = time.perf_counter()
                     for _ in range(n_sp):
-                        step()
+                        wl["step"]()
                     torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
                 finally:
                     ctx.set_option("matrix_path", "exact_f32")
-                line[key] = {"value": nodes_per_step * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
+                line[key] = {"value": wl["nodes_per_step"] * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
                              "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
                              "note": f"matrix_path={env}: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
                                      "opt-in, not the headline"}
-        if extras and world == 1 and args.workload == "tiles" and not unfused and B > 1:
-            # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
-            d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
-            hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)
-            out1 = torch.empty((3, S * S), dtype=torch.float32, device=dev)
-            for _ in range(5):
-                eng.infer_device(hw1, res1, d1, m1, None, out=out1)
-            torch.cuda.synchronize(dev); t3 = time.perf_counter()
-            n_one = 50
-            for _ in range(n_one):
-                eng.infer_device(hw1, res1, d1, m1, None, out=out1)
-            torch.cuda.synchronize(dev); t_one = (time.perf_counter() - t3) / n_one
-            line["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
-                                   "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
-        if extras and world == 1 and not args.no_cpu_baseline and args.workload == "tiles":
-            line["cpu_baseline"] = cpu_baseline(args.cpu_tiles, S, sd, 100, conn)
-            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            del g1
+            # ---- the other single-GPU BASELINE configs, same protocol (rank 0, N = 1), each with its own roofline ----------
+            k_x, w_x = max(4, min(args.steps, 10)), 2
+
+            def side(w, steps=k_x, warmup=w_x, extra=None):
+                r = bench.report(w, bench.measure(w, steps, warmup))
+                r["dtype"] = dtype_name(w)
+                r["higher_is_better"] = True
+                if extra:
+                    r.update(extra)
+                if "close" in w:
+                    w["close"]()
+                return r
+
+            c3 = bench.tiles(128, 256, "V0", "16-dilated", matrix_path="bf16")
+            line["config3"] = side(c3, extra={"config": "BASELINE configs[2]: batch of 128 x 256x256 tiles, k=16, bf16 node features"})
+            del c3
+            torch.cuda.empty_cache()
+            grids = bench.syn.vr_grid_stream(args.vr_grids, seed0=1000)
+            v1 = side(bench.vr(args.vr_grids, args.vr_budget, 1, grids=grids))
+            v4 = side(bench.vr(args.vr_grids, args.vr_budget, 4, grids=grids))
+            line["config4"] = {"config": "BASELINE configs[3]: VR-BAG mixed refinement grids (3x3..50x50), 4096-grid stream, "
+                                         f"{args.vr_budget}-node batches (scripts/inference_native.py:128)",
+                               "value": v1["value"], "unit": "nodes/s", "ms_per_step": v1["ms_per_step"], "roofline": v1["roofline"],
+                               "note": "value = ONE library context / HIP stream: what NativeVRProcessor.flush_batch (the reference-shaped "
+                                       "API) gives; four_contexts = the same batches dealt over 4 contexts",
+                               "one_context": v1, "four_contexts": v4}
+            del grids
+            torch.cuda.empty_cache()
+            sv = bench.survey(args.extras_survey_size)
+            line["config5"] = side(sv, steps=1, warmup=0, extra={
+                "config": f"BASELINE configs[4] at {args.extras_survey_size}x{args.extras_survey_size} on ONE GPU (the full 60000x60000 survey runs "
+                          "in tests/test_gpu_survey.py and with --workload survey --survey-size 60000)",
+                "survey": {k: sv[k] for k in ("size", "tiles_total", "tiles_processed", "tiles_skipped")}})
+            del sv
+            torch.cuda.empty_cache()
+        if extras and not args.no_cpu_baseline and wl["kind"] == "tiles":
+            line["cpu_baseline"] = cpu_baseline(args.cpu_runs, S, bench.model(7)[1], 100, wl["conn"])
+            line["gpu_over_cpu"] = rep["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

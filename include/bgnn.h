@@ -49,6 +49,9 @@ const char *bgnn_last_error(void);
  * Replaces: the device selection in models/pipeline.py:73-88 and
  * scripts/inference_native.py:381-394. */
 int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out);
+/* Synchronises the stream and releases the context's arenas AND every graph built on it that has not been destroyed yet:
+ * their bgnn_graph handles are invalid afterwards and must not be passed to any call, bgnn_graph_destroy included.
+ * Models are separate allocations: destroy them first. */
 int bgnn_ctx_destroy(bgnn_ctx *ctx);
 int bgnn_ctx_synchronize(bgnn_ctx *ctx);
 void *bgnn_ctx_stream(bgnn_ctx *ctx);

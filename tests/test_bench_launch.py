@@ -58,3 +58,60 @@ def test_bare_multi_gpu_invocation_fails_loudly_without_the_devices():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode != 0
     assert b"--gpus 2 but only" in r.stderr and b"n_gpus" not in r.stdout
+
+
+def _fake_kfd(tmp_path, nodes):
+    """nodes: list of (simd_count, render_minor, device_file_exists)"""
+    sysfs = tmp_path / "nodes"; dev = tmp_path / "dri"
+    sysfs.mkdir(); dev.mkdir()
+    for i, (simd, minor, present) in enumerate(nodes):
+        (sysfs / str(i)).mkdir()
+        (sysfs / str(i) / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+        if present:
+            (dev / f"renderD{minor}").write_text("")
+    return str(sysfs), str(dev)
+
+
+def test_visible_gpu_count_reads_the_kfd_topology_not_the_runtime(tmp_path):
+    """the parent of a multi-rank run counts GPUs without torch / HIP: KFD nodes with SIMDs whose render
+    node this process can open, capped by the *_VISIBLE_DEVICES lists."""
+    sysfs, dev = _fake_kfd(tmp_path, [(0, 0, False), (0, 0, False)] + [(1024, 128 + i, i < 3) for i in range(8)])
+    assert bench.visible_gpu_count({}, sysfs, dev) == 3                        # 8 GPUs on the host, 3 render nodes in this container
+    assert bench.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,1"}, sysfs, dev) == 2
+    assert bench.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "0,1,2,3,4"}, sysfs, dev) == 3
+    assert bench.visible_gpu_count({"CUDA_VISIBLE_DEVICES": ""}, sysfs, dev) == 0
+    assert bench.visible_gpu_count({}, str(tmp_path / "missing"), dev) == 0
+    # launch_plan takes the count lazily: a launcher-started worker never evaluates it
+    boom = lambda: (_ for _ in ()).throw(AssertionError("evaluated"))
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8"}, boom) == ("worker", None)
+    assert bench.launch_plan(1, {}, boom) == ("single", None)
+    assert bench.launch_plan(2, {}, lambda: 2) == ("spawn", None)
+
+
+def test_spawn_ranks_kills_the_survivors_of_a_failed_rank(tmp_path):
+    """rank 1 dies while rank 0 would sit in a barrier for a long time -- the command must come back with rank 1's
+    status at once instead of waiting for rank 0."""
+    import time
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    time.sleep(0.5); sys.exit(9)\n"
+                      "time.sleep(120)\n")
+    t0 = time.perf_counter()
+    assert bench.spawn_ranks(2, [str(script)]) == 9
+    assert time.perf_counter() - t0 < 30
+
+
+@pytest.mark.parametrize("workload", ["c3", "vr", "survey"])
+def test_every_workload_is_accepted_under_gpus_n(workload):
+    """`--workload c3 | vr | survey` under `--gpus N`: parsed, and (no devices here) refused loudly before any GPU work."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the bare invocation would really run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"--gpus 2 but only" in r.stderr and b"n_gpus" not in r.stdout
+    # a mismatching launcher environment is refused as well (the driver's torch.distributed.run form sets WORLD_SIZE)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload],
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"WORLD_SIZE=4" in r.stderr

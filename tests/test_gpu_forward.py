@@ -41,6 +41,13 @@ def _model(sd, in_channels=7, num_layers=4, heads=4, hidden=64, predict_correcti
     return m.to(torch.device("cuda:0")).eval()
 
 
+def _sure_grid(sd, og):
+    """Cells of an oracle graph's grid whose oracle class is decided (top-2 probability gap > TOL); cells without a node count
+    as decided (they are class 0 by construction)."""
+    top2 = np.sort(gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr)["class_probs"].numpy(), axis=1)
+    return graph_cpu.graph_to_grid(og, ((top2[:, -1] - top2[:, -2]) > TOL).astype(np.float32), 1.0).astype(bool)
+
+
 def _compare(out, ref, check_flags=True, require_mixed=None):
     """require_mixed: the oracle's classes / actions must not be constant (None: whenever the graph has >= 400 nodes --
     pass False where the model's heads were not calibrated on this graph)."""
@@ -141,16 +148,18 @@ def test_variants_heads_hidden_nocorr_legacy_keys(gpu_device):
 
 def test_batched_equals_per_graph_and_vr_processor(gpu_device):
     """NativeVRProcessor semantics (scripts/inference_native.py:249-342): batched flush == per-grid
-    processing == oracle; empty grids return zeros immediately."""
+    processing == oracle; empty grids return zeros immediately.  Heads calibrated on the first eight grids' block-diagonal
+    graph, so classes and actions mix over the compared grids."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor
-    sd = synthetic.synthetic_state_dict(in_channels=8, seed=1234)
+    grids = synthetic.vr_grid_stream(24, seed0=2000)
+    ogs = [graph_cpu.build_graph(d, (d != 1.0e6) & np.isfinite(d), u, r) for d, u, r in grids[:8]]
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=8, seed=1234), *graph_cpu.batch_graphs(ogs)[:3])
     model = _model(sd, in_channels=8)
     gb = GraphBuilder()
     proc = NativeVRProcessor(model, gb, torch.device("cuda:0"))
     assert proc.expected_in_channels == 8
-    grids = synthetic.vr_grid_stream(24, seed0=2000)
     dead = np.full((5, 6), 1.0e6, np.float32)
     assert proc.add_to_batch(dead, np.zeros_like(dead), (1.0, 1.0)) is not None
     for d, u, r in grids:
@@ -158,32 +167,39 @@ def test_batched_equals_per_graph_and_vr_processor(gpu_device):
     assert proc.batch_pending and not proc.batch_ready
     res = proc.flush_batch()
     assert len(res) == len(grids) and not proc.batch_pending
-    for (d, u, r), (cls, conf, corr) in zip(grids[:8], res[:8]):
+    seen_cls, seen_act = set(), set()
+    for (d, u, r), og, (cls, conf, corr) in zip(grids[:8], ogs, res[:8]):
         m = (d != 1.0e6) & np.isfinite(d)
-        og = graph_cpu.build_graph(d, m, u, r)
         ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
         single = proc.process_grid(d, u, r)
         assert cls.shape == d.shape and cls.dtype == np.float32
         assert np.abs(conf - ref["confidence"]).max() < TOL and np.abs(corr - ref["correction"]).max() < 2e-4
         assert np.abs(single[1] - conf).max() < 1e-6 and np.array_equal(single[0], cls)
-        top2 = np.sort(gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr)["class_probs"].numpy(), axis=1)
-        sure = graph_cpu.graph_to_grid(og, (top2[:, -1] - top2[:, -2]) > TOL, 0.0).astype(bool)
-        assert np.array_equal(cls[sure], ref["classification"][sure])
+        sure = _sure_grid(sd, og)
+        assert sure[m].mean() > 0.9
+        assert np.array_equal(cls[sure], ref["classification"][sure])          # exact away from ties
         assert np.all(cls[~m] == 0) and np.all(conf[~m] == 0) and np.all(corr[~m] == 0)
+        seen_cls |= set(np.unique(ref["classification"][m]).tolist())
+        c = ref["confidence"][m]; k = ref["classification"][m]
+        seen_act |= set(np.unique(np.where(c < 0.6, 2, np.where((k == 2) & (c > 0.85), 1, 0))).tolist())
+    assert len(seen_cls) >= 2 and seen_act == {0, 1, 2}, (seen_cls, seen_act)    # the comparison above was not vacuous
 
 
 def test_seven_channel_model_drops_uncertainty(gpu_device):
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor
-    sd = synthetic.synthetic_state_dict(in_channels=7, seed=3)
-    proc = NativeVRProcessor(_model(sd), GraphBuilder(), torch.device("cuda:0"))
-    d, u, r = synthetic.vr_grid_stream(1, seed0=5)[0]
-    cls, conf, corr = proc.process_grid(d, u, r)
+    d, u, r = synthetic.vr_grid_stream(1, seed0=6, lo=30)[0]
     m = (d != 1.0e6) & np.isfinite(d)
     og = graph_cpu.build_graph(d, m, None, r)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=7, seed=3), og.x, og.edge_index, og.edge_attr)
+    proc = NativeVRProcessor(_model(sd), GraphBuilder(), torch.device("cuda:0"))
+    cls, conf, corr = proc.process_grid(d, u, r)
     ref = gat_cpu.process_tile(sd, og)
-    assert np.abs(conf - ref["confidence"]).max() < TOL
+    assert np.abs(conf - ref["confidence"]).max() < TOL and np.abs(corr - ref["correction"]).max() < 2e-4
+    assert len(np.unique(ref["classification"][m])) >= 2, "calibrated heads: classes mix on this grid"
+    sure = _sure_grid(sd, og)
+    assert np.array_equal(cls[sure], ref["classification"][sure])
     # and a graph with the wrong number of feature columns fails like the reference's matmul would
     g8 = GraphBuilder().build_graph(d, m, u, r)
     with pytest.raises(RuntimeError):
@@ -197,12 +213,13 @@ def test_full_batch_properties(gpu_device):
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
-    sd = synthetic.synthetic_state_dict(seed=1234)
+    B, n = 8, 256
+    depth, mask, _ = synthetic.synthetic_tile_batch(B, n, n, 100, "V1")
+    og = graph_cpu.build_graph(depth[0][:96, :96], mask[0][:96, :96], None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
     model = _model(sd)
     gb = GraphBuilder()
     eng = TileBatchEngine(model, gb, torch.device("cuda:0"))
-    B, n = 8, 256
-    depth, mask, _ = synthetic.synthetic_tile_batch(B, n, n, 100, "V1")
     hw = np.tile(np.array([[n, n]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
     d_t = torch.from_numpy(depth).cuda().reshape(-1); m_t = torch.from_numpy(mask.view(np.uint8)).cuda().reshape(-1)
     nn = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -221,11 +238,16 @@ def test_full_batch_properties(gpu_device):
     assert (o["class_probs"].sum(-1) - 1).abs().max().item() < 1e-5
     cls_grid = out[0].reshape(-1)[torch.from_numpy(mask).cuda().reshape(-1)]
     assert torch.equal(cls_grid, o["predicted_class"].float())
+    assert torch.unique(o["predicted_class"]).numel() == 3 and set(torch.unique(o["action"]).tolist()) == {0, 1, 2}, \
+        "calibrated heads: the permutation / repeat checks above compared mixed class and action maps"
 
 
 def test_pipeline_process_grid_matches_oracle(gpu_device):
     """BathymetricPipeline.process (models/pipeline.py:134-241) minus file I/O: overlapping tiles, batched
-    fused inference, Hann-ramp stitch, unprocessed-cell preservation, _apply_corrections."""
+    fused inference, Hann-ramp stitch, unprocessed-cell preservation, _apply_corrections.  Heads calibrated on a crop of the
+    survey, so the stitched oracle map holds several classes and all three actions and the label arbitration between
+    overlapping tiles (higher confidence wins, data/tiling.py:408-420) has something to arbitrate; classes must then be
+    EQUAL wherever the oracle's own decision is not a tie."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.config import Config
     from bathymetric_gnn_amd.data import BathymetricGrid, TileManager, TileMerger
@@ -236,7 +258,9 @@ def test_pipeline_process_grid_matches_oracle(gpu_device):
     d[:50, :60] = 1.0e6
     d[5, 5] = -20.0          # a valid cell that only the (skipped) corner tile covers
     grid = BathymetricGrid(depth=d, nodata_value=1.0e6, resolution=(0.5, 0.5))
-    sd = synthetic.synthetic_state_dict(seed=1234)
+    crop = (slice(60, 140), slice(30, 120))
+    ogc = graph_cpu.build_graph(d[crop], grid.valid_mask[crop], None, grid.resolution)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), ogc.x, ogc.edge_index, ogc.edge_attr)
     pipe = BathymetricPipeline(cfg, tile_batch=5)
     with pytest.raises(RuntimeError):
         pipe.process_grid(grid)
@@ -247,28 +271,50 @@ def test_pipeline_process_grid_matches_oracle(gpu_device):
     for k in res_host:                             # the two stitchers agree bit for bit
         assert np.array_equal(np.isnan(res[k]), np.isnan(res_host[k])), k
         assert np.array_equal(np.nan_to_num(res[k]).view(np.uint32), np.nan_to_num(res_host[k]).view(np.uint32)), k
-    # oracle: same tile walk, CPU forward per tile, same merger
+    # oracle: same tile walk, CPU forward per tile, same merger; beside it, per cell, what makes the stitched label a tie
     tm = TileManager(64, 16, 0.3)
     _, _, specs = tm.compute_tile_grid(grid.shape)
     by_pos = {(s.tile_row, s.tile_col): s for s in specs}
     merger = TileMerger(tm)
     merger.initialize(grid.shape, ["cleaned_depth", "classification", "confidence", "correction"])
+    unsure = np.zeros(grid.shape, bool)                       # some covering tile's own class is a near-tie
+    c1 = np.full(grid.shape, -1.0, np.float32); c2 = c1.copy()   # highest / second highest confidence among the covering tiles
+    kmin = np.full(grid.shape, 9.0, np.float32); kmax = np.full(grid.shape, -1.0, np.float32)
     for t in tm.iterate_tiles(grid):
         og = graph_cpu.build_graph(t.data, t.valid_mask, None, grid.resolution)
         r = gat_cpu.process_tile(sd, og, 0.85, 0.6)
         r["cleaned_depth"] = t.data
-        merger.add_tile(by_pos[(t.tile_row, t.tile_col)], r)
+        sp = by_pos[(t.tile_row, t.tile_col)]
+        merger.add_tile(sp, r)
+        sl = (slice(sp.row_start, sp.row_end), slice(sp.col_start, sp.col_end))
+        unsure[sl] |= ~_sure_grid(sd, og)
+        cf = r["confidence"]
+        c2[sl] = np.maximum(c2[sl], np.minimum(c1[sl], cf)); c1[sl] = np.maximum(c1[sl], cf)
+        kmin[sl] = np.minimum(kmin[sl], r["classification"]); kmax[sl] = np.maximum(kmax[sl], r["classification"])
     ref = merger.finalize()
     vm = grid.valid_mask
     proc = ~np.isnan(ref["classification"])
     assert np.array_equal(np.isnan(res["confidence"]), np.isnan(ref["confidence"]) & ~vm)
     assert np.nanmax(np.abs(res["confidence"][proc] - ref["confidence"][proc])) < TOL
     assert np.nanmax(np.abs(res["correction"][proc] - ref["correction"][proc])) < 2e-4
-    agree = (res["classification"][proc] == ref["classification"][proc]).mean()
-    assert agree > 0.995                      # (ties between near-equal probabilities / confidences aside)
+    # the oracle's stitched map is not constant: classes mix, every action occurs, overlapping tiles disagree somewhere
+    pv = proc & vm
+    kk, cc = ref["classification"][pv], ref["confidence"][pv]
+    acts = np.where(cc < 0.6, 2, np.where((kk == 2) & (cc > 0.85), 1, 0))
+    assert len(np.unique(kk)) >= 2 and set(np.unique(acts).tolist()) == {0, 1, 2}
+    assert (pv & (kmin != kmax)).sum() > 20, "label arbitration between overlapping tiles is exercised"
+    decided = proc & ~unsure & ((kmin == kmax) | (c1 - c2 > 2 * TOL))
+    assert decided[pv].mean() > 0.9
+    assert np.array_equal(res["classification"][decided], ref["classification"][decided])     # exact away from ties
     unproc = vm & ~proc
     assert unproc.any() and np.all(res["classification"][unproc] == 0) and np.all(res["confidence"][unproc] == 0)
     assert np.array_equal(res["cleaned_depth"][unproc], d[unproc])
+    # _apply_corrections (models/pipeline.py:316-349) on the stitched maps: depth - correction where noise & conf > 0.85 & valid
+    fire = pv & (ref["classification"] == 2) & (ref["confidence"] > 0.85)
+    safe = decided & (np.abs(ref["confidence"] - 0.85) > TOL)
+    exp = np.where(fire, d - ref["correction"], d)
+    assert (fire & safe).sum() > 20
+    assert np.abs(res["cleaned_depth"][pv & safe] - exp[pv & safe]).max() < 2e-4
     assert res["valid_mask"].dtype == np.float32 and np.array_equal(res["valid_mask"] > 0, vm)
     with pytest.raises(ImportError):
         pipe.process("in.bag", "out.bag")

@@ -160,3 +160,63 @@ def test_full_tile_properties_256(gpu_device):
     assert int((deg == 8).sum()) == (n - 2) ** 2 and int((deg == 5).sum()) == 4 * (n - 2) and int((deg == 3).sum()) == 4
     g2 = gb.build_graph(d, m, None, (0.5, 0.5))
     assert torch.equal(g.x, g2.x) and torch.equal(g.edge_attr, g2.edge_attr) and torch.equal(ei, g2.edge_index)
+
+
+def test_many_live_graphs_of_distinct_shapes_keep_their_tables(gpu_device):
+    """the per-context cache of tile / work-item tables holds 8 shapes.  Graphs that are still alive pin
+    their entry: building a 9th, 10th, ... shape must neither free tables a live graph points into nor hand it another
+    shape's tables.  Ten graphs of distinct shapes are kept alive; the FIRST is then exported and run and must equal a
+    fresh build of the same tile bit for bit."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    gb = GraphBuilder(device=gpu_device)
+    shapes = [(40 + 3 * i, 64 - 2 * i) for i in range(12)]
+    tiles = [synthetic.synthetic_tile(h, w, 300 + i, "V1") for i, (h, w) in enumerate(shapes)]
+    live = [gb.build_graph(d, m, None, (0.5, 0.5)) for d, m, _ in tiles]            # 12 distinct shapes, all alive
+    sd = synthetic.synthetic_state_dict(seed=1234)
+    model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model = model.to(gpu_device).eval()
+    for i in (0, 1, 11):
+        d, m, _ = tiles[i]
+        og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+        g = live[i]
+        assert torch.equal(g.edge_index.cpu(), torch.from_numpy(og.edge_index))
+        assert np.array_equal(g.x.cpu().numpy()[:, [0, 3, 4, 5, 6]], og.x[:, [0, 3, 4, 5, 6]])
+        out_live = model.predict(g)["class_logits"].clone()
+        fresh = gb.build_graph(d, m, None, (0.5, 0.5))
+        assert torch.equal(out_live, model.predict(fresh)["class_logits"])
+        del fresh
+    # dropping the graphs unpins the entries: the same shapes can be built (and evicted) again
+    del live, g
+    again = [gb.build_graph(d, m, None, (0.5, 0.5)) for d, m, _ in tiles]
+    og = graph_cpu.build_graph(tiles[5][0], tiles[5][1], None, (0.5, 0.5))
+    assert torch.equal(again[5].edge_index.cpu(), torch.from_numpy(og.edge_index))
+
+
+def test_graphs_of_a_closed_context_are_inert(gpu_device):
+    """Context.close() destroys the library context while GraphData objects built on it are alive.  The
+    library releases those graphs with the context; the Python objects refuse to run afterwards and their finaliser
+    does not touch the dead handle."""
+    import gc
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    gb = GraphBuilder(device=gpu_device)
+    ctx = rt.new_context(gpu_device)
+    d, m, _ = synthetic.synthetic_tile(48, 40, 3, "V1")
+    hw, res, dt, mt, ut = gb.upload_tiles([d], [m], None, [(0.5, 0.5)])
+    graphs = [gb.build_from_device(hw, res, dt, mt, ut, ctx=ctx) for _ in range(3)]
+    n = graphs[0].num_nodes
+    assert n == int(m.sum()) and graphs[0].x.shape == (n, 7)
+    free0 = torch.cuda.mem_get_info(gpu_device)[0]
+    ctx.close()
+    assert ctx.handle is None
+    assert torch.cuda.mem_get_info(gpu_device)[0] >= free0          # the graphs' arenas went back with the context
+    assert graphs[0].x.shape == (n, 7)                              # tensors already exported stay valid (torch owns them)
+    with pytest.raises(rt.BgnnError):
+        graphs[1].edge_index                                        # a new export would need the dead handle
+    del graphs
+    gc.collect()                                                    # finalisers run: must not call into the freed context
+    g2 = gb.build_graph(d, m, None, (0.5, 0.5))                     # the default context is unaffected
+    assert g2.num_nodes == n

@@ -80,3 +80,39 @@ def test_two_rank_stitch_equals_single_process():
     vm = grid.valid_mask
     assert not np.isnan(single["classification"][vm]).any()
     assert set(np.unique(single["classification"][vm])) <= {0.0, 1.0, 2.0}
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bathymetric_gnn_amd.models.pipeline import exchange_tile_results
+    mine = {}
+    if rank == 0:          # rank 1 holds NO tile (world larger than the number of kept tiles)
+        mine = {5: {"cleaned_depth": np.full((4, 6), 4.0, np.float32), "classification": np.full((4, 6), 1.0, np.float32),
+                    "confidence": np.full((4, 6), 0.25, np.float32), "correction": np.full((4, 6), -0.5, np.float32)}}
+    got = exchange_tile_results(mine)
+    q.put((rank, {i: {k: v.copy() for k, v in r.items()} for i, r in got.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_channel_order_on_a_rank_without_tiles():
+    """a rank that holds no tile used to unpack the all-gathered block in another channel order than the
+    ranks that packed it (classification and cleaned_depth came back swapped)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    want = {"cleaned_depth": 4.0, "classification": 1.0, "confidence": 0.25, "correction": -0.5}
+    for rank in (0, 1):
+        assert list(got[rank].keys()) == [5]
+        for k, v in want.items():
+            assert np.all(got[rank][5][k] == v), (rank, k, got[rank][5][k][0, 0])

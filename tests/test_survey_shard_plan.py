@@ -134,3 +134,37 @@ def test_band_gather_to_rank0_gloo_four_ranks():
     exp = (np.arange(1000, dtype=np.float32)[None, :, None] * 1000 + np.arange(37, dtype=np.float32)[None, None, :]
            + 0.25 * np.arange(4, dtype=np.float32)[:, None, None])
     assert np.array_equal(host, exp)
+
+
+def _gather_worker_rank0_empty(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bathymetric_gnn_amd.models.pipeline import gather_bands_to_rank0, survey_shard_plan
+    rs, re = _rows(400, 512, 128)                           # ONE tile row, three ranks: rank 0 owns no rows
+    plan = survey_shard_plan(rs, re, 400, world)
+    R0, R1 = plan[rank]["cell_rows"]
+    band = torch.full((4, R1 - R0, 9), float(rank), dtype=torch.float32) if R1 > R0 else None
+    host = gather_bands_to_rank0(plan, rank, band, 9, device="cpu")
+    q.put((rank, None if host is None else host.copy(), [list(p["cell_rows"]) for p in plan]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_gather_when_rank0_owns_no_rows():
+    """with more ranks than tile rows rank 0 can be the rank without a band; it still has to receive the others'
+    (the receive device comes from the caller, not from rank 0's own band)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker_rank0_empty, args=(r, 3, port, q)) for r in range(3)]
+    for pr in procs:
+        pr.start()
+    res = {r: (h, bands) for r, h, bands in (q.get(timeout=180) for _ in range(3))}
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    host, bands = res[0]
+    assert bands[0][0] == bands[0][1], "the case under test: rank 0 without rows"
+    owner = [r for r in range(3) if bands[r][1] > bands[r][0]]
+    assert len(owner) == 1 and host.shape == (4, 400, 9) and np.all(host == float(owner[0]))
