@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 #include "gat_tile_common.h"
 
 namespace bgnn {
@@ -122,6 +123,52 @@ __device__ __forceinline__ float lds_read1(uint32_t addr) {
 __device__ __forceinline__ void lds_reads_done() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write1(uint32_t addr, float v) {     // (an LDS write hipcc does not see either: same reason)
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int K, int... B>
+__device__ __forceinline__ void lds_write_coefficients(uint32_t addr, const float (&part)[K + 1], std::integer_sequence<int, B...>) {
+  (lds_write1<B * 4>(addr, part[B]), ...);
+}
+template <int OFF>
+__device__ __forceinline__ int lds_read1i(uint32_t addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+// Phase A's operands out of the halo tables (node ids `hid [HR]`, alpha_src `has [HR][H]`) by asm reads: phase A runs while slab
+// 0's LDS-DMA is still in flight, and a compiler-visible LDS read there would be given an s_waitcnt vmcnt(0) (see above), i.e.
+// the whole phase would queue up behind the DMA instead of passing under it.  Every read's offset is an immediate relative to the
+// stencil's lowest halo row (pack expansion over the slots), 2 K + 1 reads in flight, one wait.
+template <int K, int HWID>
+struct HaloSlot {
+  using Off = StencilOffsets<K>;
+  static constexpr int R = K == 16 ? 2 : 1;
+  static constexpr int MAXOFF = R * HWID + R;                        // self_idx - MAXOFF = the lowest row a slot can address
+  static constexpr int rel(int b) { return MAXOFF - (Off::dr[b] * HWID + Off::dc[b]); }   // >= 0: slot b's source row, relative to it
+};
+template <int H, int K, int HWID, int... B>
+__device__ __forceinline__ void halo_operands(uint32_t hid_lo, uint32_t has_lo, int (&nb)[K], float (&hs)[K + 1],
+                                              std::integer_sequence<int, B...>) {
+  using S = HaloSlot<K, HWID>;
+  ((nb[B] = lds_read1i<S::rel(B) * 4>(hid_lo)), ...);
+  ((hs[B] = lds_read1<S::rel(B) * H * 4>(has_lo)), ...);
+  hs[K] = lds_read1<S::MAXOFF * H * 4>(has_lo);
+  lds_reads_done();
+}
+// attention_coefficients_head_pre (gat_tile_common.h) with the halo operands fetched as above: same arithmetic, same results
+template <int H, int K, int HWID>
+__device__ __forceinline__ void attention_coefficients_head_asm(int self_idx, int hh, uint32_t hid0, uint32_t has0,
+                                                                const float (&eraw)[K * 3], float ad, const float (&v)[3], float *out) {
+  using S = HaloSlot<K, HWID>;
+  int nb[K];
+  float hs[K + 1];
+  halo_operands<H, K, HWID>(hid0 + (uint32_t)(self_idx - S::MAXOFF) * 4u, has0 + (uint32_t)((self_idx - S::MAXOFF) * H + hh) * 4u, nb, hs,
+                            std::make_integer_sequence<int, K>{});
+  attention_coefficients_head_vals<K>(nb, hs, eraw, ad, v, out);
 }
 
 // MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
@@ -476,33 +523,24 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   constexpr int NHL = (H + 1) / 2;                      // heads per lane
   constexpr int NPIECE = (HR * CPR + NTH - 1) / NTH;
   static_assert((NPIECE - 2) * NTH + NTH - 64 < HR * CPR, "every wave moves NPIECE or NPIECE - 1 pieces");
-  int my_pre = -1, hid_v = -1;
-  {
-    const int gr = pos.r0 + tid / HW_ - RAD, gc = pos.c0 + tid % HW_ - RAD;
-    if (tid < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) hid_v = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
-  }
-  if (!DBG(32)) {
-    const int gr = pos.r0 + tr, gc = pos.c0 + tc;
-    if (gr < pos.h && gc < pos.w) my_pre = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
-  }
-  if (a.cell_map) {                  // canvas walk (wave-uniform test): blocks that hold only gutter / free space leave here
-    // (not __syncthreads_or: its library reduction brings 256 bytes of static LDS in front of the dynamic region)
-    const bool wave_any = __builtin_amdgcn_ballot_w64(my_pre >= 0) != 0;
-    if (lane == 0) minid[wave] = wave_any ? 1 : 0;
-    __syncthreads();
-    if ((minid[0] | minid[1] | minid[2] | minid[3]) == 0) {
-      __builtin_amdgcn_s_waitcnt(0);   // the W DMAs land in this WG's LDS: drain them before the LDS can be handed on
-      return;
-    }
-  }
+  // Round 1 is ONE round: every load is unconditional (coordinates clamped into the tile, validity applied to the value
+  // afterwards), so nothing is exec-masked, no branch separates the loads and the compiler keeps all of them in flight behind
+  // a single wait.  (With `if (inside) id = node_id[..]` per load, hipcc waited for the halo row's id, then for the own cell's,
+  // then for the DMA rows': three dependent trips to L2 before round 2 could start.)
+  auto cell_index = [&](int gr, int gc) -> int64_t {
+    gr = gr < 0 ? 0 : gr >= pos.h ? pos.h - 1 : gr;
+    gc = gc < 0 ? 0 : gc >= pos.w ? pos.w - 1 : gc;
+    return pos.cell_off + (int64_t)gr * pos.w + gc;
+  };
+  const int gr_h = pos.r0 + tid / HW_ - RAD, gc_h = pos.c0 + tid % HW_ - RAD;
+  const int gr_m = pos.r0 + tr, gc_m = pos.c0 + tc;
+  const int raw_h = a.node_id[cell_index(gr_h, gc_h)];
+  const int raw_m = a.node_id[cell_index(gr_m, gc_m)];
   int drow[NPIECE];
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) {
     const int row = (p * NTH + tid) / CPR;
-    const int gr = pos.r0 + row / HW_ - RAD, gc = pos.c0 + row % HW_ - RAD;
-    drow[p] = -1;
-    // (measured with ids COMPUTED instead of loaded, all-valid tiles: 0.3 % (exact) / 2 % (bf16) -- the id round is already hidden)
-    if (row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w) drow[p] = a.node_id[pos.cell_off + (int64_t)gr * pos.w + gc];
+    drow[p] = a.node_id[cell_index(pos.r0 + row / HW_ - RAD, pos.c0 + row % HW_ - RAD)];
   }
   constexpr int NSC = (HC + NTH - 1) / NTH;
   float scv[NSC], shv[NSC];                             // folded scale / shift: to LDS once phase A has released R
@@ -517,6 +555,67 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     const int hh = hl + i * 2;
 #pragma unroll
     for (int f = 0; f < 3; ++f) vpre[i][f] = hh < H ? a.V[hh * 3 + f] : 0.0f;
+  }
+  // heads: the small second-stage weights go the same way (registers now, LDS at slab 0).  Read straight from global memory in the
+  // final epilogue they were 28 dependent float4 loads per lane behind runtime class tests: 41 % of that instance's lifetime.
+  float hwv[2] = {0.0f, 0.0f};
+  if constexpr (EPI == EPI_HEADS) {
+    const int nrow = a.classes + 1 + (a.has_corr ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * NTH;
+      if (idx < 96) hwv[i] = a.hd_b0[idx];
+      else if (idx < 96 + nrow * 32) hwv[i] = a.hd_W1[idx - 96];
+      else if (idx >= 288 && idx < 288 + nrow) hwv[i] = a.hd_b1[idx - 288];
+    }
+  }
+  // validity (ids < 0 in the table encode invalid cells)
+  int hid_v = (tid < HR && gr_h >= 0 && gr_h < pos.h && gc_h >= 0 && gc_h < pos.w && raw_h >= 0) ? raw_h : -1;
+  int my_pre = (!DBG(32) && gr_m < pos.h && gc_m < pos.w) ? raw_m : -1;
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) {
+    // (measured with ids COMPUTED instead of loaded, all-valid tiles: 0.3 % (exact) / 2 % (bf16) -- the id round is already hidden)
+    const int row = (p * NTH + tid) / CPR;
+    const int gr = pos.r0 + row / HW_ - RAD, gc = pos.c0 + row % HW_ - RAD;
+    if (!(row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w)) drow[p] = -1;
+  }
+  if (a.cell_map) {                  // canvas walk (wave-uniform test): blocks that hold only gutter / free space leave here
+    // (not __syncthreads_or: its library reduction brings 256 bytes of static LDS in front of the dynamic region)
+    const bool wave_any = __builtin_amdgcn_ballot_w64(my_pre >= 0) != 0;
+    if (lane == 0) minid[wave] = wave_any ? 1 : 0;
+    __syncthreads();
+    if ((minid[0] | minid[1] | minid[2] | minid[3]) == 0) {
+      __builtin_amdgcn_s_waitcnt(0);   // the W DMAs land in this WG's LDS: drain them before the LDS can be handed on
+      return;
+    }
+  }
+  // Round 2, complete BEFORE slab 0's DMA is queued (hipcc only ever waits vmcnt(0) with an LDS-DMA in flight): alpha_src of
+  // this thread's halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...).  Unconditional as well:
+  // rows without a node read row 0 and are masked afterwards.
+  float eraw[K * 3], adv[NHL], hasv[H];
+  {
+    const int64_t hrow = hid_v >= 0 ? hid_v : 0, mrow = my_pre >= 0 ? my_pre : 0;
+    if constexpr (H % 4 == 0) {
+#pragma unroll
+      for (int q = 0; q < H / 4; ++q) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(a.asd + hrow * 2 * H + 4 * q);
+        hasv[4 * q] = v4.x; hasv[4 * q + 1] = v4.y; hasv[4 * q + 2] = v4.z; hasv[4 * q + 3] = v4.w;
+      }
+    } else {
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) hasv[hh] = a.asd[hrow * 2 * H + hh];
+    }
+    const float4 *ep = reinterpret_cast<const float4 *>(a.eattr + mrow * K * 3);
+#pragma unroll
+    for (int i = 0; i < K * 3 / 4; ++i) {
+      const float4 q = ep[i];
+      eraw[4 * i] = q.x; eraw[4 * i + 1] = q.y; eraw[4 * i + 2] = q.z; eraw[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) {
+      const int hh = hl + i * 2;
+      adv[i] = hh < H ? a.asd[mrow * 2 * H + H + hh] : 0.0f;
+    }
   }
   // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 64 / CPR rows x ROWB bytes;
   // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk p ^ swz(row), with
@@ -559,46 +658,29 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       }
     }
   };
-  issue_slab(0);
-  BGNN_STAMP(0)   // round 1, slab 0 issued
-
-  // heads: the small second-stage weights go the same way (registers now -- with the second load round, behind the id round -- LDS at slab 0).  Read straight from global memory in the
-  // final epilogue they were 28 dependent float4 loads per lane behind runtime class tests: 41 % of that instance's lifetime.
-  float hwv[2] = {0.0f, 0.0f};
-  if constexpr (EPI == EPI_HEADS) {
-    const int nrow = a.classes + 1 + (a.has_corr ? 1 : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + i * NTH;
-      if (idx < 96) hwv[i] = a.hd_b0[idx];
-      else if (idx < 96 + nrow * 32) hwv[i] = a.hd_W1[idx - 96];
-      else if (idx >= 288 && idx < 288 + nrow) hwv[i] = a.hd_b1[idx - 288];
-    }
-  }
-
-  if (hid_v < 0) hid_v = -1;
-  float eraw[K * 3], adv[NHL], hasv[H];
-#pragma unroll
-  for (int hh = 0; hh < H; ++hh) hasv[hh] = hid_v >= 0 ? a.asd[(int64_t)hid_v * 2 * H + hh] : 0.0f;
-  if (my_pre >= 0) {
-    const float4 *ep = reinterpret_cast<const float4 *>(a.eattr + (int64_t)my_pre * K * 3);
-#pragma unroll
-    for (int i = 0; i < K * 3 / 4; ++i) {
-      const float4 q = ep[i];
-      eraw[4 * i] = q.x; eraw[4 * i + 1] = q.y; eraw[4 * i + 2] = q.z; eraw[4 * i + 3] = q.w;
-    }
-#pragma unroll
-    for (int i = 0; i < NHL; ++i) {
-      const int hh = hl + i * 2;
-      adv[i] = hh < H ? a.asd[(int64_t)my_pre * 2 * H + H + hh] : 0.0f;
-    }
-  }
+  // Round 2's values go to the halo tables first -- hipcc waits vmcnt(0) for them, which must not include slab 0's DMA -- and
+  // only then is slab 0 requested: it is in flight during the whole of phase A, whose LDS reads are asm (no compiler wait).
   if (tid < HR) {
     hid[tid] = hid_v;
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hasv[hh];
+    for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hid_v >= 0 ? hasv[hh] : 0.0f;
   }
-  __syncthreads();
+  {   // (phase A's register operands are complete as well before the DMA is queued: no wait behind it later)
+    // (the table writes above sit under `tid < HR`: a wave that skips them has not waited yet -- touch every round-2 register)
+    float sink = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) sink += adv[i];
+#pragma unroll
+    for (int i = 0; i < K * 3; ++i) sink += eraw[i];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) sink += hasv[hh];
+    asm volatile("" ::"v"(sink));
+  }
+  issue_slab(0);
+  BGNN_STAMP(0)   // rounds 1 and 2 done, slab 0 issued
+  // (raw barrier, not __syncthreads(): its fence would wait vmcnt(0), i.e. for slab 0's DMA, which phase A is meant to pass under)
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
   BGNN_STAMP(1)   // round 2, halo tables in LDS
 
   // ---- phase A: attention coefficients -> LDS.  The two lanes that share a cell take the heads round-robin.
@@ -608,7 +690,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
     for (int b = 0; b < (K + 2) / 2; ++b) apk[i][b] = 0u;
   {
-    const int my = DBG(32) ? -1 : hid[self_idx];
+    const uint32_t hid0 = lds_addr(hid), has0 = lds_addr(has);
+    int my = lds_read1i<0>(hid0 + (uint32_t)self_idx * 4u);
+    lds_reads_done();
+    if (DBG(32)) my = -1;
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
       const int hh = hl + i * 2;
@@ -616,13 +701,13 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         float part[K + 1];
 #pragma unroll
         for (int b = 0; b <= K; ++b) part[b] = 0.0f;
-        if (my >= 0) attention_coefficients_head_pre<H, K, HW_>(self_idx, hh, hid, has, eraw, adv[i], vpre[i], part);
+        if (my >= 0) attention_coefficients_head_asm<H, K, HW_>(self_idx, hh, hid0, has0, eraw, adv[i], vpre[i], part);
         if constexpr (SP == 3) {      // kept in registers as bf16 pairs until this head's slabs come up (densified there)
 #pragma unroll
           for (int b = 0; b <= K; b += 2) apk[i][b / 2] = pack_bf16x2(part[b], b + 1 <= K ? part[b + 1] : 0.0f);
         } else {
-#pragma unroll
-          for (int b = 0; b <= K; ++b) alx[cell * APITCH + hh * (K + 1) + b] = part[b];
+          // (asm writes: with slab 0's DMA in flight hipcc would wait vmcnt(0) in front of a visible ds_write too)
+          lds_write_coefficients<K>(lds_addr(alx + cell * APITCH + hh * (K + 1)), part, std::make_integer_sequence<int, K + 1>{});
         }
       }
     }
