@@ -80,6 +80,7 @@ struct BgnnOpts {
   int fused_persistent = 0;  // 1 (opt-in experiment): big uniform batches run the 256 -> 256 exact-f32 fused layer in its persistent
                              // one-workgroup-per-CU form (bit-identical; measured 11.4 ms per launch against 10.15: DESIGN.md)
   int fused_front = 1;       // 1: extractor layer 1 runs inside the lin_0 GEMM where that GEMM's W-resident form is used (0: own launch)
+  int features_tiled = 1;    // 1: LDS-tiled feature kernel with mirrored-edge slope reuse (K = 8 / 16); 0: thread-per-cell form (bit-identical)
   int ragged_atlas = 1;      // ragged batches: fused layers walk a shelf-packed canvas of the grids (0: per-grid 8x16 blocks)
   int fused_lds_pad_kb = 0;    // experiment: pad the fused kernel's LDS request (occupancy)
   int diag_mask = 0;         // BGNN_DIAG builds only: phase ablation bits of the fused kernel

@@ -394,11 +394,23 @@ struct AggWindow {
   static constexpr int ROWS = (2 + 2 * G::R) * G::HW;     // 120 / 72
   static constexpr int NKB = (ROWS + 15) / 16;            // 8 / 5 MFMAs per slab
   static constexpr int PAD = NKB * 16;                    // 128 / 80
+  // Dense alpha matrix of a wave: [32 cells][PITCH bytes] of bf16, window row wp of cell r at r * PITCH + 2 wp.  PITCH is an ODD
+  // multiple of 16 bytes >= 2 ROWS: 16 consecutive cell rows then start in 16 different 16-byte bank groups, so the B-operand reads
+  // (16 lanes x ds_read_b128 = one row chunk each) are conflict-free without an XOR swizzle, and the matrix is 240 / 176 bytes
+  // wide instead of 256 (k = 16: 30 KB per workgroup instead of 32 -- what lets the narrow instances fit three per CU).
+  // k = 16: the last MFMA's upper k-half (window rows 120..127 = bytes 240..255) lies beyond the pitch: those lanes feed zeros.
+  static constexpr int PITCH = K == 16 ? 240 : 176;
+  static constexpr bool TAIL_BEYOND_PITCH = PAD * 2 > PITCH;
+  static constexpr int LAST = TAIL_BEYOND_PITCH ? ROWS : PAD;   // rows the last wave's window may use
+  static_assert(PITCH % 32 == 16 && PITCH >= 2 * ROWS && (PAD - 8) * 2 <= PITCH, "odd multiple of 16 B that holds every window row");
   __device__ static __forceinline__ int base(int wave) {  // first halo row of the wave's window (the last wave's is pulled inside)
+    // k <= 8: pulled back so that all PAD rows the MFMAs read are slab rows.  k = 16: the matrix is only ROWS wide (PITCH), so
+    // the window starts at most at HR - ROWS; the last MFMA's A operand then reads 8 rows past the slab image -- the head of the W
+    // buffer, always finite bf16 weights -- against B rows that are zero by construction (TAIL_BEYOND_PITCH).
     const int b = wave * 2 * G::HW;
-    return b < G::HR - PAD ? b : G::HR - PAD;
+    return b < G::HR - LAST ? b : G::HR - LAST;
   }
-  static_assert((2 * G::HW) % 4 == 0 && (G::HR - PAD) % 4 == 0, "windows start on a 4-row boundary (uniform swizzle per read)");
+  static_assert((2 * G::HW) % 4 == 0 && (G::HR - LAST) % 4 == 0, "windows start on a 4-row boundary (uniform swizzle per read)");
 };
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int OFF>
@@ -412,27 +424,31 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   const bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
-// one batch of NB window blocks: reads first (A: two transposed reads, B: one row read per block), then the MFMAs
-template <int KB0, int NB, bool ZERO>
-__device__ __forceinline__ void agg_blocks(f32x16 &d, uint32_t tr0, uint32_t tr1, uint32_t bq) {
+// one batch of NB window blocks: reads first (A: two transposed reads, B: one row read per block), then the MFMAs.
+// TAILZ: block 7's upper k-half lies beyond the dense matrix's pitch (AggWindow): lanes with hl = 1 feed zeros there.
+template <int KB0, int NB, bool ZERO, bool TAILZ>
+__device__ __forceinline__ void agg_blocks(f32x16 &d, uint32_t tr0, uint32_t tr1, uint32_t bq, int hl) {
   u32x2 a0[NB], a1[NB];
   u32x4 b[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     // (the immediate must be a literal: spell the blocks out)
-    if (KB0 + i == 0) { a0[i] = lds_read_tr<0>(tr0); a1[i] = lds_read_tr<0>(tr1); }
-    if (KB0 + i == 1) { a0[i] = lds_read_tr<1024>(tr0); a1[i] = lds_read_tr<1024>(tr1); }
-    if (KB0 + i == 2) { a0[i] = lds_read_tr<2048>(tr0); a1[i] = lds_read_tr<2048>(tr1); }
-    if (KB0 + i == 3) { a0[i] = lds_read_tr<3072>(tr0); a1[i] = lds_read_tr<3072>(tr1); }
-    if (KB0 + i == 4) { a0[i] = lds_read_tr<4096>(tr0); a1[i] = lds_read_tr<4096>(tr1); }
-    if (KB0 + i == 5) { a0[i] = lds_read_tr<5120>(tr0); a1[i] = lds_read_tr<5120>(tr1); }
-    if (KB0 + i == 6) { a0[i] = lds_read_tr<6144>(tr0); a1[i] = lds_read_tr<6144>(tr1); }
-    if (KB0 + i == 7) { a0[i] = lds_read_tr<7168>(tr0); a1[i] = lds_read_tr<7168>(tr1); }
-    b[i] = lds_read4u<0>(bq ^ ((uint32_t)(KB0 + i) << 5));
+    if (KB0 + i == 0) { a0[i] = lds_read_tr<0>(tr0); a1[i] = lds_read_tr<0>(tr1); b[i] = lds_read4u<0>(bq); }
+    if (KB0 + i == 1) { a0[i] = lds_read_tr<1024>(tr0); a1[i] = lds_read_tr<1024>(tr1); b[i] = lds_read4u<32>(bq); }
+    if (KB0 + i == 2) { a0[i] = lds_read_tr<2048>(tr0); a1[i] = lds_read_tr<2048>(tr1); b[i] = lds_read4u<64>(bq); }
+    if (KB0 + i == 3) { a0[i] = lds_read_tr<3072>(tr0); a1[i] = lds_read_tr<3072>(tr1); b[i] = lds_read4u<96>(bq); }
+    if (KB0 + i == 4) { a0[i] = lds_read_tr<4096>(tr0); a1[i] = lds_read_tr<4096>(tr1); b[i] = lds_read4u<128>(bq); }
+    if (KB0 + i == 5) { a0[i] = lds_read_tr<5120>(tr0); a1[i] = lds_read_tr<5120>(tr1); b[i] = lds_read4u<160>(bq); }
+    if (KB0 + i == 6) { a0[i] = lds_read_tr<6144>(tr0); a1[i] = lds_read_tr<6144>(tr1); b[i] = lds_read4u<192>(bq); }
+    if (KB0 + i == 7) { a0[i] = lds_read_tr<7168>(tr0); a1[i] = lds_read_tr<7168>(tr1); b[i] = lds_read4u<224>(bq); }
   }
   lds_reads_done();
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
+    if (TAILZ && KB0 + i == 7) {
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      if (hl) b[i] = z4;
+    }
     const u32x4 av = {a0[i].x, a0[i].y, a1[i].x, a1[i].y};
     const bf16x8 A = __builtin_bit_cast(bf16x8, av), B = __builtin_bit_cast(bf16x8, b[i]);
     if (ZERO && i == 0) {
@@ -453,14 +469,21 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   // the epilogue's four wave-private 32 x 36 store patches reuse slab (+ wbuf)
   static constexpr int PATCH_PAD = EPI == EPI_NEXT && SLAB + WBUF < 4 * 32 * TILED_PITCH ? 4 * 32 * TILED_PITCH - SLAB - WBUF : 0;
   static constexpr int HEADW = 96 + 6 * 32 + 8;          // heads: first-layer biases | second-layer rows (<= 4 classes + 2) | their biases
-  static constexpr int RA = HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : HEADW);
+  // bf16 storage path, two space savers (so that its narrow instances fit three workgroups per CU):
+  //  * the halo's alpha_src table (phase A only) lives in the dense-alpha region, which is first written after phase A;
+  //  * the heads' small weight table (final epilogue only) is parked in the slab region once the last slab has been gathered.
+  static constexpr bool HAS_IN_ALPHA = SP == 3, HEADW_LATE = SP == 3 && EPI == EPI_HEADS;
+  static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : HEADW_LATE ? 0 : HEADW);
   static constexpr int RSZ = RA > RB ? RA : RB;
   static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
   // attention coefficients: [128 cells][APITCH] f32 (sparse, every head); bf16 storage path: the CURRENT head's coefficients as
-  // four wave-private dense [32 cells][128 window rows] bf16 matrices (the aggregation's MFMA B operand) -- see AggWindow
-  static constexpr int ALPHA = SP == 3 ? 4 * 32 * 128 / 2 : 128 * APITCH;
+  // four wave-private dense [32 cells][window rows] bf16 matrices (the aggregation's MFMA B operand) -- see AggWindow
+  static constexpr int ALPHA = SP == 3 ? 4 * 32 * AggWindow<K>::PITCH / 4 : 128 * APITCH;
+  static_assert(!HAS_IN_ALPHA || HR * H <= ALPHA, "the alpha_src table fits the dense-alpha region");
+  static_assert(!HEADW_LATE || HEADW <= SLAB, "the heads' weight table fits the slab region");
+  static_assert(SP != 3 || !AggWindow<K>::TAIL_BEYOND_PITCH || WBUF * 4 >= 8 * 64, "the 8 rows read past the slab image stay inside the W buffer");
   static constexpr int PRE = SLAB + WBUF + PATCH_PAD + RSZ + HR + 4;
-  static constexpr int ALIGN = SP == 3 ? (64 - PRE % 64) % 64 : 0;       // the dense matrices start on a 256-byte boundary
+  static constexpr int ALIGN = (4 - PRE % 4) % 4;        // the dense matrices start on a 16-byte boundary
   static constexpr int FLOATS = PRE + ALIGN + ALPHA;
   static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
 };
@@ -486,15 +509,16 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // Region R is time-shared: alpha_src of the halo rows during phase A, then (from the first slab barrier on)
   // the folded scale / shift table and, behind it, the next layer's att_src | att_dst for the epilogue.
   constexpr int RSZ = Lds::RSZ, APITCH = Lds::APITCH;
-  float *has = wbuf + Lds::WBUF + Lds::PATCH_PAD;      // [HR][H]   (phase A)
-  float *scsh = has;                                   // [2][HC]   folded scale / shift (slab loop)
-  float *attr = has + 2 * HC;                          // [2][NC]   att_src | att_dst (epilogue, EPI_NEXT)
-  int *hid = reinterpret_cast<int *>(has + RSZ);       // [HR]
+  float *rreg = wbuf + Lds::WBUF + Lds::PATCH_PAD;
+  float *scsh = rreg;                                  // [2][HC]   folded scale / shift (slab loop)
+  float *attr = Lds::HEADW_LATE ? slab : rreg + 2 * HC;   // [2][NC] att_src | att_dst (epilogue, EPI_NEXT) / heads' weight table
+  int *hid = reinterpret_cast<int *>(rreg + RSZ);      // [HR]
   int *minid = hid + HR;                               // [4]
   float *alx = reinterpret_cast<float *>(minid + 4) + Lds::ALIGN;   // [128][APITCH]  alpha[cell][head][K+1]; bf16 path: dense (AggWindow)
+  float *has = Lds::HAS_IN_ALPHA ? alx : rreg;         // [HR][H]   (phase A; bf16 path: inside the not yet written dense-alpha region)
 
 #if BGNN_DIAG
-  unsigned long long t_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_clk0 = t_prev, t_real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // in-kernel clock probe
 #endif
@@ -569,6 +593,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       else if (idx >= 288 && idx < 288 + nrow) hwv[i] = a.hd_b1[idx - 288];
     }
   }
+  BGNN_STAMP(9)    // block decode, address arithmetic, round 1 requested
   // validity (ids < 0 in the table encode invalid cells)
   int hid_v = (tid < HR && gr_h >= 0 && gr_h < pos.h && gc_h >= 0 && gc_h < pos.w && raw_h >= 0) ? raw_h : -1;
   int my_pre = (!DBG(32) && gr_m < pos.h && gc_m < pos.w) ? raw_m : -1;
@@ -579,6 +604,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     const int gr = pos.r0 + row / HW_ - RAD, gc = pos.c0 + row % HW_ - RAD;
     if (!(row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w)) drow[p] = -1;
   }
+#if BGNN_DIAG
+  if (a.stamps) asm volatile("" ::"v"(hid_v), "v"(my_pre), "v"(drow[0]));
+#endif
+  BGNN_STAMP(10)   // round 1 arrived
   if (a.cell_map) {                  // canvas walk (wave-uniform test): blocks that hold only gutter / free space leave here
     // (not __syncthreads_or: its library reduction brings 256 bytes of static LDS in front of the dynamic region)
     const bool wave_any = __builtin_amdgcn_ballot_w64(my_pre >= 0) != 0;
@@ -676,8 +705,9 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     for (int hh = 0; hh < H; ++hh) sink += hasv[hh];
     asm volatile("" ::"v"(sink));
   }
+  BGNN_STAMP(11)   // round 2 arrived, halo tables written
   issue_slab(0);
-  BGNN_STAMP(0)   // rounds 1 and 2 done, slab 0 issued
+  BGNN_STAMP(0)   // slab 0 issued
   // (raw barrier, not __syncthreads(): its fence would wait vmcnt(0), i.e. for slab 0's DMA, which phase A is meant to pass under)
   wait_lgkm0();
   __builtin_amdgcn_s_barrier();
@@ -737,8 +767,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // bf16 storage: addresses of the aggregation's operands (AggWindow)
   using Win = AggWindow<K>;
   const int wbase = Win::base(wave);
-  const uint32_t dn0 = lds_addr(alx) + wave * (32 * 256);                       // this wave's dense alpha [32][128] bf16
-  const uint32_t bq0 = dn0 + r * 256 + (((r & 15) >> 1) << 5) + ((hl ^ (r & 1)) << 4);   // chunk (2 kb + hl) ^ (r & 15): ^ (kb << 5)
+  const uint32_t dn0 = lds_addr(alx) + wave * (32 * Win::PITCH);                // this wave's dense alpha [32 cells][PITCH bytes] bf16
+  const uint32_t bq0 = dn0 + r * Win::PITCH + hl * 16;                         // window rows 16 kb + 8 hl ..: + 32 kb (immediate)
   uint32_t tr0 = 0, tr1 = 0;
   if constexpr (SP == 3) {
     // transposed read: lane 4q + p of a 16-lane group addresses row q, channels 4p..4p+3 of the group's 16 channels
@@ -764,29 +794,32 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       // alone a narrow next stage (NQ = 2 or 3) waited for EVERYTHING at each of these points, the next slab included.
       constexpr int WREM = WHalf<NT, SP>::NQ % 4;
       const bool wextra = wave < WREM;
-      if constexpr (SP == 3) {
-        if (s % SPH == 0) {
-          // a new head: its coefficients become the wave's dense [32 cells][window rows] matrix.  Wave-private, and LDS
-          // operations of one wave complete in order: no barrier, the reads below simply follow the writes.
-          const int hd = s / SPH;
-          const u32x4 z4 = {0u, 0u, 0u, 0u};
+      // bf16 storage: a new head's coefficients become the wave's dense [32 cells][window rows] matrix.  Wave-private, and LDS
+      // operations of one wave complete in order: no barrier, the aggregation's reads simply follow the writes.  Head 0 is
+      // written after slab 0's first barrier (until then the region holds the alpha_src table phase A reads on every wave).
+      auto densify = [&](int hd) {
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        constexpr int DB = 32 * Win::PITCH;
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < (DB + 1023) / 1024; ++i)
+          if ((i + 1) * 1024 <= DB || lane * 16 + i * 1024 < DB)
             asm volatile("ds_write_b128 %0, %1" ::"v"(dn0 + lane * 16 + i * 1024), "v"(z4) : "memory");
-          if (hl == (hd & 1)) {
-            const int wself = self_idx - wbase;
-            const uint32_t rowb = dn0 + r * 256;
+        if (hl == (hd & 1)) {
+          const int wself = self_idx - wbase;
+          const uint32_t rowb = dn0 + r * Win::PITCH;
 #pragma unroll
-            for (int b = 0; b <= K; ++b) {
-              const int off = b < K ? Off::dr[b < K ? b : 0] * HW_ + Off::dc[b < K ? b : 0] : 0;
-              const int wp = wself - off;
-              const uint32_t ad = rowb + ((((uint32_t)wp >> 3) ^ (uint32_t)(r & 15)) << 4) + ((uint32_t)wp & 7) * 2;
-              const uint32_t v = NHL > 1 && (hd >> 1) ? apk[NHL > 1 ? 1 : 0][b / 2] : apk[0][b / 2];
-              if (b & 1) asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(ad), "v"(v) : "memory");
-              else asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"(v) : "memory");
-            }
+          for (int b = 0; b <= K; ++b) {
+            const int off = b < K ? Off::dr[b < K ? b : 0] * HW_ + Off::dc[b < K ? b : 0] : 0;
+            const int wp = wself - off;
+            const uint32_t ad = rowb + (uint32_t)wp * 2u;
+            const uint32_t v = NHL > 1 && (hd >> 1) ? apk[NHL > 1 ? 1 : 0][b / 2] : apk[0][b / 2];
+            if (b & 1) asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(ad), "v"(v) : "memory");
+            else asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"(v) : "memory");
           }
         }
+      };
+      if constexpr (SP == 3) {
+        if (s % SPH == 0 && s > 0) densify(s / SPH);
       }
       if (s == 0) wait_vm_lgkm<0>();                    // (slab 0 was queued BEHIND its W rows: wait for everything)
       else if (WREM && wextra) wait_vm_lgkm<2 * (WH + 1)>();
@@ -801,7 +834,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
           const int c = tid + i * NTH;
           if (c < HC) { scsh[c] = scv[i]; scsh[HC + c] = shv[i]; }
         }
-        if constexpr (EPI == EPI_HEADS) {
+        if constexpr (SP == 3) densify(0);             // (every wave is past phase A: the alpha_src table is dead)
+        if constexpr (EPI == EPI_HEADS && !Lds::HEADW_LATE) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             if (tid + i * NTH < Lds::HEADW) attr[tid + i * NTH] = hwv[i];
@@ -823,12 +857,12 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
           // the neighbourhood sum on the matrix pipe (AggWindow): result register i = channel 8 (i >> 2) + 4 hl + (i & 3)
           f32x16 d;
           if constexpr (Win::NKB == 8) {
-            agg_blocks<0, 4, true>(d, tr0, tr1, bq0);
-            agg_blocks<4, 4, false>(d, tr0, tr1, bq0);
+            agg_blocks<0, 4, true, false>(d, tr0, tr1, bq0, hl);
+            agg_blocks<4, 4, false, Win::TAIL_BEYOND_PITCH>(d, tr0, tr1, bq0, hl);
           } else {
             static_assert(Win::NKB == 5, "window blocks");
-            agg_blocks<0, 3, true>(d, tr0, tr1, bq0);
-            agg_blocks<3, 2, false>(d, tr0, tr1, bq0);
+            agg_blocks<0, 3, true, false>(d, tr0, tr1, bq0, hl);
+            agg_blocks<3, 2, false, false>(d, tr0, tr1, bq0, hl);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) g[j] = (f32x4){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
@@ -874,6 +908,15 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
       BGNN_STAMP(5)   // wait for WA + barrier
       if (s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
+      if constexpr (Lds::HEADW_LATE) {
+        // last slab gathered by every wave: its region now takes the heads' weight table (registers since the prologue); the two
+        // barriers between here and the final epilogue publish it
+        if (s + 1 == NSLAB) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (tid + i * NTH < Lds::HEADW) lds_write1<0>(lds_addr(attr + tid + i * NTH), hwv[i]);
+        }
+      }
       // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
       using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
       using LPE = typename std::conditional<SP == 2, _Float16, __bf16>::type;
@@ -1081,9 +1124,9 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   if (a.stamps && threadIdx.x == 0) {
     // counters 0..15: every instance; 32..47: the 256 -> 64 instance; 48..63: the heads instance (16..31: the persistent kernel)
     unsigned long long *own = a.stamps + (EPI == EPI_HEADS ? 48 : NT == 2 ? 32 : 0);
-    for (int i = 0; i < 9; ++i) atomicAdd(a.stamps + i, t_sum[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(a.stamps + i, t_sum[i]);
     if (own != a.stamps) {
-      for (int i = 0; i < 9; ++i) atomicAdd(own + i, t_sum[i]);
+      for (int i = 0; i < 12; ++i) atomicAdd(own + i, t_sum[i]);
       atomicAdd(own + 15, 1ull);
     }
     atomicAdd(a.stamps + 15, 1ull);

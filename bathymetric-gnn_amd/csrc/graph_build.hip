@@ -605,6 +605,201 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
   }
 }
 
+// ---- LDS-tiled form of the feature kernel for the usual shapes (K = 8 / 16, 3 edge features) -------------------------------
+// The thread-per-cell form above issues ~30 (K = 8) / ~60 (K = 16) scattered global loads per cell (every stencil access goes to
+// L2) and one float64 division + atan per in-edge.  This form works on chunks of 8 x 64 cells of the work item's row band:
+//   1. the chunk and a halo of R cells (depth, nan_to_num'ed filled depth, node id) is staged in LDS by coalesced loads --
+//      every global array is then read once per chunk (+ halo) instead of once per stencil access;
+//   2. an edge and its mirror image have opposite depth differences and the same length, and atan is odd, so the slope of the
+//      in-edge of slot b at cell T from source S is the negative of the slope of the in-edge of slot mirror(b) at S from T:
+//      every cell computes only its FORWARD slots (source earlier in row-major order: 4 of 8 / 8 of 16) and leaves the values in
+//      LDS; the other half is read back, negated, from the partner cell -- or computed in place where the partner lies outside
+//      the chunk (last R rows / columns of a chunk).  4.4 instead of 8 (9.3 instead of 16) float64 atan per cell.
+// Outputs are bit-identical to the thread-per-cell form: (float)(-x) == -(float)x, fl(a - b) == -fl(b - a), and the cases
+// where the sign does not flip (zero or NaN depth difference -> +0) are told apart (tests/test_gpu_graph.py).
+template <int KV> struct FeatStencil;
+template <> struct FeatStencil<8> {
+  static constexpr int dr[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+  static constexpr int dc[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+};
+template <> struct FeatStencil<16> {
+  static constexpr int dr[16] = {-1, -1, -1, 0, 0, 1, 1, 1, -2, -2, -2, 0, 0, 2, 2, 2};
+  static constexpr int dc[16] = {-1, 0, 1, -1, 1, -1, 0, 1, -2, 0, 2, -2, 2, -2, 0, 2};
+};
+
+template <int KV>
+__global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Stencil st) {
+  using FS = FeatStencil<KV>;
+  constexpr int R = KV == 16 ? 2 : 1, CR = 8, CW = 64, SW = CW + 2 * R, SH = CR + 2 * R, NS = SH * SW;
+  constexpr int NF = KV / 2;                                    // forward slots per cell: b % 8 >= 4
+  __shared__ float s_depth[NS], s_fill[NS];
+  __shared__ int s_nid[NS];
+  __shared__ float s_fwd[CR * CW * NF];
+  __shared__ double s_dist[16];
+  const BgnnWorkItem it = a.items[blockIdx.x];
+  const BgnnTileMeta t = a.tiles[it.tile];
+  const int h = t.h, w = t.w;
+  const int64_t tb = t.cell_off;
+  const int tid = threadIdx.x;
+  if (tid < KV) {
+    const double dx = (double)st.dc[tid] * t.rx, dy = (double)st.dr[tid] * t.ry;
+    s_dist[tid] = sqrt(dx * dx + dy * dy);
+  }
+  // slope of the edge source -> target with depth difference dz = depth[target] - depth[source], exactly as the form above
+  auto slope_of = [&](float dz, double dist) -> float {
+    double slope = 0.0;
+    if (dist > 0.0) slope = atan((double)dz / dist) * 57.29577951308232;
+    return (slope != slope) ? 0.0f : (float)slope;
+  };
+  for (int rr0 = it.r0; rr0 < it.r0 + it.nr; rr0 += CR) {
+    const int rows = min(CR, it.r0 + it.nr - rr0);
+    for (int c0 = 0; c0 < w; c0 += CW) {
+      const int cols = min(CW, w - c0);
+      __syncthreads();                                          // the previous chunk's readers are done (first pass: s_dist visible)
+      for (int i = tid; i < NS; i += 256) {
+        const int gr = rr0 - R + i / SW, gc = c0 - R + i % SW;
+        float d = 0.0f, f = 0.0f;
+        int nid = -1;
+        if (gr >= 0 && gr < h && gc >= 0 && gc < w && gr < rr0 + rows + R && gc < c0 + cols + R) {
+          const int64_t gi = tb + (int64_t)gr * w + gc;
+          d = a.depth[gi];
+          const int id = a.node_id[gi];
+          nid = id < 0 ? -1 : id;
+          f = nan_to_num_f32(id >= 0 ? d : a.local_mean[gi]);    // mask[gi] <=> node_id[gi] >= 0
+        }
+        s_depth[i] = d; s_fill[i] = f; s_nid[i] = nid;
+      }
+      __syncthreads();
+      // ---- pass 1: forward slopes ---------------------------------------------------------------------------------------------
+#pragma unroll
+      for (int k = 0; k < CR * CW / 256; ++k) {
+        const int li = tid + 256 * k, lr = li / CW, lc = li % CW;
+        const int si = (lr + R) * SW + lc + R;
+        if (lr < rows && lc < cols && s_nid[si] >= 0) {
+          const float dt = s_depth[si];
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int b = (j / 4) * 8 + 4 + (j % 4);
+            const int ss = si - FS::dr[b] * SW - FS::dc[b];
+            float v = 0.0f;
+            if (s_nid[ss] >= 0) v = slope_of(dt - s_depth[ss], s_dist[b]);
+            s_fwd[j * (CR * CW) + li] = v;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- pass 2: node features, stencil row, edge attributes -------------------------------------------------------------------
+#pragma unroll 1
+      for (int k = 0; k < CR * CW / 256; ++k) {
+        const int li = tid + 256 * k, lr = li / CW, lc = li % CW;
+        const int si = (lr + R) * SW + lc + R;
+        if (!(lr < rows && lc < cols)) continue;
+        const int id = s_nid[si];
+        if (id < 0) continue;
+        const int r = rr0 + lr, c = c0 + lc;
+        const int64_t idx = tb + (int64_t)r * w + c;
+        const float f0 = s_fill[si];
+        float gy, gx;
+        if (r == 0) gy = s_fill[si + SW] - f0;
+        else if (r == h - 1) gy = f0 - s_fill[si - SW];
+        else gy = (s_fill[si + SW] - s_fill[si - SW]) / 2.0f;
+        if (c == 0) gx = s_fill[si + 1] - f0;
+        else if (c == w - 1) gx = f0 - s_fill[si - 1];
+        else gx = (s_fill[si + 1] - s_fill[si - 1]) / 2.0f;
+        const float gmag = sqrtf(gx * gx + gy * gy);
+        const double up = (double)(r > 0 ? s_fill[si - SW] : f0);
+        const double dn = (double)(r < h - 1 ? s_fill[si + SW] : f0);
+        const double lf = (double)(c > 0 ? s_fill[si - 1] : f0);
+        const double rt = (double)(c < w - 1 ? s_fill[si + 1] : f0);
+        const double cc0 = (double)f0 * -2.0;
+        float lap = (float)(cc0 + (up + dn)) + (float)(cc0 + (lf + rt));
+        int cnt = 0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+          for (int dc = -1; dc <= 1; ++dc) cnt += s_nid[si + dr * SW + dc] >= 0 ? 1 : 0;    // (outside the tile: staged as -1)
+        if (cnt < 3) lap = 0.0f;
+        const float lstd = a.local_std[idx];
+        const float dz_tgt = s_depth[si];
+        float cand[8];
+        cand[BGNN_NF_DEPTH] = dz_tgt;
+        cand[BGNN_NF_LOCAL_MEAN] = a.local_mean[idx];
+        cand[BGNN_NF_LOCAL_STD] = lstd;
+        cand[BGNN_NF_GRADIENT_X] = gx;
+        cand[BGNN_NF_GRADIENT_Y] = gy;
+        cand[BGNN_NF_GRADIENT_MAGNITUDE] = gmag;
+        cand[BGNN_NF_CURVATURE] = lap;
+        cand[BGNN_NF_UNCERTAINTY] = a.unc ? a.unc[idx] : 0.0f;
+        float xo[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          float v = 0.0f;
+          if (f < a.F) {
+            const int fid = a.feat_ids[f];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (fid == q) v = cand[q];
+            v = nan_to_num_f32(v);
+          }
+          xo[f] = v;
+        }
+        float4 *xp = reinterpret_cast<float4 *>(a.x8 + (int64_t)id * 8);
+        xp[0] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+        xp[1] = make_float4(xo[4], xo[5], xo[6], xo[7]);
+        a.node_local_std[id] = nan_to_num_f32(lstd);
+        int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * KV);
+        float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * (3 * KV));
+#pragma unroll 1
+        for (int half = 0; half < KV / 8; ++half) {
+          int sids[8];
+          float evs[24];
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) {
+            const int b = half * 8 + bb;
+            const int sdr = half ? 2 * FS::dr[bb] : FS::dr[bb], sdc = half ? 2 * FS::dc[bb] : FS::dc[bb];
+            const int ss = si - sdr * SW - sdc;
+            const int sid = s_nid[ss];
+            sids[bb] = sid;
+            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+            if (sid >= 0) {
+              const double dist = s_dist[b];
+              const float dz = dz_tgt - s_depth[ss];
+              float sl;
+              if (bb >= 4) {
+                sl = s_fwd[(half * 4 + (bb - 4)) * (CR * CW) + li];        // this cell's own forward slot
+              } else {
+                // mirrored slot: the partner is cell ss, its forward slot 7 - bb of the same half (offset negated)
+                const int plr = lr - sdr, plc = lc - sdc;
+                if (plr < rows && plc >= 0 && plc < cols) {                 // (plr >= lr: the partner lies below or to the right)
+                  const float fv = s_fwd[(half * 4 + (3 - bb)) * (CR * CW) + plr * CW + plc];
+                  sl = (!(dist > 0.0) || dz != dz || dz == 0.0f) ? 0.0f : -fv;
+                } else {
+                  sl = slope_of(dz, dist);
+                }
+              }
+              float vals[3];
+#pragma unroll
+              for (int f = 0; f < 3; ++f) {
+                const int eid = a.edge_ids[f];
+                float v = 0.0f;
+                if (eid == BGNN_EF_DISTANCE) { const double d = dist; v = (d != d) ? 0.0f : (float)d; }
+                else if (eid == BGNN_EF_DEPTH_DIFFERENCE) v = nan_to_num_f32(dz);
+                else if (eid == BGNN_EF_SLOPE) v = sl;
+                vals[f] = v;
+              }
+              e0 = vals[0]; e1 = vals[1]; e2 = vals[2];
+            }
+            evs[3 * bb] = e0; evs[3 * bb + 1] = e1; evs[3 * bb + 2] = e2;
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // counts per tile (nodes, edges)
 // ------------------------------------------------------------------------------------------
@@ -805,7 +1000,10 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     }
     if (tiles->uncertainty && !listed_unc) a.feat_ids[nf++] = BGNN_NF_UNCERTAINTY;
     for (int i = 0; i < opts->n_edge_features; ++i) a.edge_ids[i] = opts->edge_features[i];
-    if (st.K == 8 && a.ED == 3) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    const bool tiled = ctx->opts.features_tiled != 0;   // (0: the thread-per-cell form -- kept as the statement the tiled form is tested against)
+    if (st.K == 8 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 16 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 8 && a.ED == 3) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 16 && a.ED == 3) hipLaunchKernelGGL(features_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else hipLaunchKernelGGL(features_kernel<0>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
   }

@@ -220,3 +220,53 @@ def test_graphs_of_a_closed_context_are_inert(gpu_device):
     gc.collect()                                                    # finalisers run: must not call into the freed context
     g2 = gb.build_graph(d, m, None, (0.5, 0.5))                     # the default context is unaffected
     assert g2.num_nodes == n
+
+
+@pytest.mark.parametrize("conn", ["8-connected", "16-dilated"])
+def test_tiled_feature_kernel_is_bit_identical_to_the_cell_kernel(conn, gpu_device):
+    """The LDS-tiled feature kernel computes the float64 slope of an edge once for both directions (atan is odd, the depth
+    difference antisymmetric) and reads stencil operands from a staged tile; the thread-per-cell kernel (option
+    features_tiled = 0) is the statement it must reproduce BIT FOR BIT: random masks, NaN / inf / nodata depths inside the
+    mask, equal depths (zero slope: the sign must not flip), huge and tiny resolutions, ragged shapes that leave partial
+    8 x 64 chunks, widths below and above one chunk."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    ctx = rt.get_context(gpu_device)
+    rng = np.random.default_rng(5)
+    cases = []
+    for (h, w), res in [((37, 150), (0.5, 0.5)), ((64, 64), (1.0, 2.0)), ((9, 300), (1000.0, 1000.0)), ((130, 70), (1e-3, 0.25)), ((5, 3), (0.5, 0.5)),
+                         ((256, 256), (0.5, 0.5))]:
+        d, m, _ = synthetic.synthetic_tile(h, w, int(rng.integers(1 << 30)), "V1" if min(h, w) >= 16 else "V0")
+        d = d.copy(); m = m.copy()
+        k = max(1, h * w // 50)
+        ii = rng.integers(0, h * w, size=(6, k))
+        d.flat[ii[0]] = np.nan; d.flat[ii[1]] = np.inf; d.flat[ii[2]] = -np.inf; d.flat[ii[3]] = 1.0e6
+        d.flat[ii[4]] = -20.0                                   # equal depths: zero depth difference, slope +0 both ways
+        d.flat[ii[5]] = d.flat[np.minimum(ii[5] + 1, h * w - 1)]
+        m.flat[ii[0][: k // 2]] = True; m.flat[ii[1][: k // 2]] = True; m.flat[ii[2][: k // 2]] = True     # non-finite depths INSIDE the mask
+        cases.append((d.astype(np.float32), m, res))
+    gb = GraphBuilder(connectivity=conn, device=gpu_device)
+    outs = {}
+    for tiled in (0, 1):
+        with ctx.options(features_tiled=tiled):
+            per = []
+            for d, m, res in cases:
+                g = gb.build_graph(d, m, None, res)
+                per.append((g.x.clone(), g.edge_attr.clone(), g.edge_index.clone(), g.local_std.clone()))
+            # and one ragged batch (several grids in one build)
+            g = gb.build_graphs([c[0] for c in cases[:5]], [c[1] for c in cases[:5]], None, [c[2] for c in cases[:5]])
+            per.append((g.x.clone(), g.edge_attr.clone(), g.edge_index.clone(), g.local_std.clone()))
+            outs[tiled] = per
+    n_edges = 0
+    for a, b in zip(outs[0], outs[1]):
+        for ta, tb in zip(a, b):
+            assert ta.shape == tb.shape
+            va = ta.view(torch.int32) if ta.dtype == torch.float32 else ta
+            vb = tb.view(torch.int32) if tb.dtype == torch.float32 else tb
+            assert torch.equal(va, vb)
+        n_edges += a[1].shape[0]
+    assert n_edges > 500000
+    # the zero-slope sign case really occurred: some edge has depth difference exactly 0 and slope +0 (not -0)
+    ea = outs[1][0][1]
+    zero = ea[:, 1] == 0
+    assert int(zero.sum()) > 0 and bool((ea[zero, 2].view(torch.int32) == 0).all())

@@ -29,8 +29,10 @@ lib=rt.load_library(); lib.bgnn_debug_stamps.argtypes=[C.c_void_p, C.POINTER(C.c
 buf=(C.c_uint64*64)(); lib.bgnn_debug_stamps(eng.ctx.handle, buf)
 eng.infer_device(hw,res,d_t,m_t,None); torch.cuda.synchronize()
 lib.bgnn_debug_stamps(eng.ctx.handle, buf)
-n=buf[15]; names=["prologue ids","dma offs+issue","phase A","wait slab+bar","gather","wait W+bar","MFMA(+slab issue)","bar+W issue","final epilogue"]
-tot=sum(buf[i] for i in range(9))
+n=buf[15]; names=["slab 0 DMA issue","halo-table barrier","phase A","wait slab+bar","gather","wait W+bar","MFMA(+slab issue)","bar+W issue","final epilogue",
+                  "decode + round 1 issue", "round 1 wait", "round 2 (+ table writes)"]
+NS=len(names)
+tot=sum(buf[i] for i in range(NS))
 print("blocks",n, "total cycles/block", tot/n)
 for i,nm in enumerate(names): print("%-20s %10.0f cycles/block  %5.1f%%"%(nm, buf[i]/n, 100*buf[i]/tot))
 if buf[14]:
@@ -48,11 +50,11 @@ if buf[31]:
 
 for base, title in ((32, "256 -> 64 instance"), (48, "heads instance")):
     if buf[base + 15]:
-        nb = buf[base + 15]; tt = sum(buf[base + i] for i in range(9))
+        nb = buf[base + 15]; tt = sum(buf[base + i] for i in range(NS))
         print(title, "blocks", nb, "cycles/block", tt / nb)
         for i, nm in enumerate(names): print("  %-20s %10.0f cycles/block  %5.1f%%" % (nm, buf[base + i] / nb, 100 * buf[base + i] / tt))
 
 if buf[15] > buf[47] + buf[63]:
-    nb = buf[15] - buf[47] - buf[63]; vals = [buf[i] - buf[32 + i] - buf[48 + i] for i in range(9)]; tt = sum(vals)
+    nb = buf[15] - buf[47] - buf[63]; vals = [buf[i] - buf[32 + i] - buf[48 + i] for i in range(NS)]; tt = sum(vals)
     print("256 -> 256 instances (by difference) blocks", nb, "cycles/block", tt / nb)
     for i, nm in enumerate(names): print("  %-20s %10.0f cycles/block  %5.1f%%" % (nm, vals[i] / nb, 100 * vals[i] / tt))
