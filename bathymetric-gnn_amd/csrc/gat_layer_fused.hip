@@ -323,19 +323,35 @@ struct SplitTiles {
   }
 };
 
-// plain bf16 (SP = 3): one MFMA per tile and 16 k; tile t's fragment sits at wh + t KiB (hi-only image)
-template <int NT, int T>
+// plain bf16 (SP = 3): one MFMA per tile and 16 k; tile t's fragment sits at wh + t KiB (hi-only image).
+// The fragments of up to FOUR tiles are requested together and waited for once: a bf16 MFMA is 8 passes, far shorter than an LDS
+// round trip, so the one-ahead scheme the f32 path uses (fragment t + 1 under the MFMA of tile t) left every one of the 16 reads
+// of a slab exposed -- ~20 % of the 256 -> 256 instance's lifetime.  With NT = 8 the second batch's reads pass under the first
+// batch's MFMAs.  (16 more live registers in a phase that has them to spare: the aggregation's operands are dead by then.)
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read4_at(uint32_t addr) { return lds_read4<OFF>(addr); }
+template <int NT, int T0>
 struct Bf16Tiles {
-  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const bf16x8 &x, uint32_t wh, f32x4 aw) {
+  static constexpr int NB = NT - T0 < 4 ? NT - T0 : 4;
+  __device__ static __forceinline__ void load(f32x4 (&w)[4], uint32_t wh) {
+    if constexpr (NB > 0) w[0] = lds_read4_at<(T0 + 0) * 1024>(wh);
+    if constexpr (NB > 1) w[1] = lds_read4_at<(T0 + 1) * 1024>(wh);
+    if constexpr (NB > 2) w[2] = lds_read4_at<(T0 + 2) * 1024>(wh);
+    if constexpr (NB > 3) w[3] = lds_read4_at<(T0 + 3) * 1024>(wh);
+  }
+  __device__ static __forceinline__ void step(f32x16 (&acc)[NT], const bf16x8 &x, uint32_t wh, f32x4 (&w)[4]) {
     lds_reads_done();
-    f32x4 nw = aw;
-    if constexpr (T + 1 < NT) nw = lds_read4<(T + 1) * 1024>(wh);
-    acc[T] = mfma_lp(__builtin_bit_cast(bf16x8, aw), x, acc[T]);
-    if constexpr (T + 1 < NT) Bf16Tiles<NT, T + 1>::step(acc, x, wh, nw);
+    f32x4 nw[4];
+    if constexpr (T0 + NB < NT) Bf16Tiles<NT, T0 + NB>::load(nw, wh);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[T0 + i] = mfma_lp(__builtin_bit_cast(bf16x8, w[i]), x, acc[T0 + i]);
+    if constexpr (T0 + NB < NT) Bf16Tiles<NT, T0 + NB>::step(acc, x, wh, nw);
   }
   __device__ static __forceinline__ void run(f32x16 (&acc)[NT], const bf16x8 &x, uint32_t wh) {
-    static_assert(T == 0, "entry point");
-    step(acc, x, wh, lds_read4<0>(wh));
+    static_assert(T0 == 0, "entry point");
+    f32x4 w[4];
+    load(w, wh);
+    step(acc, x, wh, w);
   }
 };
 
@@ -464,7 +480,13 @@ template <int HC, int C, int K, int NT, int EPI, int SP>
 struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and launcher agree through this)
   static constexpr int H = HC / C, NC = NT * 32, HR = FusedGeom<K>::HR;
   static constexpr int XB = SP == 3 ? 2 : 4;             // bytes per stored activation
-  static constexpr int SLAB = HR * 32 * XB / 4;          // [HR][32 channels]
+  static constexpr int SLAB1 = HR * 32 * XB / 4;         // one slab image: [HR][32 channels]
+  // bf16 storage, 256 -> 256 instance (two workgroups per CU whatever the LDS, its 128 accumulator registers decide): the slab image is
+  // DOUBLE-BUFFERED -- slab s + 1 is requested as soon as slab s is visible, a whole slab period ahead, instead of after slab s has
+  // been gathered (half a period ahead: with no matrix work to hide under, ~17 % of that instance's lifetime was spent waiting
+  // for it).  Paid for by aliasing (alpha_src table and halo ids inside the alpha region, att vectors parked in the free buffer).
+  static constexpr bool DBUF = SP == 3 && NT == 8 && EPI == EPI_NEXT;
+  static constexpr int SLAB = DBUF ? 2 * SLAB1 : SLAB1;
   static constexpr int WBUF = 2 * WHalf<NT, SP>::BYTES / 4;
   // the epilogue's four wave-private 32 x 36 store patches reuse slab (+ wbuf)
   static constexpr int PATCH_PAD = EPI == EPI_NEXT && SLAB + WBUF < 4 * 32 * TILED_PITCH ? 4 * 32 * TILED_PITCH - SLAB - WBUF : 0;
@@ -472,17 +494,23 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   // bf16 storage path, two space savers (so that its narrow instances fit three workgroups per CU):
   //  * the halo's alpha_src table (phase A only) lives in the dense-alpha region, which is first written after phase A;
   //  * the heads' small weight table (final epilogue only) is parked in the slab region once the last slab has been gathered.
-  static constexpr bool HAS_IN_ALPHA = SP == 3, HEADW_LATE = SP == 3 && EPI == EPI_HEADS;
-  static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? 2 * NC : HEADW_LATE ? 0 : HEADW);
+  //  * DBUF: the halo ids live there as well (the epilogue takes its row ids from the lanes' own registers), and the next layer's
+  //    att vectors are DMA'd into the free slab buffer during the last slab.
+  static constexpr bool HAS_IN_ALPHA = SP == 3, HEADW_LATE = SP == 3 && EPI == EPI_HEADS, HID_IN_ALPHA = DBUF, ATT_LATE = DBUF;
+  // (floats) past the four store patches, which start at image A, and past the 8 rows (128 floats) image A's last MFMA over-reads
+  static constexpr int ATT_OFF = SLAB1 + 128 > 4 * 32 * TILED_PITCH ? SLAB1 + 128 : 4 * 32 * TILED_PITCH;
+  static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? (ATT_LATE ? 0 : 2 * NC) : HEADW_LATE ? 0 : HEADW);
   static constexpr int RSZ = RA > RB ? RA : RB;
   static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
   // attention coefficients: [128 cells][APITCH] f32 (sparse, every head); bf16 storage path: the CURRENT head's coefficients as
   // four wave-private dense [32 cells][window rows] bf16 matrices (the aggregation's MFMA B operand) -- see AggWindow
   static constexpr int ALPHA = SP == 3 ? 4 * 32 * AggWindow<K>::PITCH / 4 : 128 * APITCH;
-  static_assert(!HAS_IN_ALPHA || HR * H <= ALPHA, "the alpha_src table fits the dense-alpha region");
+  static_assert(!HAS_IN_ALPHA || HR * H + (HID_IN_ALPHA ? HR : 0) <= ALPHA, "the alpha_src table (and the halo ids) fit the dense-alpha region");
+  static_assert(!DBUF || (4 * 32 * TILED_PITCH <= ATT_OFF && ATT_OFF + 2 * NC <= SLAB), "patches | att vectors share the slab region");
   static_assert(!HEADW_LATE || HEADW <= SLAB, "the heads' weight table fits the slab region");
   static_assert(SP != 3 || !AggWindow<K>::TAIL_BEYOND_PITCH || WBUF * 4 >= 8 * 64, "the 8 rows read past the slab image stay inside the W buffer");
-  static constexpr int PRE = SLAB + WBUF + PATCH_PAD + RSZ + HR + 4;
+  // (HID_IN_ALPHA: the epilogue's row ids come from a compact [128 cells] table instead of the halo table)
+  static constexpr int PRE = SLAB + WBUF + PATCH_PAD + RSZ + (HID_IN_ALPHA ? 128 : HR) + 4;
   static constexpr int ALIGN = (4 - PRE % 4) % 4;        // the dense matrices start on a 16-byte boundary
   static constexpr int FLOATS = PRE + ALIGN + ALPHA;
   static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
@@ -506,16 +534,22 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   extern __shared__ __attribute__((aligned(128))) float lds[];
   float *slab = lds;                                   // [HR][32]  halo rows of the current slab, 16-B chunks XOR-swizzled
   float *wbuf = slab + Lds::SLAB;                      // W_{l+1} rows of the current slab: two 16-row halves
+  // DBUF: two slab images.  EVEN slabs use the upper one (B, next to the W buffer), odd slabs the lower one (A): the k = 16
+  // window's last MFMA reads 8 rows past its image (AggWindow) -- past B that is the W buffer's head, past A it is B's head,
+  // which by then holds rows of an even slab (landed, or being replaced by the next one's): finite bf16 either way.
+  constexpr bool DBUF = Lds::DBUF;
+  constexpr int SLAB1B = Lds::SLAB1 * 4;                 // bytes of one slab image
   // Region R is time-shared: alpha_src of the halo rows during phase A, then (from the first slab barrier on)
   // the folded scale / shift table and, behind it, the next layer's att_src | att_dst for the epilogue.
   constexpr int RSZ = Lds::RSZ, APITCH = Lds::APITCH;
   float *rreg = wbuf + Lds::WBUF + Lds::PATCH_PAD;
   float *scsh = rreg;                                  // [2][HC]   folded scale / shift (slab loop)
-  float *attr = Lds::HEADW_LATE ? slab : rreg + 2 * HC;   // [2][NC] att_src | att_dst (epilogue, EPI_NEXT) / heads' weight table
-  int *hid = reinterpret_cast<int *>(rreg + RSZ);      // [HR]
-  int *minid = hid + HR;                               // [4]
+  float *attr = Lds::HEADW_LATE ? slab : Lds::ATT_LATE ? slab + Lds::ATT_OFF : rreg + 2 * HC;   // [2][NC] att_src | att_dst (epilogue, EPI_NEXT) / heads' weight table
+  int *cid = reinterpret_cast<int *>(rreg + RSZ);      // [128] node id of each block cell (HID_IN_ALPHA only)
+  int *minid = cid + (Lds::HID_IN_ALPHA ? 128 : HR);   // [4]
   float *alx = reinterpret_cast<float *>(minid + 4) + Lds::ALIGN;   // [128][APITCH]  alpha[cell][head][K+1]; bf16 path: dense (AggWindow)
   float *has = Lds::HAS_IN_ALPHA ? alx : rreg;         // [HR][H]   (phase A; bf16 path: inside the not yet written dense-alpha region)
+  int *hid = Lds::HID_IN_ALPHA ? reinterpret_cast<int *>(alx + HR * H) : reinterpret_cast<int *>(rreg + RSZ);   // [HR]
 
 #if BGNN_DIAG
   unsigned long long t_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -683,7 +717,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     for (int p = 0; p < NPIECE; ++p) {
       if ((p + 1) * NTH <= HR * CPR || p * NTH + tid < HR * CPR) {        // (only the last piece is partial: compile-time true before)
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(dbase[p] + sb),
-                                         (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(slab + (DBUF && !(s & 1) ? Lds::SLAB1 : 0) + (p * NTH + wave * 64) * 4), 16, 0, 0);
       }
     }
   };
@@ -694,6 +728,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hid_v >= 0 ? hasv[hh] : 0.0f;
   }
+  if (Lds::HID_IN_ALPHA && hl == 0) cid[cell] = my_pre < 0 ? -1 : my_pre;
   {   // (phase A's register operands are complete as well before the DMA is queued: no wait behind it later)
     // (the table writes above sit under `tid < HR`: a wave that skips them has not waited yet -- touch every round-2 register)
     float sink = 0.0f;
@@ -840,11 +875,21 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
           for (int i = 0; i < 2; ++i)
             if (tid + i * NTH < Lds::HEADW) attr[tid + i * NTH] = hwv[i];
         }
-        if (EPI == EPI_NEXT && wave < 2 && lane * 4 < NC)
+        if (EPI == EPI_NEXT && !Lds::ATT_LATE && wave < 2 && lane * 4 < NC)
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>((wave == 0 ? a.att_src : a.att_dst) + lane * 4),
                                            (__attribute__((address_space(3))) void *)(attr + wave * NC), 16, 0, 0);
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                   // scale / shift visible
+      }
+      // DBUF: slab s is visible and the other image was released a slab ago -> request slab s + 1 NOW (VM queue: [WA s][WB s][slab s+1])
+      if (DBUF && s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
+      if constexpr (Lds::ATT_LATE) {
+        // last slab: the free image (B: the last slab is odd) takes the next layer's att_src | att_dst.  EVERY wave issues one
+        // piece (waves 2, 3 repeat 0, 1's) so that the counted wait below is the same on all of them.
+        static_assert(!Lds::ATT_LATE || (NSLAB % 2 == 0 && NC * 4 == 1024), "the last slab uses image A; one 1-KiB piece per vector");
+        if (s + 1 == NSLAB)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(((wave & 1) == 0 ? a.att_src : a.att_dst) + lane * 4),
+                                           (__attribute__((address_space(3))) void *)(attr + (wave & 1) * NC), 16, 0, 0);
       }
       BGNN_STAMP(3)   // wait for slab + barrier
       const uint32_t ap = alx0 + (s / SPH) * ((K + 1) * 4);
@@ -856,13 +901,15 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         if constexpr (SP == 3) {
           // the neighbourhood sum on the matrix pipe (AggWindow): result register i = channel 8 (i >> 2) + 4 hl + (i & 3)
           f32x16 d;
+          const uint32_t sbo = DBUF && !(s & 1) ? SLAB1B : 0;     // which slab image (wave-uniform)
+          const uint32_t ta = tr0 + sbo, tb = tr1 + sbo;
           if constexpr (Win::NKB == 8) {
-            agg_blocks<0, 4, true, false>(d, tr0, tr1, bq0, hl);
-            agg_blocks<4, 4, false, Win::TAIL_BEYOND_PITCH>(d, tr0, tr1, bq0, hl);
+            agg_blocks<0, 4, true, false>(d, ta, tb, bq0, hl);
+            agg_blocks<4, 4, false, Win::TAIL_BEYOND_PITCH>(d, ta, tb, bq0, hl);
           } else {
             static_assert(Win::NKB == 5, "window blocks");
-            agg_blocks<0, 3, true, false>(d, tr0, tr1, bq0, hl);
-            agg_blocks<3, 2, false, false>(d, tr0, tr1, bq0, hl);
+            agg_blocks<0, 3, true, false>(d, ta, tb, bq0, hl);
+            agg_blocks<3, 2, false, false>(d, ta, tb, bq0, hl);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) g[j] = (f32x4){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
@@ -904,10 +951,19 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         }
       }
       BGNN_STAMP(4)   // gather + layer epilogue
-      if (WREM && wextra) wait_vm_lgkm<WH + 1>(); else wait_vm_lgkm<WH>();   // WA(s) landed (WB(s) may still fly)
+      if constexpr (DBUF) {
+        // WA(s) landed; behind it in the queue: WB(s) and the npc pieces of slab s + 1 (last slab: the att piece)
+        static_assert(!DBUF || WREM == 0, "DBUF instances deal the W pieces evenly");
+        if (DBG(4)) wait_vm_lgkm<0>();
+        else if (s + 1 == NSLAB) wait_vm_lgkm<WH + 1>();
+        else if (npc == NPIECE) wait_vm_lgkm<WH + NPIECE>();
+        else wait_vm_lgkm<WH + NPIECE - 1>();
+      } else {
+        if (WREM && wextra) wait_vm_lgkm<WH + 1>(); else wait_vm_lgkm<WH>();   // WA(s) landed (WB(s) may still fly)
+      }
       __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
       BGNN_STAMP(5)   // wait for WA + barrier
-      if (s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
+      if (!DBUF && s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
       if constexpr (Lds::HEADW_LATE) {
         // last slab gathered by every wave: its region now takes the heads' weight table (registers since the prologue); the two
         // barriers between here and the final epilogue publish it
@@ -957,7 +1013,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   if (EPI == EPI_NEXT && Lds::SLAB < 4 * 32 * TILED_PITCH) __syncthreads();
   if (!DBG(64)) {
     const int mr = tr, mc = tc;
-    const int id = hid[self_idx];
+    // (HID_IN_ALPHA: the halo id table was overwritten by the dense alpha matrices; the compact per-cell table is still there)
+    const int id = Lds::HID_IN_ALPHA ? cid[cell] : hid[self_idx];
     if (EPI == EPI_NEXT) {
       // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32).
       // att_src / att_dst were staged into LDS: no global-load latency chain here.
@@ -978,7 +1035,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
       for (int k = 0; k < NSTORE; ++k) {
         const int c = wave * 32 + lane / LPR + (64 / LPR) * k;
-        const int rid = hid[(c / TILE_W + RAD) * HW_ + c % TILE_W + RAD];
+        const int rid = Lds::HID_IN_ALPHA ? cid[c] : hid[(c / TILE_W + RAD) * HW_ + c % TILE_W + RAD];
         prow[k] = (rid >= 0 ? reinterpret_cast<char *>(a.out) + (int64_t)rid * (NC * XB) : reinterpret_cast<char *>(a.dump)) + (lane % LPR) * 16;
       }
       // The att reads go through the asm path with an explicit wait per tile: left to the scheduler, all 2*NT*4
