@@ -1000,7 +1000,11 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     }
     if (tiles->uncertainty && !listed_unc) a.feat_ids[nf++] = BGNN_NF_UNCERTAINTY;
     for (int i = 0; i < opts->n_edge_features; ++i) a.edge_ids[i] = opts->edge_features[i];
-    const bool tiled = ctx->opts.features_tiled != 0;   // (0: the thread-per-cell form -- kept as the statement the tiled form is tested against)
+    // the LDS-tiled form pays where its 8 x 64 chunks are mostly full: uniform batches of tiles at least one chunk wide and tall.
+    // Refinement grids of 3 .. 50 cells a side (ragged VR batches) leave it 10 % full and three barriers per chunk: measured 4x slower
+    // than the thread-per-cell form there.  (features_tiled = 0: always the thread-per-cell form -- the statement the tiled one is
+    // tested against; 2: the tiled form for every shape, for those tests.)
+    const bool tiled = ctx->opts.features_tiled == 2 || (ctx->opts.features_tiled == 1 && g->uni_w >= 64 && g->uni_h >= 8);
     if (st.K == 8 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 16 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 8 && a.ED == 3) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);

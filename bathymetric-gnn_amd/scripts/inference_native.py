@@ -45,6 +45,12 @@ class NativeVRProcessor:
                                        auto_correct_threshold, 0.6, CORRECTION_NORM_FLOOR)
         self._batch = []             # (depth, valid_mask, uncertainty|None, resolution)
         self._batch_node_count = 0
+        # Two batches in flight (submit_batch / collect_batch): a 50 000-node batch is ONE round of workgroups per kernel, so its
+        # twelve launches are a chain of latencies that leaves most of the GPU idle; the next batch runs on a second library
+        # context (own HIP stream, own arenas) beside it.  flush_batch() stays the reference's synchronous call.
+        self._engines = [self._engine]
+        self._inflight = []          # tickets in submission order: {"engine", "hw", "out"}
+        self._next_engine = 0
 
     # ---- helpers ---------------------------------------------------------------------------
     def _prepare(self, depth, uncertainty, resolution, nodata):
@@ -93,11 +99,69 @@ class NativeVRProcessor:
         return len(self._batch) > 0
 
     def flush_batch(self) -> List[Result]:
-        """Classify every queued grid in one fused pass (:281-342); results in insertion order."""
+        """Classify every queued grid in one fused pass (:281-342); results in insertion order.  Synchronous, like the
+        reference's (batches still in flight from ``submit_batch`` are not disturbed: this one queues behind the first
+        context's work and their results stay available to ``collect_batch``)."""
         if not self._batch:
             return []
         items, self._batch, self._batch_node_count = self._batch, [], 0
         return self._run(items)
+
+    # ---- two batches in flight (MI355X-first extension of the batching API; run_refinements uses it) --------------------------
+    MAX_IN_FLIGHT = 2
+
+    def _engine_for_next(self) -> TileBatchEngine:
+        from .. import runtime as rt
+        i = self._next_engine % self.MAX_IN_FLIGHT
+        self._next_engine += 1
+        while len(self._engines) <= i:              # the second library context is only created when batches are pipelined
+            ctx = rt.new_context(self._engine.ctx.device)
+            for k in ("matrix_path", "fused", "fold_extractor", "ragged_atlas", "fused_front", "features_tiled"):
+                ctx.set_option(k, self._engine.ctx.get_option(k))
+            self._engines.append(TileBatchEngine(self.model, self.graph_builder, self._engine.ctx.device, self.auto_correct_threshold,
+                                                 self._engine.review_threshold, self._engine.norm_floor, ctx=ctx))
+        return self._engines[i]
+
+    def submit_batch(self) -> Optional[int]:
+        """Start classifying the queued grids WITHOUT waiting for the result: the batch is uploaded and its kernels are queued on
+        one of two library contexts, alternately, so that it runs beside the batch submitted before it.  Returns the number of
+        batches now in flight (None if nothing was queued).  Results come back, in submission order, from ``collect_batch``.
+        At most ``MAX_IN_FLIGHT`` batches may be outstanding: collect the oldest first."""
+        if not self._batch:
+            return None
+        if len(self._inflight) >= self.MAX_IN_FLIGHT:
+            raise RuntimeError(f"{self.MAX_IN_FLIGHT} batches are already in flight: collect_batch() the oldest first")
+        items, self._batch, self._batch_node_count = self._batch, [], 0
+        eng = self._engine_for_next()
+        has_unc = any(it[2] is not None for it in items)
+        use_unc = [it[2] for it in items] if (has_unc and self.model.in_channels == self.graph_builder.n_node_columns(True)) else None
+        hw, res, d, m, u = self.graph_builder.upload_tiles([it[0] for it in items], [it[1] for it in items], use_unc, [it[3] for it in items])
+        out = eng.infer_device(hw, res, d, m, u, defer_end=True)     # asynchronous: nothing waits for this batch yet
+        self._inflight.append({"engine": eng, "hw": hw, "out": out, "keep": (d, m, u)})
+        return len(self._inflight)
+
+    @property
+    def batches_in_flight(self) -> int:
+        return len(self._inflight)
+
+    def _collect(self, index: int) -> List[Result]:
+        t = self._inflight.pop(index)
+        t["engine"].ctx.end()                        # the caller's stream now waits for that batch ...
+        out = t["out"].cpu().numpy()                 # ... and so does this copy
+        results, off = [], 0
+        for i in range(t["hw"].shape[0]):
+            h, w = int(t["hw"][i, 0]), int(t["hw"][i, 1])
+            n = h * w
+            results.append((out[0, off:off + n].reshape(h, w).copy(), out[1, off:off + n].reshape(h, w).copy(),
+                            out[2, off:off + n].reshape(h, w).copy()))
+            off += n
+        return results
+
+    def collect_batch(self) -> List[Result]:
+        """Results of the OLDEST batch in flight (blocks until it is done); same per-grid tuples as ``flush_batch``."""
+        if not self._inflight:
+            return []
+        return self._collect(0)
 
     # ---- whole-BAG device path (MI355X-first replacement of the main loop, :445-538) ---------------------
     def process_refinements(self, handler, writer=None, min_valid_ratio: float = 0.0,
@@ -203,12 +267,17 @@ def apply_results(depth: np.ndarray, uncertainty: Optional[np.ndarray], classifi
 
 
 def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_ratio: float = 0.0,
-                    auto_correct_threshold: Optional[float] = None, results_sink=None):
+                    auto_correct_threshold: Optional[float] = None, results_sink=None, pipelined: bool = True):
     """The grid-by-grid loop of the reference's ``main`` (:445-538): iterate the refinement grids, queue them
     with ``add_to_batch``, flush when ``batch_ready``, apply each grid's results (``apply_results`` closure,
     :480-503) and write it back with ``update_refinement_batch``.  Kept as the API-level mirror and as the
     statement ``NativeVRProcessor.process_refinements`` (records resident in HBM) is tested against.
-    ``results_sink(grid, classification, confidence, correction)`` stands where the sidecar builder is fed."""
+    ``results_sink(grid, classification, confidence, correction)`` stands where the sidecar builder is fed.
+
+    ``pipelined`` (default): a full batch is SUBMITTED (``submit_batch``) and the loop goes on queueing the next one; the
+    results of the batch before it are collected -- and applied, in the same grid order -- while the new one runs on the
+    processor's second library context.  Same results and statistics as the synchronous loop (``pipelined=False``: one
+    ``flush_batch`` per full batch, exactly the reference's control flow), grid for grid; the GPU just never waits for the host."""
     thr = processor.auto_correct_threshold if auto_correct_threshold is None else auto_correct_threshold
     stats = {"grids_processed": 0, "cells_processed": 0, "cells_classified_noise": 0, "cells_corrected": 0,
              "total_confidence": 0.0}
@@ -231,22 +300,44 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
         stats["cells_classified_noise"] += int(np.sum(noise))
         stats["total_confidence"] += float(np.sum(confidence[grid.valid_mask]))
 
-    def flush():
-        if not pending:
-            return
-        batch = processor.flush_batch()
+    def apply_all(plist, batch):
         k = 0
-        for grid, immediate in pending:
+        for grid, immediate in plist:
             if immediate is not None:
                 apply_one(grid, *immediate)
             else:
                 apply_one(grid, *batch[k]); k += 1
+
+    def flush():
+        if not pending:
+            return
+        apply_all(pending, processor.flush_batch())
         pending.clear()
+
+    submitted = []                                      # pending lists of the batches in flight, oldest first
+
+    def submit():
+        if not pending:
+            return
+        plist = list(pending); pending.clear()
+        if processor.batch_pending:
+            while processor.batches_in_flight >= processor.MAX_IN_FLIGHT:
+                apply_all(submitted.pop(0), processor.collect_batch())
+            processor.submit_batch()
+            submitted.append(plist)
+            while len(submitted) > 1:                   # the batch before this one: collect and apply it while this one runs
+                apply_all(submitted.pop(0), processor.collect_batch())
+        else:                                           # only grids without a valid cell: nothing to classify
+            while submitted:
+                apply_all(submitted.pop(0), processor.collect_batch())
+            apply_all(plist, [])
 
     for grid in handler.iterate_refinements(min_valid_ratio):
         pending.append((grid, processor.add_to_batch(grid.depth, grid.uncertainty, grid.resolution, nodata=nodata)))
         if processor.batch_ready:
-            flush()
-    flush()
+            submit() if pipelined else flush()
+    submit() if pipelined else flush()
+    while submitted:
+        apply_all(submitted.pop(0), processor.collect_batch())
     stats["mean_confidence"] = stats["total_confidence"] / stats["cells_processed"] if stats["cells_processed"] > 0 else 0
     return stats

@@ -314,6 +314,32 @@ class Bench:
                          f"of >= {budget} nodes on {streams} library context(s) / HIP stream(s), 8-connected, "
                          f"{self.layers}-layer GAT, inputs resident in HBM")}
 
+    def vr_processor_api(self, budget, base=28):
+        """The reference-shaped loop itself (scripts/inference_native.py:445-538 = run_refinements) on a synthetic VR BAG held in
+        HOST arrays: per-grid numpy work, H2D of every batch, D2H of its results, write-back -- everything a caller of the drop-in
+        API pays.  Synchronous (one flush_batch per full batch) and pipelined (two batches in flight)."""
+        from bathymetric_gnn_amd.data import GraphBuilder, VRBagHandler
+        from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor, run_refinements
+        model, _ = self.model(8)
+        md, ref = self.syn.synthetic_vr_bag(base, base, seed=4242)
+        h = VRBagHandler.from_arrays(md, ref)
+        proc = NativeVRProcessor(model, GraphBuilder(device=self.dev), self.dev)
+        proc.BATCH_NODE_BUDGET = budget
+        out = {"sample": f"synthetic VR BAG, {base}x{base} base cells, {h.num_refinement_cells} refinement grids (3x3..50x50), host arrays in / out, "
+                         f"{budget}-node batches"}
+        for name, mode in (("synchronous", False), ("pipelined", True)):
+            run_refinements(proc, h, h.copy_and_open_for_writing(), 0.0, pipelined=mode)      # warm-up (second context, arenas)
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            st = run_refinements(proc, h, h.copy_and_open_for_writing(), 0.0, pipelined=mode)
+            torch.cuda.synchronize(self.dev)
+            dt = time.perf_counter() - t0
+            out[name] = {"value": st["cells_processed"] / dt, "unit": "nodes/s", "wall_s": dt, "nodes": st["cells_processed"],
+                         "grids": st["grids_processed"]}
+        for e in proc._engines[1:]:
+            e.ctx.close()
+        return out
+
     # -- configs[4]: a survey resident in HBM, cut into overlapping tiles, classified, stitched on the device --------------
     def survey(self, size, tile=512, overlap=128, tile_batch=32):
         from bathymetric_gnn_amd.config import Config
@@ -681,13 +707,16 @@ def main():
             torch.cuda.empty_cache()
             grids = bench.syn.vr_grid_stream(args.vr_grids, seed0=1000)
             v1 = side(bench.vr(args.vr_grids, args.vr_budget, 1, grids=grids))
+            v2 = side(bench.vr(args.vr_grids, args.vr_budget, 2, grids=grids))
             v4 = side(bench.vr(args.vr_grids, args.vr_budget, 4, grids=grids))
             line["config4"] = {"config": "BASELINE configs[3]: VR-BAG mixed refinement grids (3x3..50x50), 4096-grid stream, "
                                          f"{args.vr_budget}-node batches (scripts/inference_native.py:128)",
                                "value": v1["value"], "unit": "nodes/s", "ms_per_step": v1["ms_per_step"], "roofline": v1["roofline"],
-                               "note": "value = ONE library context / HIP stream: what NativeVRProcessor.flush_batch (the reference-shaped "
-                                       "API) gives; four_contexts = the same batches dealt over 4 contexts",
-                               "one_context": v1, "four_contexts": v4}
+                               "note": "value = ONE library context / HIP stream: what one synchronous NativeVRProcessor.flush_batch after the "
+                                       "other gives; two_contexts = two batches in flight, what the processor's submit_batch / collect_batch "
+                                       "(run_refinements' default) keeps on the GPU; four_contexts = the same batches dealt over 4 contexts",
+                               "one_context": v1, "two_contexts": v2, "four_contexts": v4,
+                               "processor_api": bench.vr_processor_api(args.vr_budget)}
             del grids
             torch.cuda.empty_cache()
             sv = bench.survey(args.extras_survey_size)

@@ -70,8 +70,9 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
  *   "ragged_atlas"    1 (default): for ragged batches the fused layers walk a shelf-packed canvas of the grids (denser 8x16
  *                     blocks); 0: per-grid blocks                                                      [BGNN_NO_ATLAS]
  *   "features_tiled"  1 (default): node features / stencil table / edge attributes by the LDS-tiled kernel that computes the
- *                     float64 slope of an edge once for both of its directions (K = 8 / 16, 3 edge features); 0: the
- *                     thread-per-cell kernel (bit-identical results; the form the tiled one is tested against)
+ *                     float64 slope of an edge once for both of its directions (K = 8 / 16, 3 edge features) for uniform batches
+ *                     of tiles at least 64 cells wide; 0: always the thread-per-cell kernel (bit-identical results; the form the
+ *                     tiled one is tested against); 2: the tiled kernel for every shape (tests)
  * plus experiment / diagnostic knobs ("fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",
  * "diag_stamps", "gemm_diag" exist only in the diagnostic build of the library).  Unknown names -> BGNN_ERR_INVALID. */
 int bgnn_ctx_set_option(bgnn_ctx *ctx, const char *name, int value);

@@ -180,3 +180,49 @@ def test_config4_scale_stream_device_equals_loop(base, min_grids, gpu_device):
     for k in ("grids_processed", "cells_processed", "cells_classified_noise", "cells_corrected"):
         assert st_dev[k] == st_loop[k], k
     assert st_dev["cells_corrected"] > 0
+
+
+def test_pipelined_grid_loop_equals_the_synchronous_one(gpu_device):
+    """run_refinements with two batches in flight (submit_batch / collect_batch on two library contexts) writes the same
+    records, feeds the sink the same per-grid arrays in the same order and reports the same statistics as the reference-shaped
+    synchronous loop (one flush_batch per full batch); the submit / collect API itself keeps submission order and refuses a
+    third batch in flight."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import VRBagHandler
+    from bathymetric_gnn_amd.scripts.inference_native import run_refinements
+    proc = _processor(8)
+    proc.BATCH_NODE_BUDGET = 3000
+    md, ref = synthetic.synthetic_vr_bag(7, 8, seed=123, lo=3, hi=30, empty_fraction=0.1, sparse_fraction=0.05)
+    h = VRBagHandler.from_arrays(md, ref)
+    runs = {}
+    for mode in (False, True):
+        w = h.copy_and_open_for_writing()
+        order, sink = [], {}
+        st = run_refinements(proc, h, w, 0.0, pipelined=mode,
+                             results_sink=lambda g, a, b, c: (order.append(g.start_index), sink.__setitem__(g.start_index, (a.copy(), b.copy(), c.copy()))))
+        runs[mode] = (w.refinements.copy(), st, order, sink)
+        assert proc.batches_in_flight == 0
+    assert len(proc._engines) == 2                                        # the second context was really used
+    a, b = runs[False], runs[True]
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert a[2] == b[2] and len(a[2]) > 30
+    for k in a[1]:
+        assert a[1][k] == b[1][k], k
+    for s0 in a[3]:
+        for x, y in zip(a[3][s0], b[3][s0]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    # the API: order of collection = order of submission; at most two in flight
+    grids = synthetic.vr_grid_stream(9, seed0=900)
+    single = [proc.process_grid(d, u, r) for d, u, r in grids]
+    for lo in (0, 3, 6):
+        for d, u, r in grids[lo:lo + 3]:
+            assert proc.add_to_batch(d, u, r) is None
+        if lo < 6:
+            assert proc.submit_batch() == lo // 3 + 1
+    with pytest.raises(RuntimeError):
+        proc.submit_batch()                                              # a third batch in flight
+    got = proc.collect_batch() + proc.collect_batch()
+    got += proc.flush_batch()                                            # the queued third batch, synchronously
+    assert proc.collect_batch() == [] and len(got) == 9
+    for (c0, f0, r0), (c1, f1, r1) in zip(single, got):            # (same bar as the batched-vs-single comparison in test_gpu_forward)
+        assert np.array_equal(c0, c1) and np.abs(f0 - f1).max() < 1e-6 and np.abs(r0 - r1).max() < 1e-6
