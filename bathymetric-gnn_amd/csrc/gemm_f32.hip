@@ -65,7 +65,7 @@ __device__ __forceinline__ void stage_w(const float *Wt, float *dst, int kc, int
 template <int NT, bool ATT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
   constexpr int NC = NT * 32;
-  constexpr int WL = 2 * GEMM_KC * NC > 4 * 32 * 36 + 2 * NC ? 2 * GEMM_KC * NC : 4 * 32 * 36 + 2 * NC;   // also holds the store patches + att
+  constexpr int WL = 2 * GEMM_KC * NC > 4 * 32 * 36 + 3 * NC ? 2 * GEMM_KC * NC : 4 * 32 * 36 + 3 * NC;   // also holds the store patches + att + bias
   __shared__ float wl_[WL];
   float (*wl)[GEMM_KC * NC] = reinterpret_cast<float (*)[GEMM_KC * NC]>(wl_);
   const int64_t M = *a.d_m;
@@ -133,8 +133,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
   // heads at the end); att_src | att_dst sit in LDS behind the patches.
   __syncthreads();                                   // every wave is past its last read of wl
   float *attl = wl_ + 4 * 32 * 36;
-  if (ATT) {
-    for (int i = threadIdx.x; i < NC; i += 256) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
+  float *biasl = attl + 2 * NC;                      // the bias too: a global load per tile would queue behind the row stores (vmcnt is in order)
+  if (ATT || a.bias) {
+    if (ATT)
+      for (int i = threadIdx.x; i < NC; i += 256) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
+    if (a.bias)
+      for (int i = threadIdx.x; i < NC; i += 256) biasl[i] = a.bias[i];
     __syncthreads();
   }
   float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
       for (int g = 0; g < 4; ++g) {
         v[g] = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
         if (a.bias) {
-          const float4 b = *reinterpret_cast<const float4 *>(a.bias + t * 32 + 8 * g + 4 * h);
+          const float4 b = *reinterpret_cast<const float4 *>(biasl + t * 32 + 8 * g + 4 * h);
           v[g].x += b.x; v[g].y += b.y; v[g].z += b.z; v[g].w += b.w;
         }
         if (a.relu) {
@@ -254,6 +258,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   float *patches = wl + WFLOATS;                     // [8][32 * PP]
   float *attl = patches + 8 * 32 * PP;               // [2][NC]
   float *b0l = attl + 2 * NC;                        // [64]  (FRONT)
+  // The output bias lives in LDS as well: read from global memory inside the epilogue, each of its 32 float4 loads per block
+  // sat -- vmcnt counts loads and stores in one in-order queue on gfx9 -- behind the row stores of the tile pair before it, so
+  // the epilogue advanced at the pace of HBM write latency (~1 ms of the 3.2 ms launch).
+  float *biasl = b0l + 64;                           // [NC]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int NW = blockDim.x >> 6;                    // 8 (4 only in the occupancy experiment)
@@ -269,6 +277,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     if (ATT)
       for (int i = threadIdx.x; i < NC; i += blockDim.x) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
     if (FRONT && threadIdx.x < 64) b0l[threadIdx.x] = a.b0[threadIdx.x];
+    if (a.bias)
+      for (int i = threadIdx.x; i < NC; i += blockDim.x) biasl[i] = a.bias[i];
   }
   __syncthreads();                                   // (vmcnt(0): W has landed)
   const int64_t M = *a.d_m;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
       for (int g = 0; g < 4; ++g) {
         v[g] = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
         if (a.bias) {
-          const float4 b = *reinterpret_cast<const float4 *>(a.bias + t * 32 + 8 * g + 4 * h);
+          const float4 b = *reinterpret_cast<const float4 *>(biasl + t * 32 + 8 * g + 4 * h);
           v[g].x += b.x; v[g].y += b.y; v[g].z += b.z; v[g].w += b.w;
         }
         if (a.relu) {
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 
 template <int NT, bool ATT, int SP = 0, bool FRONT = false>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
-  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + 8 * 32 * 68 + 2 * NT * 32 + 64) * 4;
+  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + 8 * 32 * 68 + 2 * NT * 32 + 64 + NT * 32) * 4;
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
   auto kern = gemm_wres64_kernel<NT, ATT, SP, FRONT>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
