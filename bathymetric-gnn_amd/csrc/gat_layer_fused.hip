@@ -1126,6 +1126,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       sr += __shfl_xor(sr, 32);
       const int gr = pos.r0 + mr, gc = pos.c0 + mc;
       const bool inside = gr < pos.h && gc < pos.w;
+      // (loaded BEFORE the first output store: vmcnt is one in-order queue for loads and stores, so a load issued after the
+      //  logits / probabilities have been stored waits for HBM to take them)
+      float sd_pre = 0.0f;
+      if (hl == 0 && id >= 0 && a.has_corr && a.corr_grid) sd_pre = a.local_std[id];
       if (hl == 0 && inside && (!a.cell_map || id >= 0)) {
         // (canvas walk: only valid cells have an original position; the caller cleared the grids)
         const int64_t cidx = a.cell_map ? (int64_t)a.cell_map[id] : pos.cell_off + (int64_t)gr * pos.w + gc;
@@ -1165,7 +1169,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
           if (a.o.auto_correct) a.o.auto_correct[n] = action == 1;
           fcls = (float)arg; fconf = conf;
           if (a.has_corr && a.corr_grid) {
-            float sd = a.local_std[n];
+            float sd = sd_pre;
             sd = sd > a.norm_floor ? sd : a.norm_floor;
             fcorr = corr * sd;
           }

@@ -689,7 +689,20 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
       }
       __syncthreads();
       // ---- pass 2: node features, stencil row, edge attributes -------------------------------------------------------------------
-#pragma unroll 1
+      // (the per-cell global operands of BOTH cells of this thread are fetched before the first cell's rows are stored: loads and
+      //  stores share one in-order vmcnt queue, a load issued behind the stores would wait for HBM to take them)
+      float g_lstd[CR * CW / 256], g_lmean[CR * CW / 256], g_unc[CR * CW / 256];
+#pragma unroll
+      for (int k = 0; k < CR * CW / 256; ++k) {
+        const int li = tid + 256 * k, lr = li / CW, lc = li % CW;
+        g_lstd[k] = g_lmean[k] = g_unc[k] = 0.0f;
+        if (lr < rows && lc < cols && s_nid[(lr + R) * SW + lc + R] >= 0) {
+          const int64_t gi = tb + (int64_t)(rr0 + lr) * w + c0 + lc;
+          g_lstd[k] = a.local_std[gi]; g_lmean[k] = a.local_mean[gi];
+          if (a.unc) g_unc[k] = a.unc[gi];
+        }
+      }
+#pragma unroll
       for (int k = 0; k < CR * CW / 256; ++k) {
         const int li = tid + 256 * k, lr = li / CW, lc = li % CW;
         const int si = (lr + R) * SW + lc + R;
@@ -697,7 +710,6 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
         const int id = s_nid[si];
         if (id < 0) continue;
         const int r = rr0 + lr, c = c0 + lc;
-        const int64_t idx = tb + (int64_t)r * w + c;
         const float f0 = s_fill[si];
         float gy, gx;
         if (r == 0) gy = s_fill[si + SW] - f0;
@@ -719,17 +731,17 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
 #pragma unroll
           for (int dc = -1; dc <= 1; ++dc) cnt += s_nid[si + dr * SW + dc] >= 0 ? 1 : 0;    // (outside the tile: staged as -1)
         if (cnt < 3) lap = 0.0f;
-        const float lstd = a.local_std[idx];
+        const float lstd = g_lstd[k];
         const float dz_tgt = s_depth[si];
         float cand[8];
         cand[BGNN_NF_DEPTH] = dz_tgt;
-        cand[BGNN_NF_LOCAL_MEAN] = a.local_mean[idx];
+        cand[BGNN_NF_LOCAL_MEAN] = g_lmean[k];
         cand[BGNN_NF_LOCAL_STD] = lstd;
         cand[BGNN_NF_GRADIENT_X] = gx;
         cand[BGNN_NF_GRADIENT_Y] = gy;
         cand[BGNN_NF_GRADIENT_MAGNITUDE] = gmag;
         cand[BGNN_NF_CURVATURE] = lap;
-        cand[BGNN_NF_UNCERTAINTY] = a.unc ? a.unc[idx] : 0.0f;
+        cand[BGNN_NF_UNCERTAINTY] = a.unc ? g_unc[k] : 0.0f;
         float xo[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
