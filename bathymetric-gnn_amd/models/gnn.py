@@ -198,9 +198,8 @@ class BathymetricGNN(nn.Module):
                  heads: int = 4, num_classes: int = 3, predict_correction: bool = True, dropout: float = 0.1,
                  edge_dim: Optional[int] = None):
         super().__init__()
-        if edge_dim is None and gnn_type == "GAT":
-            raise NotImplementedError("edge_dim=None (GATConv without edge features) is outside the built path; "
-                                      "the reference always passes edge_dim=3")
+        # edge_dim=None (the signature's default, models/gnn.py:93,130,291): GATConv then has no lin_edge / att_edge and the attention
+        # logit loses its edge term.  The kernels keep one code path: the folded edge vector V = att_edge . lin_edge is packed as zeros.
         self.gnn_type = gnn_type
         self.predict_correction = predict_correction
         self.num_classes = num_classes
@@ -222,7 +221,8 @@ class BathymetricGNN(nn.Module):
     def _desc(self) -> rt.ModelDesc:
         d = rt.ModelDesc()
         d.in_channels, d.hidden, d.num_layers = self.in_channels, self.hidden_channels, self.num_gnn_layers
-        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, (self.edge_dim or 0)
+        # (edge_dim=None: the library is told the graph builder's 3 edge features and gets zero edge weights for them)
+        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, (self.edge_dim if self.edge_dim is not None else 3)
         d.gnn_type = rt.GNN_TYPES[self.gnn_type]
         d.predict_correction = 1 if self.predict_correction else 0
         d.bn_eps = float(self.gnn.norms[0].module.eps)
@@ -238,8 +238,11 @@ class BathymetricGNN(nn.Module):
         for l in range(self.num_gnn_layers):
             c, n = f"gnn.convs.{l}.", f"gnn.norms.{l}.module."
             if self.gnn_type == "GAT":
-                parts += [sd[c + "lin.weight"], sd[c + "att_src"], sd[c + "att_dst"], sd[c + "att_edge"],
-                          sd[c + "lin_edge.weight"], sd[c + "bias"]]
+                if self.edge_dim is None:        # no edge term: zero att_edge / lin_edge over the builder's 3 edge features
+                    att_e, lin_e = np.zeros_like(sd[c + "att_src"]), np.zeros(sd[c + "att_src"].size * 3, np.float32)
+                else:
+                    att_e, lin_e = sd[c + "att_edge"], sd[c + "lin_edge.weight"]
+                parts += [sd[c + "lin.weight"], sd[c + "att_src"], sd[c + "att_dst"], att_e, lin_e, sd[c + "bias"]]
             elif self.gnn_type == "GCN":
                 parts += [sd[c + "lin.weight"], sd[c + "bias"]]
             elif self.gnn_type == "GraphSAGE":

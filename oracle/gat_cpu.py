@@ -60,8 +60,10 @@ def gat_conv(x, edge_index, edge_attr, sd: Mapping, prefix: str, concat: bool, d
     W = _lin_weight(sd, prefix, dtype)                    # [H*C, D]
     att_src = _t(sd[prefix + "att_src"], dtype)           # [1,H,C]
     att_dst = _t(sd[prefix + "att_dst"], dtype)
-    att_edge = _t(sd[prefix + "att_edge"], dtype)
-    W_e = _t(sd[prefix + "lin_edge.weight"], dtype)       # [H*C, edge_dim]
+    # edge_dim=None (models/gnn.py:93,130): no lin_edge / att_edge in the state dict -> the logit has no edge term
+    has_edge = (prefix + "att_edge") in sd
+    att_edge = _t(sd[prefix + "att_edge"], dtype) if has_edge else None
+    W_e = _t(sd[prefix + "lin_edge.weight"], dtype) if has_edge else None   # [H*C, edge_dim]
     bias = _t(sd[prefix + "bias"], dtype)
     H, C = att_src.shape[1], att_src.shape[2]
 
@@ -79,8 +81,11 @@ def gat_conv(x, edge_index, edge_attr, sd: Mapping, prefix: str, concat: bool, d
     ar = torch.arange(N, dtype=src.dtype)
     src2 = torch.cat([src, ar]); dst2 = torch.cat([dst, ar]); ea2 = torch.cat([ea, loop_attr], 0)
 
-    a_e = ((ea2 @ W_e.t()).view(-1, H, C) * att_edge).sum(-1)      # [E',H]
-    e = F.leaky_relu(a_s.index_select(0, src2) + a_d.index_select(0, dst2) + a_e, 0.2)
+    if has_edge:
+        a_e = ((ea2 @ W_e.t()).view(-1, H, C) * att_edge).sum(-1)      # [E',H]
+        e = F.leaky_relu(a_s.index_select(0, src2) + a_d.index_select(0, dst2) + a_e, 0.2)
+    else:
+        e = F.leaky_relu(a_s.index_select(0, src2) + a_d.index_select(0, dst2), 0.2)
     m = torch.full((N, H), float("-inf"), dtype=dtype)
     m = m.scatter_reduce(0, dst2.unsqueeze(-1).expand(-1, H), e, reduce="amax", include_self=True)
     p = torch.exp(e - m.index_select(0, dst2))

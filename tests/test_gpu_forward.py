@@ -919,3 +919,27 @@ def test_extra_contexts_are_released(gpu_device):
     free1 = torch.cuda.mem_get_info(gpu_device)[0]
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB not returned"
     assert torch.equal(TileBatchEngine(model, gb, gpu_device).infer_device(hw, res, d, m, u), ref)
+
+
+def test_edge_dim_none_gatconv_without_edge_features(gpu_device):
+    """BathymetricGNN(edge_dim=None) -- the signature's default (models/gnn.py:93,130,291): GATConv then holds no lin_edge / att_edge
+    and the attention logit is leaky_relu(a_src[j] + a_dst[i]) only.  The state dict has no edge keys (like torch_geometric's), the
+    library gets zero edge weights, and the result must match the oracle's edge-free statement within the usual 1e-4."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    d, m, _ = synthetic.synthetic_tile(48, 56, 31, "V1")
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    sd = {k: v for k, v in synthetic.synthetic_state_dict(seed=1234).items() if "lin_edge" not in k and "att_edge" not in k}
+    sd = calibrate_heads(sd, og.x, og.edge_index, og.edge_attr)
+    model = BathymetricGNN(in_channels=7, dropout=0.0)                   # edge_dim defaults to None
+    assert not any("lin_edge" in k or "att_edge" in k for k in model.state_dict())
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})        # strict: the key sets agree
+    model = model.to(torch.device("cuda:0")).eval()
+    out = model.predict(GraphBuilder().build_graph(d, m, None, (0.5, 0.5)))
+    ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+    _compare(out, ref)
+    # and the edge term matters: the same weights WITH the synthetic edge weights give different logits
+    sd3 = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
+    ref3 = gat_cpu.predict(sd3, og.x, og.edge_index, og.edge_attr)
+    assert (ref3["confidence"] - ref["confidence"]).abs().max().item() > 1e-3

@@ -51,8 +51,11 @@ def test_state_dict_keys_match_reference_names():
         ref = synthetic.synthetic_state_dict(gnn_type=kind, num_layers=2)
         assert sk == set(ref)
         mk.load_state_dict({k: torch.as_tensor(v) for k, v in ref.items()})
-    with pytest.raises(NotImplementedError):
-        BathymetricGNN(in_channels=7, gnn_type="GAT", edge_dim=None)
+    # edge_dim=None (the reference signature's default): GATConv without edge parameters, like torch_geometric's state dict
+    m0 = BathymetricGNN(in_channels=7, gnn_type="GAT", edge_dim=None)
+    k0 = set(m0.state_dict())
+    assert k0 == {k for k in set(synthetic.synthetic_state_dict()) if "lin_edge" not in k and "att_edge" not in k}
+    assert m0.pack_weights().size == m.pack_weights().size            # the library's layout is unchanged: zero edge weights are packed
     with pytest.raises(ValueError):
         BathymetricGNN(in_channels=7, gnn_type="Transformer", edge_dim=3)
 

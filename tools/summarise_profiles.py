@@ -67,6 +67,8 @@ def main():
 
     for src_name, dst_name in (("bench_fused", "bench_fused"), ("bench_unfused", "bench_unfused"), ("bench_split", "bench_split"),
                                ("bench_split_f16", "bench_split_f16"), ("bench_vr_50k", "bench_vr_budget50k"),
+                               ("bench_vr_50k_1ctx", "bench_vr_budget50k_1ctx"), ("bench_vr_50k_2ctx", "bench_vr_budget50k_2ctx"),
+                               ("bench_survey_20000", "bench_survey_20000"),
                                ("bench_vr_1M", "bench_vr_budget1M"), ("bench_c3", "bench_c3_k16_bf16"), ("bench_bf16_k8", "bench_bf16_k8")):
         p = os.path.join(a.src, src_name + ".json")
         if os.path.exists(p):
@@ -90,12 +92,12 @@ def main():
                                     "fetch_bytes_per_launch_x2_corrected": 2.0 * fb, "write_bytes_per_launch": wb,
                                     "hbm_bytes_per_launch": 2.0 * fb + wb}
             cls = re.sub(r"<.*$", "", k)
-            if cls == "gemm_wres64_kernel":
-                cls = "gemm_f32_kernel"          # the W-resident form of the same kernel class (bench key "gemm")
+            if cls == "features_tiled_kernel":
+                cls = "features_kernel"          # the LDS-tiled form of the same kernel class (bench key "features")
             cls_acc[cls][0] += (2.0 * fb + wb) * n
             cls_acc[cls][1] += n
         for cls, (tot, n) in cls_acc.items():
-            if cls in ("gat_layer_fused_kernel", "gat_aggregate_tiled_kernel", "gemm_f32_kernel", "features_kernel"):
+            if cls in ("gat_layer_fused_kernel", "gat_aggregate_tiled_kernel", "gemm_f32_kernel", "gemm_wres64_kernel", "features_kernel"):
                 key = cls if mode not in ("split", "c3") else cls + ":" + mode
                 if mode == "unfused" and cls != "gat_aggregate_tiled_kernel":
                     continue
