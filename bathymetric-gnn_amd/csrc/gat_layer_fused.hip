@@ -485,9 +485,18 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   // DOUBLE-BUFFERED -- slab s + 1 is requested as soon as slab s is visible, a whole slab period ahead, instead of after slab s has
   // been gathered (half a period ahead: with no matrix work to hide under, ~17 % of that instance's lifetime was spent waiting
   // for it).  Paid for by aliasing (alpha_src table and halo ids inside the alpha region, att vectors parked in the free buffer).
-  static constexpr bool DBUF = SP == 3 && NT == 8 && EPI == EPI_NEXT;
+  // RING selects how the bf16 256 -> 256 instance spends its spare LDS (it runs two workgroups per CU whatever the LDS: 128 accumulator
+  // registers decide).  1: two slab images (above).  2: two FULL 32-row W chunks instead of two 16-row halves -- chunk s + 1 is
+  // requested a whole slab ahead and nothing is restaged inside a slab, so a slab needs TWO barriers instead of five.  The per-phase
+  // timers had put ~30 % of that instance's lifetime at barriers, and doubling the slab's lead (RING 1) did not shorten them: the
+  // time is barrier skew between the four waves (each shares its SIMD with a wave of the other workgroup), not DMA latency.
+  // Measured (configs[2], 128 tiles): RING 0 10.29 ms of fused time per step, RING 1 10.06-10.19, RING 2 10.03 (two spilled registers at
+  // k = 16) -- within noise of each other: neither the slab's lead nor the number of barriers is what bounds this instance.
+  // RING 1 ships (no spills).
+  static constexpr int RING = SP == 3 && NT == 8 && EPI == EPI_NEXT ? 1 : 0;
+  static constexpr bool DBUF = RING == 1, WDB = RING == 2;
   static constexpr int SLAB = DBUF ? 2 * SLAB1 : SLAB1;
-  static constexpr int WBUF = 2 * WHalf<NT, SP>::BYTES / 4;
+  static constexpr int WBUF = (WDB ? 4 : 2) * WHalf<NT, SP>::BYTES / 4;
   // the epilogue's four wave-private 32 x 36 store patches reuse slab (+ wbuf)
   static constexpr int PATCH_PAD = EPI == EPI_NEXT && SLAB + WBUF < 4 * 32 * TILED_PITCH ? 4 * 32 * TILED_PITCH - SLAB - WBUF : 0;
   static constexpr int HEADW = 96 + 6 * 32 + 8;          // heads: first-layer biases | second-layer rows (<= 4 classes + 2) | their biases
@@ -496,8 +505,9 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   //  * the heads' small weight table (final epilogue only) is parked in the slab region once the last slab has been gathered.
   //  * DBUF: the halo ids live there as well (the epilogue takes its row ids from the lanes' own registers), and the next layer's
   //    att vectors are DMA'd into the free slab buffer during the last slab.
-  static constexpr bool HAS_IN_ALPHA = SP == 3, HEADW_LATE = SP == 3 && EPI == EPI_HEADS, HID_IN_ALPHA = DBUF, ATT_LATE = DBUF;
+  static constexpr bool HAS_IN_ALPHA = SP == 3, HEADW_LATE = SP == 3 && EPI == EPI_HEADS, HID_IN_ALPHA = DBUF || WDB, ATT_LATE = DBUF || WDB;
   // (floats) past the four store patches, which start at image A, and past the 8 rows (128 floats) image A's last MFMA over-reads
+  // (WDB: at the same offset from the slab image, i.e. inside W chunk buffer 0, which the last -- odd -- slab does not use)
   static constexpr int ATT_OFF = SLAB1 + 128 > 4 * 32 * TILED_PITCH ? SLAB1 + 128 : 4 * 32 * TILED_PITCH;
   static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? (ATT_LATE ? 0 : 2 * NC) : HEADW_LATE ? 0 : HEADW);
   static constexpr int RSZ = RA > RB ? RA : RB;
@@ -507,6 +517,7 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int ALPHA = SP == 3 ? 4 * 32 * AggWindow<K>::PITCH / 4 : 128 * APITCH;
   static_assert(!HAS_IN_ALPHA || HR * H + (HID_IN_ALPHA ? HR : 0) <= ALPHA, "the alpha_src table (and the halo ids) fit the dense-alpha region");
   static_assert(!DBUF || (4 * 32 * TILED_PITCH <= ATT_OFF && ATT_OFF + 2 * NC <= SLAB), "patches | att vectors share the slab region");
+  static_assert(!WDB || (4 * 32 * TILED_PITCH <= ATT_OFF && ATT_OFF + 2 * NC <= SLAB + WBUF / 2), "patches | att vectors fit slab + W chunk buffer 0");
   static_assert(!HEADW_LATE || HEADW <= SLAB, "the heads' weight table fits the slab region");
   static_assert(SP != 3 || !AggWindow<K>::TAIL_BEYOND_PITCH || WBUF * 4 >= 8 * 64, "the 8 rows read past the slab image stay inside the W buffer");
   // (HID_IN_ALPHA: the epilogue's row ids come from a compact [128 cells] table instead of the halo table)
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // DBUF: two slab images.  EVEN slabs use the upper one (B, next to the W buffer), odd slabs the lower one (A): the k = 16
   // window's last MFMA reads 8 rows past its image (AggWindow) -- past B that is the W buffer's head, past A it is B's head,
   // which by then holds rows of an even slab (landed, or being replaced by the next one's): finite bf16 either way.
-  constexpr bool DBUF = Lds::DBUF;
+  constexpr bool DBUF = Lds::DBUF, WDB = Lds::WDB;
   constexpr int SLAB1B = Lds::SLAB1 * 4;                 // bytes of one slab image
   // Region R is time-shared: alpha_src of the halo rows during phase A, then (from the first slab barrier on)
   // the folded scale / shift table and, behind it, the next layer's att_src | att_dst for the epilogue.
@@ -570,6 +581,20 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // W rows of slab 0 depend on nothing: first in the VM queue.
   stage_w_half<NT, SP>(a.Wt, wbuf, 0, wave, lane);
   stage_w_half<NT, SP>(a.Wt, wbuf, 1, wave, lane);
+  // WDB: W chunk c (both halves, 2 x BYTES contiguous bytes of the image) lives in chunk buffer c & 1; chunk 1 can go now as well
+  auto stage_w_chunk = [&](int c) {
+    using G = WHalf<NT, SP>;
+    const char *src = reinterpret_cast<const char *>(a.Wt) + (int64_t)c * 2 * G::BYTES;
+    float *dst = wbuf + (c & 1) * (2 * G::BYTES / 4);
+#pragma unroll
+    for (int j = 0; j < (2 * G::NQ + 3) / 4; ++j) {
+      const int q = j * 4 + wave;
+      if (q < 2 * G::NQ)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(dst + q * 256), 16, 0, 0);
+    }
+  };
+  if constexpr (WDB) { if (NSLAB > 1) stage_w_chunk(1); }
 
   // Prologue loads, two dependent rounds with everything of a round in flight together:
   //   round 1: node id of this thread's halo row (HR <= NTH: one row per thread), of this lane's own cell, and of
@@ -856,7 +881,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       if constexpr (SP == 3) {
         if (s % SPH == 0 && s > 0) densify(s / SPH);
       }
-      if (s == 0) wait_vm_lgkm<0>();                    // (slab 0 was queued BEHIND its W rows: wait for everything)
+      if (s == 0 || WDB) wait_vm_lgkm<0>();             // (slab 0 was queued BEHIND its W rows: wait for everything; WDB: slab s and
+                                                        //  W chunk s are all this wave has in flight)
       else if (WREM && wextra) wait_vm_lgkm<2 * (WH + 1)>();
       else wait_vm_lgkm<2 * WH>();
       __builtin_amdgcn_s_barrier();                     // slab s visible to every wave
@@ -883,7 +909,17 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       }
       // DBUF: slab s is visible and the other image was released a slab ago -> request slab s + 1 NOW (VM queue: [WA s][WB s][slab s+1])
       if (DBUF && s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
-      if constexpr (Lds::ATT_LATE) {
+      // WDB: every wave is past the MFMAs of slab s - 1, so chunk buffer (s + 1) & 1 is free: request W chunk s + 1 (chunk 1 went in the prologue)
+      if constexpr (WDB) { if (s >= 1 && s + 1 < NSLAB && !DBG(8)) stage_w_chunk(s + 1); }
+      if constexpr (Lds::ATT_LATE && WDB) {
+        // last slab (odd: it multiplies out of chunk buffer 1): chunk buffer 0 takes the next layer's att_src | att_dst, past the store
+        // patches' reach; the __syncthreads in front of the final epilogue waits for it
+        static_assert(!WDB || (NSLAB % 2 == 0 && NC * 4 == 1024), "the last slab uses chunk buffer 1; one 1-KiB piece per vector");
+        if (s + 1 == NSLAB && wave < 2)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>((wave == 0 ? a.att_src : a.att_dst) + lane * 4),
+                                           (__attribute__((address_space(3))) void *)(attr + wave * NC), 16, 0, 0);
+      }
+      if constexpr (Lds::ATT_LATE && DBUF) {
         // last slab: the free image (B: the last slab is odd) takes the next layer's att_src | att_dst.  EVERY wave issues one
         // piece (waves 2, 3 repeat 0, 1's) so that the counted wait below is the same on all of them.
         static_assert(!Lds::ATT_LATE || (NSLAB % 2 == 0 && NC * 4 == 1024), "the last slab uses image A; one 1-KiB piece per vector");
@@ -951,7 +987,9 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         }
       }
       BGNN_STAMP(4)   // gather + layer epilogue
-      if constexpr (DBUF) {
+      if constexpr (WDB) {
+        wait_lgkm0();                                   // (W chunk s landed with the wait at the top of the slab)
+      } else if constexpr (DBUF) {
         // WA(s) landed; behind it in the queue: WB(s) and the npc pieces of slab s + 1 (last slab: the att piece)
         static_assert(!DBUF || WREM == 0, "DBUF instances deal the W pieces evenly");
         if (DBG(4)) wait_vm_lgkm<0>();
@@ -963,7 +1001,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       }
       __builtin_amdgcn_s_barrier();                     // every wave has finished reading slab s
       BGNN_STAMP(5)   // wait for WA + barrier
-      if (!DBUF && s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);
+      if (!DBUF && s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);     // (WDB too: single slab image)
       if constexpr (Lds::HEADW_LATE) {
         // last slab gathered by every wave: its region now takes the heads' weight table (registers since the prologue); the two
         // barriers between here and the final epilogue publish it
@@ -979,6 +1017,16 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       LP8 xh0, xl0, xh1, xl1;
       if constexpr (SP == 1 || SP == 2) { split_lp<LP8, LPE>(g[0], g[1], xh0, xl0); split_lp<LP8, LPE>(g[2], g[3], xh1, xl1); }
       if constexpr (SP == 3) { xh0 = to_bf16x8(g[0], g[1]); xh1 = to_bf16x8(g[2], g[3]); }
+      if constexpr (WDB) {
+        // both halves out of chunk buffer s & 1, nothing restaged, no barrier until the next slab's top
+        const uint32_t cb = wsp0 + (uint32_t)(s & 1) * (2 * WHALF);
+        if (!DBG(2)) {
+          Bf16Tiles<NT, 0>::run(acc, xh0, cb);
+          Bf16Tiles<NT, 0>::run(acc, xh1, cb + WHALF);
+        }
+        BGNN_STAMP(6)   // MFMA
+        continue;
+      }
       if (!DBG(2)) {
         if constexpr (SP == 3) Bf16Tiles<NT, 0>::run(acc, xh0, wsp0);
         else if constexpr (SP != 0) SplitTiles<NT, 0, LP8>::run(acc, xh0, xl0, wsp0);
