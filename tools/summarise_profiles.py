@@ -30,9 +30,18 @@ def short(name):
     return re.sub(r"\(.*\)$", "", name)
 
 
+def newest(files, window_s=3600):
+    """gpurun MERGES a run's output into the local gpurun_out/: files of an earlier round's run may sit beside the new ones.
+    Only the files of the most recent run (modified within an hour of the newest one) are summarised."""
+    if not files:
+        return files
+    t = max(os.path.getmtime(f) for f in files)
+    return sorted((f for f in files if os.path.getmtime(f) >= t - window_s), key=os.path.getmtime, reverse=True)
+
+
 def per_launch(counter_dir, counter):
     """kernel -> [(grid, KiB)] from one --pmc pass (one row per dispatch and counter; rows of one dispatch are summed)"""
-    files = glob.glob(os.path.join(counter_dir, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(glob.glob(os.path.join(counter_dir, "**", "*counter_collection.csv"), recursive=True))
     by_dispatch = defaultdict(float)
     meta = {}
     for f in files:
@@ -78,7 +87,7 @@ def main():
     all_k, classes = {}, {}
     for mode, label in (("fused", "fused, exact f32"), ("unfused", "unfused"), ("split", "fused, bf16x3"),
                         ("c3", "fused, k=16, bf16 storage (BASELINE configs[2])")):
-        st = glob.glob(os.path.join(a.src, f"{mode}_stats", "**", "*kernel_stats.csv"), recursive=True)
+        st = newest(glob.glob(os.path.join(a.src, f"{mode}_stats", "**", "*kernel_stats.csv"), recursive=True))
         if st:
             shutil.copy(st[0], os.path.join(dst, f"{tag}_{mode}_kernel_stats.csv"))
         fetch = per_launch(os.path.join(a.src, f"{mode}_fetch"), "FETCH_SIZE")
