@@ -653,7 +653,7 @@ def test_training_mode_refusals(gpu_device):
 # Neither exists in the reference (config/config.py:221-222 validates 4 / 8-connected only; everything is float32), so there
 # is no reference-held vector: edge_index / features are checked against the oracle's identical extension, the forward
 # against the oracle's float64 forward.  bf16 storage has NO 1e-4 contract: the achieved error is printed and bounded.
-BF16_LOGIT_BOUND = 3e-2        # absolute, on |logit| <= ~0.4 (calibrated heads); observed values are printed by the test
+BF16_LOGIT_BOUND = 2e-2        # absolute, on |logit| <= ~0.25 (calibrated heads); observed 1.5e-2 max / 3.2e-3 rms (k = 16), 1.6e-2 / 3.5e-3 (k = 8): profiles/r03_config3_accuracy_*.json
 
 
 def _fp64_distance(out, ref64):
