@@ -610,20 +610,40 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // afterwards), so nothing is exec-masked, no branch separates the loads and the compiler keeps all of them in flight behind
   // a single wait.  (With `if (inside) id = node_id[..]` per load, hipcc waited for the halo row's id, then for the own cell's,
   // then for the DMA rows': three dependent trips to L2 before round 2 could start.)
-  auto cell_index = [&](int gr, int gc) -> int64_t {
-    gr = gr < 0 ? 0 : gr >= pos.h ? pos.h - 1 : gr;
-    gc = gc < 0 ? 0 : gc >= pos.w ? pos.w - 1 : gc;
-    return pos.cell_off + (int64_t)gr * pos.w + gc;
+  // (Integer work is kept short on purpose: on the exact path this wave's SIMD partners stream f32 MFMAs, and every VALU
+  //  instruction of the prologue waits for a gap between two of them -- ~50-100 cycles each by the per-phase timers.  Cell indices
+  //  are 32-bit (a batch has < 2^30 cells), the node-id table is addressed base + 32-bit offset, the DMA pieces' halo rows advance
+  //  by a constant step instead of being divided out, and validity is one unsigned compare per coordinate.)
+  const uint32_t cbase = (uint32_t)pos.cell_off, uw = (uint32_t)pos.w, uh = (uint32_t)pos.h;
+  const int h1 = pos.h - 1, w1 = pos.w - 1;
+  auto cell_index = [&](int gr, int gc) -> uint32_t {    // clamped into the tile: always a readable cell
+    const int r_ = max(0, min(gr, h1)), c_ = max(0, min(gc, w1));
+    return cbase + __umul24((uint32_t)r_, uw) + (uint32_t)c_;      // (r, w < 2^14)
   };
-  const int gr_h = pos.r0 + tid / HW_ - RAD, gc_h = pos.c0 + tid % HW_ - RAD;
+  // node id of a cell: table base (uniform) + 32-bit BYTE offset -> the load's saddr + voffset form, no 64-bit address arithmetic
+  auto node_at = [&](uint32_t cell) -> int {
+    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.node_id) + (cell << 2));
+  };
+  auto in_tile = [&](int gr, int gc) -> bool { return (uint32_t)gr < uh && (uint32_t)gc < uw; };
+  const int hr_t = tid / HW_, hc_t = tid - hr_t * HW_;
+  const int gr_h = pos.r0 + hr_t - RAD, gc_h = pos.c0 + hc_t - RAD;
   const int gr_m = pos.r0 + tr, gc_m = pos.c0 + tc;
-  const int raw_h = a.node_id[cell_index(gr_h, gc_h)];
-  const int raw_m = a.node_id[cell_index(gr_m, gc_m)];
-  int drow[NPIECE];
+  const int raw_h = node_at(cell_index(gr_h, gc_h));
+  const int raw_m = node_at(cell_index(gr_m, gc_m));
+  // DMA piece p moves chunk (p * NTH + tid) % CPR of halo row (p * NTH + tid) / CPR: the row advances by NTH / CPR per piece
+  static_assert(NTH % CPR == 0, "pieces advance by whole halo rows");
+  constexpr int RSTEP = NTH / CPR, RSTEP_R = RSTEP / HW_, RSTEP_C = RSTEP % HW_;
+  int drow[NPIECE], prow_r[NPIECE], prow_c[NPIECE];
+  {
+    const int row0 = tid / CPR;
+    int pr = row0 / HW_, pc = row0 - pr * HW_;
 #pragma unroll
-  for (int p = 0; p < NPIECE; ++p) {
-    const int row = (p * NTH + tid) / CPR;
-    drow[p] = a.node_id[cell_index(pos.r0 + row / HW_ - RAD, pos.c0 + row % HW_ - RAD)];
+    for (int p = 0; p < NPIECE; ++p) {
+      prow_r[p] = pr; prow_c[p] = pc;
+      drow[p] = node_at(cell_index(pos.r0 + pr - RAD, pos.c0 + pc - RAD));
+      pr += RSTEP_R; pc += RSTEP_C;
+      if (pc >= HW_) { pc -= HW_; pr += 1; }
+    }
   }
   constexpr int NSC = (HC + NTH - 1) / NTH;
   float scv[NSC], shv[NSC];                             // folded scale / shift: to LDS once phase A has released R
@@ -654,14 +674,13 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   }
   BGNN_STAMP(9)    // block decode, address arithmetic, round 1 requested
   // validity (ids < 0 in the table encode invalid cells)
-  int hid_v = (tid < HR && gr_h >= 0 && gr_h < pos.h && gc_h >= 0 && gc_h < pos.w && raw_h >= 0) ? raw_h : -1;
-  int my_pre = (!DBG(32) && gr_m < pos.h && gc_m < pos.w) ? raw_m : -1;
+  int hid_v = (tid < HR && in_tile(gr_h, gc_h) && raw_h >= 0) ? raw_h : -1;
+  int my_pre = (!DBG(32) && in_tile(gr_m, gc_m)) ? raw_m : -1;
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) {
     // (measured with ids COMPUTED instead of loaded, all-valid tiles: 0.3 % (exact) / 2 % (bf16) -- the id round is already hidden)
-    const int row = (p * NTH + tid) / CPR;
-    const int gr = pos.r0 + row / HW_ - RAD, gc = pos.c0 + row % HW_ - RAD;
-    if (!(row < HR && gr >= 0 && gr < pos.h && gc >= 0 && gc < pos.w)) drow[p] = -1;
+    const bool row_ok = (p + 1) * NTH <= HR * CPR || prow_r[p] < FT_H + 2 * RAD;       // rows past the halo: last piece only
+    if (!(row_ok && in_tile(pos.r0 + prow_r[p] - RAD, pos.c0 + prow_c[p] - RAD))) drow[p] = -1;
   }
 #if BGNN_DIAG
   if (a.stamps) asm volatile("" ::"v"(hid_v), "v"(my_pre), "v"(drow[0]));
@@ -682,7 +701,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // rows without a node read row 0 and are masked afterwards.
   float eraw[K * 3], adv[NHL], hasv[H];
   {
-    const int64_t hrow = hid_v >= 0 ? hid_v : 0, mrow = my_pre >= 0 ? my_pre : 0;
+    const uint64_t hrow = (uint32_t)(hid_v >= 0 ? hid_v : 0), mrow = (uint32_t)(my_pre >= 0 ? my_pre : 0);   // (zero-extended: one v_mad_u64_u32 each)
     if constexpr (H % 4 == 0) {
 #pragma unroll
       for (int q = 0; q < H / 4; ++q) {
@@ -711,27 +730,23 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // 16 distinct 16-byte bank groups).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
   // offsets (32 bits, relative to the smallest node id this WAVE touches) are computed once.
   auto swz = [](int row) { return XB == 4 ? (row >> 1) & 7 : (row >> 2) & 3; };
-  int id0;
-  {
-    int m = 0x7fffffff;
-#pragma unroll
-    for (int p = 0; p < NPIECE; ++p) if (drow[p] >= 0 && drow[p] < m) m = drow[p];
-#pragma unroll
-    for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o));
-    id0 = __builtin_amdgcn_readfirstlane(m);             // 0x7fffffff: the wave's rows hold no node
-  }
-  // Per piece ONE 64-bit source base for the whole block: rows without a node read the context's zero page, which holds
-  // more than NSLAB * ROWB zero bytes, so that they can advance by ROWB per slab exactly like real rows (no per-slab select)
-  // and EVERY wave issues a fixed number of slab pieces (npc): the counted waits below can leave exactly the next slab in flight.
+  // Per piece ONE 64-bit source base for the whole block (a single 32 x 32 -> 64-bit multiply-add off the table's base; an earlier
+  // version kept 32-bit offsets relative to the smallest id of the wave, which cost a six-step wave reduction per block): rows
+  // without a node read the context's zero page, which holds more than NSLAB * ROWB zero bytes, so that they can advance by ROWB
+  // per slab exactly like real rows (no per-slab select) and EVERY wave issues a fixed number of slab pieces (npc): the counted
+  // waits below can leave exactly the next slab in flight.
   static_assert(NSLAB * ROWB <= 4096, "the zero page covers a whole block's worth of slab offsets");
-  const char *xbase = reinterpret_cast<const char *>(a.xw) + (int64_t)(id0 == 0x7fffffff ? 0 : id0) * (HC * XB);
+  const char *xbase = reinterpret_cast<const char *>(a.xw);
   const char *zp = reinterpret_cast<const char *>(a.zero_page);
   const char *dbase[NPIECE];
+  {
+    const int cc = tid % CPR;
 #pragma unroll
-  for (int p = 0; p < NPIECE; ++p) {
-    const int idx = p * NTH + tid;
-    const int row = idx / CPR, c = (idx % CPR) ^ swz(row);
-    dbase[p] = drow[p] >= 0 ? xbase + ((uint32_t)(drow[p] - id0) * (uint32_t)(HC * XB) + (uint32_t)(c * 16)) : zp;
+    for (int p = 0; p < NPIECE; ++p) {
+      const int row = prow_r[p] * HW_ + prow_c[p];
+      const int c = cc ^ swz(row);
+      dbase[p] = drow[p] >= 0 ? xbase + ((uint64_t)(uint32_t)drow[p] * (uint32_t)(HC * XB) + (uint32_t)(c * 16)) : zp;
+    }
   }
   int npc = 0;
 #pragma unroll
