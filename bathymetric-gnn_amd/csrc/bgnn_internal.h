@@ -192,6 +192,10 @@ struct bgnn_graph {
   float *d_x8 = nullptr;              // [rows][8]
   float *d_local_std = nullptr;       // [rows]
   int32_t *d_nbr = nullptr;           // grid: [rows][K] ; generic: col[E]
+  // grid graphs: the stencil id table is built ON DEMAND (ensure_stencil_table): the fused layer kernels never read it -- only
+  // the export, the edge counts, the generic aggregate and the non-attention backbones do -- and writing it was 32 (k = 8) / 64
+  // (k = 16) of the feature kernel's 188 / 380 bytes per node
+  mutable bool nbr_valid = false;
   float *d_eattr = nullptr;           // grid: [rows][K][ED] ; generic: [E][ED]
   int32_t *d_rowptr = nullptr;        // generic only [N+1]
   int32_t *d_edge_perm = nullptr;     // generic only
@@ -235,6 +239,7 @@ struct ProfScope {
 int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts);
 int launch_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edge_attr, float *pos,
                         int64_t *valid_rows, int64_t *valid_cols, float *local_std, int64_t *batch);
+int ensure_stencil_table(const bgnn_graph *g);     // builds d_nbr of a grid graph if it has not been built yet (stream-ordered)
 int launch_graph_count_edges(bgnn_graph *g);
 int launch_graph_scatter(bgnn_graph *g, const float *node_values, float fill, float *grid);
 int launch_results_to_grids(bgnn_graph *g, const int64_t *cls, const float *conf, const float *corr,

@@ -585,8 +585,10 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
           edge_slot(half * 8 + b, sids[b], ev);
           evs[3 * b] = ev[0]; evs[3 * b + 1] = ev[1]; evs[3 * b + 2] = ev[2];
         }
+        if (a.nbr) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+          for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+        }
 #pragma unroll
         for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
       }
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
         int sid;
         float ev[4];
         edge_slot(b, sid, ev);
-        a.nbr[(int64_t)id * st.K + b] = sid;
+        if (a.nbr) a.nbr[(int64_t)id * st.K + b] = sid;
         for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f];
       }
     }
@@ -802,8 +804,10 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
             }
             evs[3 * bb] = e0; evs[3 * bb + 1] = e1; evs[3 * bb + 2] = e2;
           }
+          if (a.nbr) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+            for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+          }
 #pragma unroll
           for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
         }
@@ -949,6 +953,38 @@ __global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *til
   atlas[(int64_t)(pos[2 * t] + r) * atlas_w + pos[2 * t + 1] + c] = id;
 }
 
+// stencil id table on demand: nbr[node][b] = node id of the cell at -offset[b] (the SOURCE of the block-b in-edge), -1 if absent --
+// exactly what the feature kernels used to write inline (graph_construction.py:196-223)
+__global__ __launch_bounds__(256) void stencil_table_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *node_id, int64_t cells,
+                                                            Stencil st, int32_t *nbr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cells) return;
+  const int id = node_id[i];
+  if (id < 0) return;
+  const BgnnTileMeta t = tiles[find_tile(tiles, n_tiles, i)];
+  const int li = (int)(i - t.cell_off), r = li / t.w, c = li - r * t.w;
+  for (int b = 0; b < st.K; ++b) {
+    const int sr = r - st.dr[b], sc = c - st.dc[b];
+    int sid = -1;
+    if (sr >= 0 && sr < t.h && sc >= 0 && sc < t.w) {
+      sid = node_id[(int64_t)t.cell_off + (int64_t)sr * t.w + sc];
+      if (sid < 0) sid = -1;
+    }
+    nbr[(int64_t)id * st.K + b] = sid;
+  }
+}
+
+int ensure_stencil_table(const bgnn_graph *g) {
+  if (g->kind != 0 || g->nbr_valid || g->total_cells <= 0) return BGNN_OK;
+  bgnn_ctx *ctx = g->ctx;
+  const Stencil st = make_stencil(g->K);
+  hipLaunchKernelGGL(stencil_table_kernel, dim3((unsigned)((g->total_cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles,
+                     g->n_tiles, g->d_node_id, (int64_t)g->total_cells, st, g->d_nbr);
+  BGNN_HIP_CHECK(hipGetLastError());
+  g->nbr_valid = true;
+  return BGNN_OK;
+}
+
 int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts) {
   const Stencil st = make_stencil(opts->connectivity);
   const int64_t cells = g->total_cells;
@@ -1000,7 +1036,8 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     FeatureArgs a{};
     a.tiles = g->d_tiles; a.items = g->d_items; a.depth = tiles->depth; a.mask = tiles->mask;
     a.unc = tiles->uncertainty; a.local_mean = lmean; a.local_std = lstd; a.node_id = g->d_node_id;
-    a.x8 = g->d_x8; a.node_local_std = g->d_local_std; a.nbr = g->d_nbr; a.eattr = g->d_eattr;
+    a.x8 = g->d_x8; a.node_local_std = g->d_local_std; a.nbr = nullptr; a.eattr = g->d_eattr;    // (stencil id table: on demand)
+    g->nbr_valid = false;
     a.F = g->F; a.ED = g->ED;
     // final column list: requested features (uncertainty skipped when absent), then
     // uncertainty appended when given and not listed (:288-316)
@@ -1030,6 +1067,7 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
 int launch_graph_count_edges(bgnn_graph *g) {
   // per-tile node / edge counts -> host prefix offsets (synchronises)
   bgnn_ctx *ctx = g->ctx;
+  BGNN_TRY(ensure_stencil_table(g));
   void *p;
   BGNN_TRY(ctx_workspace(ctx, 5, (size_t)g->n_tiles * sizeof(int64_t) * 2, &p));
   int64_t *tn = (int64_t *)p, *te = tn + g->n_tiles;
@@ -1051,6 +1089,7 @@ int launch_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edg
                        valid_cols, local_std, batch);
   }
   if (edge_index || edge_attr) {
+    BGNN_TRY(ensure_stencil_table(g));
     const int KS = g->K + (g->include_self_loops ? 1 : 0);
     EdgeValue ev{g->d_tiles, g->n_tiles, g->K, KS, g->d_node_id, g->d_nbr};
     const int64_t n = (int64_t)g->total_cells * KS;

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void neighbor_reduce_kernel(ReduceArgs a) {
 int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv) {
   const int64_t rows = g->row_capacity;
   if (rows <= 0) return BGNN_OK;
+  BGNN_TRY(ensure_stencil_table(g));
   ProfScope ps(ctx, BGNN_K_AGGREGATE);
   hipLaunchKernelGGL(degree_inv_sqrt_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream,
                      g->d_nbr, g->kind == 0 ? nullptr : g->d_rowptr, g->K, g->d_counts, dinv);
@@ -107,6 +108,7 @@ int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const f
   const int64_t rows = g->row_capacity;
   if (rows <= 0) return BGNN_OK;
   BGNN_REQUIRE(D == 32 || D == 64, "neighbor_reduce: width %d unsupported (32 or 64)", D);
+  BGNN_TRY(ensure_stencil_table(g));
   ReduceArgs a{x, g->d_nbr, g->kind == 0 ? nullptr : g->d_rowptr, dinv, scale, shift, out,
                copy_self, g->d_counts, g->K, D, ldo, mode, relu, g->kind == 0 ? g->include_self_loops : 0};
   ProfScope ps(ctx, BGNN_K_AGGREGATE);
