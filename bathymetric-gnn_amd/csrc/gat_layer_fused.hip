@@ -511,7 +511,9 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int ATT_OFF = SLAB1 + 128 > 4 * 32 * TILED_PITCH ? SLAB1 + 128 : 4 * 32 * TILED_PITCH;
   static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? (ATT_LATE ? 0 : 2 * NC) : HEADW_LATE ? 0 : HEADW);
   static constexpr int RSZ = RA > RB ? RA : RB;
-  static constexpr int APITCH = (H * (K + 1) + 3) & ~3;
+  // ODD pitch (in dwords): the gather reads one coefficient per cell with ds_read_b32, whose 32-lane groups bank on (a / 4) mod 32 --
+  // with the round-2 pitch of 36 dwords the 32 cells of a group fell on 8 banks (4-way conflict on every coefficient read)
+  static constexpr int APITCH = (H * (K + 1)) | 1;
   // attention coefficients: [128 cells][APITCH] f32 (sparse, every head); bf16 storage path: the CURRENT head's coefficients as
   // four wave-private dense [32 cells][window rows] bf16 matrices (the aggregation's MFMA B operand) -- see AggWindow
   static constexpr int ALPHA = SP == 3 ? 4 * 32 * AggWindow<K>::PITCH / 4 : 128 * APITCH;
@@ -726,10 +728,17 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   }
   // Halo rows go global -> LDS by LDS-DMA.  A wave-instruction writes 64 x 16 B linearly = 64 / CPR rows x ROWB bytes;
   // bank spreading is an XOR swizzle on the SOURCE side: LDS chunk p of a row holds channel chunk p ^ swz(row), with
-  // swz(row) = (row >> 1) & 7 for 128-byte rows and (row >> 2) & 3 for 64-byte rows (16 consecutive rows then cover the
-  // 16 distinct 16-byte bank groups).  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
+  // swz(row) = ((row % HW) >> 1) & 7 for 128-byte rows -- by the row's COLUMN in the halo, see below -- and (row >> 2) & 3 for
+  // 64-byte rows.  Each thread always moves the same <= NPIECE (row, chunk) pairs, so their source
   // offsets (32 bits, relative to the smallest node id this WAVE touches) are computed once.
-  auto swz = [](int row) { return XB == 4 ? (row >> 1) & 7 : (row >> 2) & 3; };
+  // 128-byte rows: a ds_read_b128 is served in four groups of 16 lanes, and a group is NOT 16 consecutive lanes: {0-3, 12-15,
+  // 20-27}, {4-11, 16-19, 28-31} (+32): eight cells of the wave's first block row and the COMPLEMENTARY eight columns of its second.
+  // A slot (parity of the row, chunk ^ swz) is free of conflicts when the 16 rows of a group differ in (row & 1, swz): with the
+  // swizzle taken from the halo column, hc >> 1, any 16 distinct columns do (HW is even, so the parity follows the column too).
+  // Round 2's (row >> 1) & 7 shifted the second block row's slots by one against the first: two 2-way conflicts per group, i.e.
+  // every gather read took twice its LDS cycles (SQ_LDS_BANK_CONFLICT: 37-47 % of the exact instances' LDS-active cycles).
+  static_assert(HW_ % 2 == 0, "row parity follows the halo column");
+  auto swz = [](int row) { return XB == 4 ? ((row % HW_) >> 1) & 7 : (row >> 2) & 3; };
   // Per piece ONE 64-bit source base for the whole block (a single 32 x 32 -> 64-bit multiply-add off the table's base; an earlier
   // version kept 32-bit offsets relative to the smallest id of the wave, which cost a six-step wave reduction per block): rows
   // without a node read the context's zero page, which holds more than NSLAB * ROWB zero bytes, so that they can advance by ROWB
@@ -971,7 +980,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
           for (int b = 0; b <= K; ++b) {
             const int nidx = nb_index(b);
-            const uint32_t rb = slabs + nidx * 128 + (((((nidx >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
+            const int hcol = tc + RAD - (b < K ? Off::dc[b < K ? b : 0] : 0);          // the source row's column in the halo
+            const uint32_t rb = slabs + nidx * 128 + (((((hcol >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
             f32x4 x[4];
             const float alpha = lds_read1<0>(ap + 4 * b);
             x[0] = lds_read4<0>(rb); x[1] = lds_read4<0>(rb ^ CX1); x[2] = lds_read4<0>(rb ^ CX2); x[3] = lds_read4<0>(rb ^ CX3);
@@ -1284,7 +1294,7 @@ struct PersistLds {
   static constexpr int HR = FusedGeom<K>::HR;
   static constexpr int SLAB = HR * 32;                    // floats per slab buffer (f32)
   static constexpr int WSL = 32 * 256;                    // floats per 32-row W chunk (the epilogue's store patches reuse chunk buffer 1)
-  static constexpr int APITCH = (4 * (K + 1) + 3) & ~3;
+  static constexpr int APITCH = (4 * (K + 1)) | 1;       // odd, as in FusedLds
   static constexpr int HIDP = (HR + 3) & ~3;
   static constexpr int EAT = 128 * K * 3;                 // the cells' edge-attribute blocks
   static constexpr int FLOATS = 2 * SLAB + 2 * WSL + 2 * 256 + 2 * 256 + 2 * HIDP + HR * 4 + EAT + 128 * 4 + 128 * APITCH;
@@ -1340,7 +1350,7 @@ __global__ __launch_bounds__(256, 1) void gat_layer_persist_kernel(FusedArgs a, 
   // (pin them here: left to the scheduler their wait lands inside the block loop, as a vmcnt(0) in front of phase A)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(vpre[0][0]), "+v"(vpre[0][1]), "+v"(vpre[0][2]), "+v"(vpre[1][0]), "+v"(vpre[1][1]), "+v"(vpre[1][2]));
 
-  auto swz = [](int row) { return (row >> 1) & 7; };
+  auto swz = [](int row) { return ((row % HW_) >> 1) & 7; };       // by halo column: see gat_layer_fused_kernel
   const char *zp = reinterpret_cast<const char *>(a.zero_page);
   const int bpt = a.tb.bh * a.tb.bw;
   const int64_t tile_cells = (int64_t)uni_h * uni_w;
@@ -1544,7 +1554,8 @@ __global__ __launch_bounds__(256, 1) void gat_layer_persist_kernel(FusedArgs a, 
           const int b = b0 + j;
           if (b <= K) {
             const int nidx = b >= K ? self_idx : self_idx - Off::dr[b < K ? b : 0] * HW_ - Off::dc[b < K ? b : 0];
-            const uint32_t rb = slabs + nidx * 128 + ((((nidx >> 1) & 7) ^ hl) << 4);
+            const int hcol = tc + RAD - (b < K ? Off::dc[b < K ? b : 0] : 0);
+            const uint32_t rb = slabs + nidx * 128 + ((((hcol >> 1) & 7) ^ hl) << 4);
             al[j] = lds_read1<0>(ap + 4 * b);
             x[j][0] = lds_read4<0>(rb); x[j][1] = lds_read4<0>(rb ^ 32); x[j][2] = lds_read4<0>(rb ^ 64); x[j][3] = lds_read4<0>(rb ^ 96);
           }
