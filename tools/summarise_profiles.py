@@ -30,9 +30,9 @@ def short(name):
     return re.sub(r"\(.*\)$", "", name)
 
 
-def newest(files, window_s=3600):
+def newest(files, window_s=300):
     """gpurun MERGES a run's output into the local gpurun_out/: files of an earlier round's run may sit beside the new ones.
-    Only the files of the most recent run (modified within an hour of the newest one) are summarised."""
+    Only the files of the most recent run (modified within five minutes of the newest file of the same pass) are summarised."""
     if not files:
         return files
     t = max(os.path.getmtime(f) for f in files)
