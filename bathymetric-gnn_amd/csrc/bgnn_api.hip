@@ -554,6 +554,16 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     const size_t boff = k == 0 ? 0 : d->num_classes + (k - 1);
     std::copy(p, p + nout, pk.begin() + o_hb1 + boff); p += nout;
   }
+  // the fused heads kernel takes all of the above as ONE LDS image (a single DMA piece per workgroup): first-layer biases at 0,
+  // second-layer row j at 96 + 32 j, second-layer biases at 288 (gat_layer_fused.hip, FusedLds::HEADW)
+  const size_t o_htab = reserve(296);
+  const int n_rows1 = d->num_classes + nh - 1;
+  const bool htab_ok = HT <= 96 && hh == 32 && n_rows1 <= 6;
+  if (htab_ok) {
+    std::copy(pk.begin() + o_hb0, pk.begin() + o_hb0 + HT, pk.begin() + o_htab);
+    std::copy(pk.begin() + o_hW1, pk.begin() + o_hW1 + (size_t)n_rows1 * hh, pk.begin() + o_htab + 96);
+    std::copy(pk.begin() + o_hb1, pk.begin() + o_hb1 + n_rows1, pk.begin() + o_htab + 288);
+  }
   if ((size_t)(p - w) != n_weights) {
     set_error("internal: weight unpack consumed %zu of %zu floats", (size_t)(p - w), n_weights);
     return BGNN_ERR_INVALID;
@@ -650,6 +660,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->hd_W0sp = gat ? m->blob + o_hW0sp : nullptr;
   m->hd_W0sp16 = gat && f16_ok ? m->blob + o_hW0sp16 : nullptr;
   m->hd_W0t = m->blob + o_hW0t; m->hd_b0 = m->blob + o_hb0; m->hd_W1 = m->blob + o_hW1; m->hd_b1 = m->blob + o_hb1;
+  m->hd_tab = htab_ok ? m->blob + o_htab : nullptr;
   *out = m;
   return BGNN_OK;
 }

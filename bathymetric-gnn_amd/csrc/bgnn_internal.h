@@ -166,6 +166,7 @@ struct bgnn_model {
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
   float *hd_W0sp = nullptr, *hd_W0sp16 = nullptr;   // hd_W0t as bf16 / float16 hi / lo split images
   float *hd_W1, *hd_b1;       // second layers packed: cls [classes][hid/2], conf [hid/2], corr [hid/2]; biases
+  float *hd_tab = nullptr;    // fused heads epilogue's LDS image, [296]: b0 [96] | second-layer rows [<= 6][32] | their biases [8]
 };
 
 struct bgnn_graph {

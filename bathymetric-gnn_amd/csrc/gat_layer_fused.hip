@@ -81,9 +81,7 @@ struct FusedArgs {
   float *asd_out;         // [rows][2*H2]
   int H2, C2;
   // EPI_HEADS
-  const float *hd_b0;     // [NC]
-  const float *hd_W1;     // cls [classes][hh], conf [hh], corr [hh]
-  const float *hd_b1;
+  const float *hd_tab;    // [HEADW] b0 [96] | second-layer rows (cls [classes], conf, corr) at 96 + 32 j | their biases at 288
   const float *local_std; // [rows]
   int classes, hh, has_corr;
   float thr_auto, thr_review, norm_floor;
@@ -150,25 +148,16 @@ struct HaloSlot {
   static constexpr int MAXOFF = R * HWID + R;                        // self_idx - MAXOFF = the lowest row a slot can address
   static constexpr int rel(int b) { return MAXOFF - (Off::dr[b] * HWID + Off::dc[b]); }   // >= 0: slot b's source row, relative to it
 };
-template <int H, int K, int HWID, int... B>
-__device__ __forceinline__ void halo_operands(uint32_t hid_lo, uint32_t has_lo, int (&nb)[K], float (&hs)[K + 1],
-                                              std::integer_sequence<int, B...>) {
+template <int K, int HWID, int... B>
+__device__ __forceinline__ void halo_ids(uint32_t hid_lo, int (&nb)[K], std::integer_sequence<int, B...>) {
   using S = HaloSlot<K, HWID>;
   ((nb[B] = lds_read1i<S::rel(B) * 4>(hid_lo)), ...);
+}
+template <int H, int K, int HWID, int... B>
+__device__ __forceinline__ void halo_alpha_src(uint32_t has_lo, float (&hs)[K + 1], std::integer_sequence<int, B...>) {
+  using S = HaloSlot<K, HWID>;
   ((hs[B] = lds_read1<S::rel(B) * H * 4>(has_lo)), ...);
   hs[K] = lds_read1<S::MAXOFF * H * 4>(has_lo);
-  lds_reads_done();
-}
-// attention_coefficients_head_pre (gat_tile_common.h) with the halo operands fetched as above: same arithmetic, same results
-template <int H, int K, int HWID>
-__device__ __forceinline__ void attention_coefficients_head_asm(int self_idx, int hh, uint32_t hid0, uint32_t has0,
-                                                                const float (&eraw)[K * 3], float ad, const float (&v)[3], float *out) {
-  using S = HaloSlot<K, HWID>;
-  int nb[K];
-  float hs[K + 1];
-  halo_operands<H, K, HWID>(hid0 + (uint32_t)(self_idx - S::MAXOFF) * 4u, has0 + (uint32_t)((self_idx - S::MAXOFF) * H + hh) * 4u, nb, hs,
-                            std::make_integer_sequence<int, K>{});
-  attention_coefficients_head_vals<K>(nb, hs, eraw, ad, v, out);
 }
 
 // MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
@@ -526,7 +515,11 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int PRE = SLAB + WBUF + PATCH_PAD + RSZ + (HID_IN_ALPHA ? 128 : HR) + 4;
   static constexpr int ALIGN = (4 - PRE % 4) % 4;        // the dense matrices start on a 16-byte boundary
   static constexpr int FLOATS = PRE + ALIGN + ALPHA;
-  static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
+  // (exact-f32 k = 16 heads instance: phase A holds 48 edge terms + 17 alpha_src + 17 logits next to twelve 64-bit slab bases --
+  //  more than the 170 registers a third workgroup leaves (46 spills, and a spill reload shares vmcnt with the slab DMAs): two
+  //  workgroups per CU.  The bf16 instance has half the slab pieces and stays at three: measured 1.08 ms against 1.27 ms at two.)
+  static constexpr bool WIDE_PHASE_A = K == 16 && EPI == EPI_HEADS && SP == 0;
+  static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 && !WIDE_PHASE_A ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
 };
 
 template <int HC, int C, int K, int NT, int EPI, int SP = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3, 3 bf16 storage + MFMA
@@ -661,19 +654,11 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
     for (int f = 0; f < 3; ++f) vpre[i][f] = hh < H ? a.V[hh * 3 + f] : 0.0f;
   }
-  // heads: the small second-stage weights go the same way (registers now, LDS at slab 0).  Read straight from global memory in the
-  // final epilogue they were 28 dependent float4 loads per lane behind runtime class tests: 41 % of that instance's lifetime.
-  float hwv[2] = {0.0f, 0.0f};
-  if constexpr (EPI == EPI_HEADS) {
-    const int nrow = a.classes + 1 + (a.has_corr ? 1 : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + i * NTH;
-      if (idx < 96) hwv[i] = a.hd_b0[idx];
-      else if (idx < 96 + nrow * 32) hwv[i] = a.hd_W1[idx - 96];
-      else if (idx >= 288 && idx < 288 + nrow) hwv[i] = a.hd_b1[idx - 288];
-    }
-  }
+  // (heads: the small second-stage weight table -- 296 floats, packed on the host in its LDS layout -- is one LDS-DMA piece
+  //  issued where its LDS region falls free, see stage_head_table below.  Read straight from global memory in the final epilogue
+  //  it was 28 dependent float4 loads per lane behind runtime class tests, 41 % of that instance's lifetime; held in registers
+  //  from the prologue on -- round 2 -- it cost three exec-masked loads with a vmcnt(0) each and, at k = 16, spills whose
+  //  reloads share vmcnt with the slab DMAs.)
   BGNN_STAMP(9)    // block decode, address arithmetic, round 1 requested
   // validity (ids < 0 in the table encode invalid cells)
   int hid_v = (tid < HR && in_tile(gr_h, gc_h) && raw_h >= 0) ? raw_h : -1;
@@ -760,6 +745,15 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   int npc = 0;
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) npc += (p * NTH + wave * 64 < HR * CPR) ? 1 : 0;
+  // heads: the weight table -> LDS, one DMA piece (waves 0 and 1: 64 + 10 lanes x 16 B)
+  static_assert(Lds::HEADW % 4 == 0 && Lds::HEADW <= 128 * 4, "the heads' table is at most two wave pieces");
+  auto stage_head_table = [&]() {
+    if constexpr (EPI == EPI_HEADS) {
+      if (wave < 2 && (wave * 64 + lane) * 4 < Lds::HEADW)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a.hd_tab + (wave * 64 + lane) * 4),
+                                         (__attribute__((address_space(3))) void *)(attr + wave * 256), 16, 0, 0);
+    }
+  };
   auto issue_slab = [&](int s) {
     const int sb = s * ROWB;                           // wave-uniform
 #pragma unroll
@@ -775,7 +769,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   if (tid < HR) {
     hid[tid] = hid_v;
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hid_v >= 0 ? hasv[hh] : 0.0f;
+    for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hid_v >= 0 ? hasv[hh] : -__builtin_inff();   // (-inf: an absent source drops out of the softmax)
   }
   if (Lds::HID_IN_ALPHA && hl == 0) cid[cell] = my_pre < 0 ? -1 : my_pre;
   {   // (phase A's register operands are complete as well before the DMA is queued: no wait behind it later)
@@ -805,23 +799,57 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     for (int b = 0; b < (K + 2) / 2; ++b) apk[i][b] = 0u;
   {
     const uint32_t hid0 = lds_addr(hid), has0 = lds_addr(has);
-    int my = lds_read1i<0>(hid0 + (uint32_t)self_idx * 4u);
+    // (k = 16 bf16 heads instance, which runs at its register limit: the cell's halo index is recomputed from the thread id here --
+    //  kept, it is spilled across the id rounds, and its reload would wait vmcnt(0), i.e. for slab 0's DMA, in front of phase A)
+    int self_a = self_idx;
+    if constexpr (K == 16 && EPI == EPI_HEADS && SP == 3) {
+      int t2 = threadIdx.x;
+      asm volatile("" : "+v"(t2));
+      const int c2 = (t2 & 31) | (t2 >> 6) << 5;                 // wave * 32 + (lane & 31)
+      self_a = (c2 / TILE_W + RAD) * HW_ + c2 % TILE_W + RAD;
+    }
+    int my = lds_read1i<0>(hid0 + (uint32_t)self_a * 4u);
     lds_reads_done();
     if (DBG(32)) my = -1;
+    // the cell's node ids of the stencil sources once, alpha_src per head; then the head-independent edge terms once and the
+    // lane's heads -- both at once, as packed f32 halves, when it owns two (gat_tile_common.h)
+    float part[NHL][K + 1];
+    if (my < 0) {                                       // (zeros only where they are needed: no live range across the arithmetic)
+#pragma unroll
+      for (int i = 0; i < NHL; ++i)
+#pragma unroll
+        for (int b = 0; b <= K; ++b) part[i][b] = 0.0f;
+    } else {
+      using S = HaloSlot<K, HW_>;
+      int nb[K];
+      float hs[NHL][K + 1];
+      halo_ids<K, HW_>(hid0 + (uint32_t)(self_a - S::MAXOFF) * 4u, nb, std::make_integer_sequence<int, K>{});
+#pragma unroll
+      for (int i = 0; i < NHL; ++i) {
+        const int hh = hl + i * 2 < H ? hl + i * 2 : 0;
+        halo_alpha_src<H, K, HW_>(has0 + (uint32_t)((self_a - S::MAXOFF) * H + hh) * 4u, hs[i], std::make_integer_sequence<int, K>{});
+      }
+      lds_reads_done();
+      EdgeTerms<K> et;
+      edge_terms<K>(nb, eraw, et);
+      if constexpr (NHL == 2 && H % 2 == 0 && H >= 4) {
+        attention_head_pair<K, false>(et, hs[0], hs[1], adv[0], adv[1], vpre[0], vpre[1], part[0], part[1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NHL; ++i)
+          if (hl + i * 2 < H) attention_head<K, false>(et, hs[i], adv[i], vpre[i], part[i]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
       const int hh = hl + i * 2;
       if (hh < H) {
-        float part[K + 1];
-#pragma unroll
-        for (int b = 0; b <= K; ++b) part[b] = 0.0f;
-        if (my >= 0) attention_coefficients_head_asm<H, K, HW_>(self_idx, hh, hid0, has0, eraw, adv[i], vpre[i], part);
         if constexpr (SP == 3) {      // kept in registers as bf16 pairs until this head's slabs come up (densified there)
 #pragma unroll
-          for (int b = 0; b <= K; b += 2) apk[i][b / 2] = pack_bf16x2(part[b], b + 1 <= K ? part[b + 1] : 0.0f);
+          for (int b = 0; b <= K; b += 2) apk[i][b / 2] = pack_bf16x2(part[i][b], b + 1 <= K ? part[i][b + 1] : 0.0f);
         } else {
           // (asm writes: with slab 0's DMA in flight hipcc would wait vmcnt(0) in front of a visible ds_write too)
-          lds_write_coefficients<K>(lds_addr(alx + cell * APITCH + hh * (K + 1)), part, std::make_integer_sequence<int, K + 1>{});
+          lds_write_coefficients<K>(lds_addr(alx + cell * APITCH + hh * (K + 1)), part[i], std::make_integer_sequence<int, K + 1>{});
         }
       }
     }
@@ -920,11 +948,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
           if (c < HC) { scsh[c] = scv[i]; scsh[HC + c] = shv[i]; }
         }
         if constexpr (SP == 3) densify(0);             // (every wave is past phase A: the alpha_src table is dead)
-        if constexpr (EPI == EPI_HEADS && !Lds::HEADW_LATE) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            if (tid + i * NTH < Lds::HEADW) attr[tid + i * NTH] = hwv[i];
-        }
+        if constexpr (EPI == EPI_HEADS && !Lds::HEADW_LATE) stage_head_table();   // (R is free; the last slab's full wait covers it)
         if (EPI == EPI_NEXT && !Lds::ATT_LATE && wave < 2 && lane * 4 < NC)
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>((wave == 0 ? a.att_src : a.att_dst) + lane * 4),
                                            (__attribute__((address_space(3))) void *)(attr + wave * NC), 16, 0, 0);
@@ -1028,13 +1052,9 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       BGNN_STAMP(5)   // wait for WA + barrier
       if (!DBUF && s + 1 < NSLAB && !DBG(4)) issue_slab(s + 1);     // (WDB too: single slab image)
       if constexpr (Lds::HEADW_LATE) {
-        // last slab gathered by every wave: its region now takes the heads' weight table (registers since the prologue); the two
-        // barriers between here and the final epilogue publish it
-        if (s + 1 == NSLAB) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            if (tid + i * NTH < Lds::HEADW) lds_write1<0>(lds_addr(attr + tid + i * NTH), hwv[i]);
-        }
+        // last slab gathered by every wave: its region now takes the heads' weight table; the two barriers between here and the
+        // final epilogue publish it
+        if (s + 1 == NSLAB) stage_head_table();       // (the vmcnt(0) after this slab's first MFMA half covers it)
       }
       // rank-16 update with W rows 0-15, then hand that half of the buffer to the next slab's DMA
       using LP8 = typename std::conditional<SP == 2, f16x8, bf16x8>::type;
@@ -1788,7 +1808,7 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
                              const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid) {
-  if (!fused_supported(g, C, ED) || L.heads != 1 || m->desc.num_classes > 4 || m->head_hidden_total != 96 ||
+  if (!fused_supported(g, C, ED) || L.heads != 1 || m->desc.num_classes > 4 || m->head_hidden_total != 96 || !m->hd_tab ||
       (m->desc.predict_correction ? 3 : 2) * (C / 2) > 96 || o->hidden)
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
@@ -1797,7 +1817,7 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
   if (split == 2 && !m->hd_W0sp16) split = 1;
   if ((split == 1 || split == 2) && g->K == 16) split = 0;
   a.Wt = split == 3 ? m->hd_W0bf : split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0fp;
-  a.hd_b0 = m->hd_b0; a.hd_W1 = m->hd_W1; a.hd_b1 = m->hd_b1;
+  a.hd_tab = m->hd_tab;
   a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;
   a.thr_auto = thr_auto; a.thr_review = thr_review; a.norm_floor = norm_floor; a.o = *o;

@@ -238,54 +238,75 @@ __device__ __forceinline__ void attention_coefficients_head(int my, int self_idx
   for (int b = 0; b <= K; ++b) out[b] = lg[b] / den;
 }
 
-// attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
-// edge-attribute block, `ad` = its alpha_dst for head hh, `v` = V[hh][0..2].  Lets the caller issue those global loads before the
-// halo ids are known (one latency less on the workgroup's critical path).
-// The arithmetic of one head's attention coefficients, with every operand already in registers: `nb` = node ids of the K stencil
-// sources (< 0: absent), `hs` = alpha_src of the K sources and (slot K) of the node itself, `eraw` = the node's [K][3] edge
-// attributes, `ad` = its alpha_dst, `v` = V[head][0..2].  Shared by every caller so that they agree bit for bit.
+// ---- attention coefficients of the fused kernels, every operand already in registers -------------------------------------------
+// Split in two so that what does not depend on the head is computed ONCE per cell (it used to be redone per head: the operand
+// reads are asm, so the compiler could not see that both heads mask the same edge attributes):
+//   EdgeTerms: which stencil sources exist, their edge attributes (0 where absent), and the self loop's attributes = mean of the
+//              present ones (GATConv fill_value = 'mean'; scatter-mean = sum / max(count, 1));
+//   per head : e_b = leaky_relu(a_src[b] + a_dst + ea_b . V, 0.2), softmax over the present sources and the self loop
+//              (exp(e - max) / (sum + 1e-16)).
+// A lane that owns TWO heads (H = 4: heads hl and hl + 2) runs them as the two halves of packed f32 operations
+// (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): the same IEEE operations in the same order per head, so the pair form and the
+// single-head form agree bit for bit (the persistent kernel and the heads instances use the single form; tests/test_gpu_forward.py).
+// exp through v_exp_f32 (2^x), one v_rcp_f32 per head instead of K + 1 divisions and one for the mean's 1 / count: ~1 ulp each,
+// far inside the 1e-4 bar.  leaky_relu(x, 0.2) = max(x, 0.2 x) for every x (one multiply + one max).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <int K>
-__device__ __forceinline__ void attention_coefficients_head_vals(const int (&nb)[K], const float (&hs)[K + 1],
-                                                                 const float (&eraw)[K * 3], float ad, const float (&v)[3],
-                                                                 float *out) {
-  float ea_sum[3] = {0.f, 0.f, 0.f};
-  int deg = 0;
-  float mx = -__builtin_inff();
-  float lg[K + 1];
+struct EdgeTerms {
   bool present[K];
+  float e[K][3];         // edge attributes of slot b, 0 where the source is absent
+  float mean[3];         // the self loop's attributes
+};
+
+template <int K>
+__device__ __forceinline__ void edge_terms(const int (&nb)[K], const float (&eraw)[K * 3], EdgeTerms<K> &t) {
+  float sum[3] = {0.f, 0.f, 0.f};
+  int deg = 0;
 #pragma unroll
   for (int b = 0; b < K; ++b) {
-    present[b] = nb[b] >= 0;
-    float dot = 0.0f;
+    t.present[b] = nb[b] >= 0;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-      const float e = present[b] ? eraw[b * 3 + f] : 0.0f;
-      ea_sum[f] += e;
-      dot += e * v[f];
+      t.e[b][f] = t.present[b] ? eraw[b * 3 + f] : 0.0f;
+      sum[f] += t.e[b][f];
     }
-    float x = hs[b] + ad + dot;
-    x = x > 0.0f ? x : 0.2f * x;
-    lg[b] = x;
-    if (present[b]) { mx = fmaxf(mx, x); ++deg; }
+    deg += t.present[b] ? 1 : 0;
   }
-  {
-    const float cnt = (float)(deg > 0 ? deg : 1);
-    float dot = 0.0f;
+  const float rc = __builtin_amdgcn_rcpf((float)(deg > 0 ? deg : 1));
 #pragma unroll
-    for (int f = 0; f < 3; ++f) dot += (ea_sum[f] / cnt) * v[f];
-    float x = hs[K] + ad + dot;
-    x = x > 0.0f ? x : 0.2f * x;
-    lg[K] = x;
-    mx = fmaxf(mx, x);
+  for (int f = 0; f < 3; ++f) t.mean[f] = sum[f] * rc;
+}
+
+__device__ __forceinline__ float leaky02(float x) {
+  float r;
+  const float y = 0.2f * x;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));     // (asm: the C fmax adds a canonicalising instruction)
+  return r;
+}
+
+// MASKED = false: the caller's alpha_src is -inf where the source is absent (the fused kernel writes its halo table that way), so the
+// logit is -inf, drops out of the max and its exp is exactly 0 -- the same values as the masked form, without the selects and without
+// keeping the presence flags alive next to the logits.
+template <int K, bool MASKED = true>
+__device__ __forceinline__ void attention_head(const EdgeTerms<K> &t, const float (&hs)[K + 1], float ad, const float (&v)[3], float *out) {
+  float mx = -__builtin_inff();
+  float lg[K + 1];
+#pragma unroll
+  for (int b = 0; b <= K; ++b) {
+    const float *e = b < K ? t.e[b < K ? b : 0] : t.mean;
+    float dot = e[0] * v[0];
+    dot = __builtin_fmaf(e[1], v[1], dot);
+    dot = __builtin_fmaf(e[2], v[2], dot);
+    const float x = leaky02((hs[b] + ad) + dot);
+    lg[b] = x;
+    const bool on = b == K || !MASKED ? true : t.present[b < K ? b : 0];
+    mx = fmaxf(mx, on ? x : -__builtin_inff());
   }
-  // exp through the hardware v_exp_f32 (2^x) and one reciprocal per head instead of libm expf and K + 1 IEEE
-  // divisions: ~1 ulp each, far inside the 1e-4 bar, and 4x fewer VALU instructions in a phase that cannot overlap
-  // the other workgroup's MFMAs (on gfx950 a wave streaming f32 MFMAs leaves the SIMD no issue slot for its
-  // neighbour: tools/mfma_overlap_probe.hip)
   float den = 0.0f;
 #pragma unroll
   for (int b = 0; b <= K; ++b) {
-    const bool on = b == K ? true : present[b];
+    const bool on = b == K || !MASKED ? true : t.present[b < K ? b : 0];
     const float pe = on ? __builtin_amdgcn_exp2f((lg[b] - mx) * 1.44269504088896340736f) : 0.0f;
     lg[b] = pe;
     den += pe;
@@ -294,6 +315,61 @@ __device__ __forceinline__ void attention_coefficients_head_vals(const int (&nb)
   const float rden = __builtin_amdgcn_rcpf(den);
 #pragma unroll
   for (int b = 0; b <= K; ++b) out[b] = lg[b] * rden;
+}
+
+// two heads of one cell at once: element 0 = the first head, element 1 = the second
+template <int K, bool MASKED = true>
+__device__ __forceinline__ void attention_head_pair(const EdgeTerms<K> &t, const float (&hs0)[K + 1], const float (&hs1)[K + 1], float ad0,
+                                                    float ad1, const float (&v0)[3], const float (&v1)[3], float *out0, float *out1) {
+  const f32x2_t ad = {ad0, ad1};
+  const f32x2_t w0 = {v0[0], v1[0]}, w1 = {v0[1], v1[1]}, w2 = {v0[2], v1[2]};
+  float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
+  f32x2_t lg[K + 1];
+#pragma unroll
+  for (int b = 0; b <= K; ++b) {
+    const float *e = b < K ? t.e[b < K ? b : 0] : t.mean;
+    const f32x2_t e0 = {e[0], e[0]}, e1 = {e[1], e[1]}, e2 = {e[2], e[2]};
+    f32x2_t dot = e0 * w0;
+    dot = __builtin_elementwise_fma(e1, w1, dot);
+    dot = __builtin_elementwise_fma(e2, w2, dot);
+    const f32x2_t hs = {hs0[b], hs1[b]};
+    const f32x2_t xs = (hs + ad) + dot;
+    const f32x2_t x = {leaky02(xs.x), leaky02(xs.y)};
+    lg[b] = x;
+    const bool on = b == K || !MASKED ? true : t.present[b < K ? b : 0];
+    mx0 = fmaxf(mx0, on ? x.x : -__builtin_inff());
+    mx1 = fmaxf(mx1, on ? x.y : -__builtin_inff());
+  }
+  const f32x2_t mx = {mx0, mx1};
+  const f32x2_t l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+  f32x2_t den = {0.0f, 0.0f};
+#pragma unroll
+  for (int b = 0; b <= K; ++b) {
+    const bool on = b == K || !MASKED ? true : t.present[b < K ? b : 0];
+    const f32x2_t arg = (lg[b] - mx) * l2e;
+    f32x2_t pe = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    if (!on) pe = (f32x2_t){0.0f, 0.0f};
+    lg[b] = pe;
+    den += pe;
+  }
+  den += (f32x2_t){1e-16f, 1e-16f};
+  const f32x2_t rden = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+#pragma unroll
+  for (int b = 0; b <= K; ++b) {
+    const f32x2_t o = lg[b] * rden;
+    out0[b] = o.x; out1[b] = o.y;
+  }
+}
+
+// one head, from the raw operands (`nb` = node ids of the K stencil sources (< 0: absent), `hs` = alpha_src of the K sources and
+// (slot K) of the node itself, `eraw` = the node's [K][3] edge attributes, `ad` = its alpha_dst, `v` = V[head][0..2])
+template <int K>
+__device__ __forceinline__ void attention_coefficients_head_vals(const int (&nb)[K], const float (&hs)[K + 1],
+                                                                 const float (&eraw)[K * 3], float ad, const float (&v)[3],
+                                                                 float *out) {
+  EdgeTerms<K> t;
+  edge_terms<K>(nb, eraw, t);
+  attention_head<K>(t, hs, ad, v, out);
 }
 
 // attention_coefficients_head with the node's own operands already in registers (ED == 3): `eraw` = its [K][3]
