@@ -404,6 +404,39 @@ static void pack_bf16_image_accop(const float *Wt, int D, int NC, float *dst_as_
                 bf16_rne(Wt[(size_t)(hc * 16 + 8 * (i >> 2) + 4 * kg + (i & 3)) * NC + t * 32 + m]);
 }
 
+// Alpha tile of the bf16 front GEMM (gemm_f32.hip, AMF): the attention dots alpha_src[hd] = sum_c Y[hd C + c] att_src[hd C + c]
+// with Y = x W + b are x (W att) + b att.  32 weight columns behind the W image, packed like one more tile: column hd = the hi
+// bf16 part of sum_c W_bf16[k][hd C + c] att_src[hd C + c], 4 + hd the same for att_dst, 8 + hd / 12 + hd the lo parts (hi + lo:
+// 16 mantissa bits; W_bf16 = the rounded weights the GEMM itself multiplies by), the rest zero; then 8 floats: b att per head.
+static void pack_alpha_tile(const float *Wt, const float *bias, const float *att_src, const float *att_dst, int D, int H, int C,
+                            float *dst) {
+  std::vector<float> Wa((size_t)D * 32, 0.0f);
+  for (int k = 0; k < D; ++k)
+    for (int hd = 0; hd < H; ++hd) {
+      double s = 0.0, d = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const double w = (double)bf16_to_f32(bf16_rne(Wt[(size_t)k * H * C + hd * C + c]));
+        s += w * (double)att_src[hd * C + c];
+        d += w * (double)att_dst[hd * C + c];
+      }
+      const float fs = (float)s, fd = (float)d;
+      const float hs = bf16_to_f32(bf16_rne(fs)), hd_ = bf16_to_f32(bf16_rne(fd));
+      Wa[(size_t)k * 32 + hd] = hs;       Wa[(size_t)k * 32 + 8 + hd] = bf16_to_f32(bf16_rne(fs - hs));
+      Wa[(size_t)k * 32 + 4 + hd] = hd_;  Wa[(size_t)k * 32 + 12 + hd] = bf16_to_f32(bf16_rne(fd - hd_));
+    }
+  pack_bf16_image_accop(Wa.data(), D, 32, dst);
+  float *cb = dst + (size_t)D / 16 * 256;
+  for (int hd = 0; hd < 8; ++hd) cb[hd] = 0.0f;
+  for (int hd = 0; hd < H; ++hd) {
+    double s = 0.0, d = 0.0;
+    for (int c = 0; c < C; ++c) {
+      s += (double)(bias ? bias[hd * C + c] : 0.0f) * (double)att_src[hd * C + c];
+      d += (double)(bias ? bias[hd * C + c] : 0.0f) * (double)att_dst[hd * C + c];
+    }
+    cb[hd] = (float)s; cb[4 + hd] = (float)d;
+  }
+}
+
 // column-permuted f32 image for the fused exact-f32 kernel: column 32 t + r of a row goes to (t / TG) * 32 TG + r * TG + t % TG,
 // TG = 4 / 2 / 1 tiles per LDS read (gat_layer_fused.hip: WTileGroup)
 static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst) {
@@ -597,7 +630,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     }
     o_hW0fp = reserve((size_t)hid * HT);
     o_hW0sp = reserve((size_t)hid * HT); o_hW0sp16 = reserve((size_t)hid * HT); o_hW0bf = reserve((size_t)hid * HT / 2);
-    o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0); o_l0fbf = reserve((size_t)hid * HC0 / 2);
+    o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0); o_l0fbf = reserve((size_t)hid * HC0 / 2 + (size_t)hid / 16 * 256 + 8);   // + the alpha tile and its constants
     for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
@@ -615,6 +648,11 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
     if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
     pack_bf16_image_accop(src0.data(), hid, HC0, pk.data() + o_l0fbf);
+    if (HC0 / hid <= 4) {
+      const std::vector<float> b0(pk.begin() + o_l0f_b, pk.begin() + o_l0f_b + HC0);
+      const std::vector<float> as0(pk.begin() + lo[0].as, pk.begin() + lo[0].as + HC0), ad0(pk.begin() + lo[0].ad, pk.begin() + lo[0].ad + HC0);
+      pack_alpha_tile(src0.data(), b0.data(), as0.data(), ad0.data(), hid, HC0 / hid, hid, pk.data() + o_l0fbf + (size_t)hid * HC0 / 2);
+    }
   }
 
   bgnn_model *m = new bgnn_model();

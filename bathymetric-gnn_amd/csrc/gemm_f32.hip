@@ -255,8 +255,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(128))) float wres_lds[];
   float *wl = wres_lds;                              // [64][NC]
   constexpr int PP = 68;                              // patch pitch: two 32-column tiles side by side + 4 pad
-  float *patches = wl + WFLOATS;                     // [8][32 * PP]
-  float *attl = patches + 8 * 32 * PP;               // [2][NC]
+  // bf16 output: the attention dots are a NINTH 32-column MFMA tile (AMF).  Its weight columns are W att folded on the host
+  // (bgnn_api.hip pack_alpha_tile): column hd = sum over head hd's columns of W_bf16[k][c] att_src[c] (4 + hd: att_dst), as bf16
+  // hi parts, columns 8.. / 12.. their bf16 lo parts, so that hi + lo carries 16 mantissa bits; the bias' share is a constant per
+  // head behind the image.  Against taking the dots from the accumulators this drops 64 ds_read_b128 of the att vectors, 64
+  // v_pk_fma_f32 and 8 scalar stores per 32 rows for 4 MFMAs and one 16-byte store: the launch was bound by exactly that LDS and
+  // VALU work in its epilogue, not by HBM (ablations in profiles/).
+  constexpr bool AMF = SP == 3 && ATT;
+  constexpr int WIMG = WFLOATS + (AMF ? 1024 : 0);   // + the alpha tile: 4 k-steps x 1 KiB
+  // bf16 output: the wave's patch holds FOUR tiles side by side as bf16, [32 rows][256 B]; else two as f32
+  constexpr int PATCHF = SP == 3 ? 32 * 64 : 32 * PP;
+  float *patches = wl + WIMG;                        // [8][PATCHF]
+  float *attl = patches + 8 * PATCHF;                // [2][NC]
   float *b0l = attl + 2 * NC;                        // [64]  (FRONT)
   // The output bias lives in LDS as well: read from global memory inside the epilogue, each of its 32 float4 loads per block
   // sat -- vmcnt counts loads and stores in one in-order queue on gfx9 -- behind the row stores of the tile pair before it, so
@@ -267,14 +277,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   const int NW = blockDim.x >> 6;                    // 8 (4 only in the occupancy experiment)
   {
     const char *src = reinterpret_cast<const char *>(a.Wt);
-    constexpr int NQ = WFLOATS * 4 / 1024;           // 1-KiB pieces
+    constexpr int NQ = WIMG * 4 / 1024;              // 1-KiB pieces
     for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
       const int q = j * NW + wave;
       if (q < NQ)
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(src + q * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void *)(wl + q * 256), 16, 0, 0);
     }
-    if (ATT)
+    if (ATT && !AMF)
       for (int i = threadIdx.x; i < NC; i += blockDim.x) { attl[i] = a.att_src[i]; attl[NC + i] = a.att_dst[i]; }
     if (FRONT && threadIdx.x < 64) b0l[threadIdx.x] = a.b0[threadIdx.x];
     if (a.bias)
@@ -282,7 +292,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   }
   __syncthreads();                                   // (vmcnt(0): W has landed)
   const int64_t M = *a.d_m;
-  float *patch = patches + wave * (32 * PP);
+  float *patch = patches + wave * PATCHF;
+  float cbv[4] = {0.f, 0.f, 0.f, 0.f};               // AMF: the bias' share of this lane's four dots (h = 0: src, h = 1: dst)
+  if constexpr (AMF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cbv[i] = a.Wt[WIMG + 4 * h + i];
+  }
   const uint32_t asl = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)(attl + 4 * h);
   const int64_t stride = (int64_t)gridDim.x * NW * 32;
   int64_t row0 = (int64_t)blockIdx.x * NW * 32 + wave * 32;
@@ -334,6 +349,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    f32x16 acca;                                        // AMF: the alpha tile
+    if constexpr (AMF) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acca[i] = 0.0f;
+    }
     if constexpr (SP == 3) {
       if (!(BGNN_DIAG && (a.dbg & 2))) {
 #pragma unroll
@@ -347,6 +367,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
           for (int t = 0; t < NT; ++t) {               // half-chunk st: tile t at (st * NT + t) KiB of the hi-only image
             const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + (st * NT + t) * 1024 + lane * 16);
             acc[t] = mfma_lp(wh, xh, acc[t]);
+          }
+          if constexpr (AMF) {                         // the alpha tile sits behind the K / 16 * NT KiB of W
+            const bf16x8 wa = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(wl) + (K / 16 * NT + st) * 1024 + lane * 16);
+            acca = mfma_lp(wa, xh, acca);
           }
         }
       }
@@ -388,13 +412,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
     if (row0 + stride < M && !(BGNN_DIAG && (a.dbg & 4))) load_x(row0 + stride);    // next block's X flies under this block's epilogue
     // stores leave as 256-byte row segments (two tiles side by side in the patch): 16 lanes x 16 B per row, 4 rows per
     // instruction -- half as many separate DRAM bursts per 1-KiB output row as 128-byte segments
-    static_assert(NT % 2 == 0, "tiles are stored in pairs");
+    static_assert(NT % 2 == 0, "tiles are stored in pairs (bf16: in fours, the last group may be short)");
     constexpr int YB = SP == 3 ? 2 : 4;              // bytes per stored output element
+    // (bf16: FOUR tiles side by side in the patch, already as bf16 -- half the LDS write bytes, half the read-backs, and the same
+    //  256-byte row segments leave as 16 bytes per lane instead of 8: half the store instructions)
+    constexpr int LB = SP == 3 ? 16 : 4 * YB;         // bytes per lane of a row-segment store
     char *dst[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int64_t rr = row0 + (lane >> 4) + 4 * k;
-      dst[k] = (rr < M ? reinterpret_cast<char *>(a.Y) + rr * a.ldy * YB : reinterpret_cast<char *>(a.dump)) + (lane & 15) * 4 * YB;
+      dst[k] = (rr < M ? reinterpret_cast<char *>(a.Y) + rr * a.ldy * YB : reinterpret_cast<char *>(a.dump)) + (lane & 15) * LB;
     }
     float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
 #pragma unroll
@@ -412,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
           v[g].z = v[g].z > 0.f ? v[g].z : 0.f; v[g].w = v[g].w > 0.f ? v[g].w : 0.f;
         }
       }
-      if (ATT) {
+      if (ATT && !AMF) {
         f32x4 s4[4], d4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -433,26 +460,61 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
         asm volatile("" : "+v"(ps), "+v"(pd));
         pts[t] = ps; ptd[t] = pd;
       }
+      if constexpr (SP == 3) {
+        // Patch layout [32 rows][256 B]: 16-byte chunk c (8 columns) of row r lives at chunk c ^ (r & 15), and the two 8-byte halves
+        // of a chunk are swapped on rows with bit 3 set.  ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks:
+        // the 16 rows of a group then hit 16 distinct bank pairs (chunk' mod 8 twice, with different halves); the ds_read_b128 below
+        // is served in 16-lane groups that pair chunks {0-3, 12-15} of one row with {4-11} of the next (MI355X_MICROARCH.md): the
+        // XOR only permutes inside those sets (the rows of one instruction share the bits above 1), so the 256-byte pitch reads
+        // without conflicts too.
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        char *pb = reinterpret_cast<char *>(patch) + r * 256 + ((h ^ ((r >> 3) & 1)) << 3);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(patch + r * PP + (t & 1) * 32 + 8 * g + 4 * h) = v[g];
-      __builtin_amdgcn_sched_barrier(0);
-      if ((t & 1) && !(BGNN_DIAG && (a.dbg & 1))) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float4 v4 = *reinterpret_cast<const float4 *>(patch + ((lane >> 4) + 4 * k) * PP + (lane & 15) * 4);
-          if constexpr (SP == 3) {                       // 4 columns -> 4 bf16 = one 8-byte store
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            bf16x4 o;
-            o[0] = (__bf16)v4.x; o[1] = (__bf16)v4.y; o[2] = (__bf16)v4.z; o[3] = (__bf16)v4.w;
-            *reinterpret_cast<bf16x4 *>(dst[k] + (t - 1) * 32 * YB) = o;
-          } else {
-            *reinterpret_cast<float4 *>(dst[k] + (t - 1) * 32 * YB) = v4;
-          }
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+          o[0] = (__bf16)v[g].x; o[1] = (__bf16)v[g].y; o[2] = (__bf16)v[g].z; o[3] = (__bf16)v[g].w;
+          *reinterpret_cast<bf16x4 *>(pb + ((((t & 3) * 4 + g) ^ (r & 15)) << 4)) = o;
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (((t & 3) == 3 || t == NT - 1) && !(BGNN_DIAG && (a.dbg & 1))) {
+          constexpr int NCH = ((NT - 1) & 3) * 4 + 4;  // chunks per row in the LAST flush (NT = 2: 8 of the 16 lanes of a row store)
+          const bool full = (t & 3) == 3;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int row = (lane >> 4) + 4 * k;       // (row >> 3) & 1 == (k >> 1) & 1: the half swap is known at compile time
+            uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(patch) + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+            if ((k >> 1) & 1) q = make_uint4(q.z, q.w, q.x, q.y);
+            if (full || (lane & 15) < NCH) *reinterpret_cast<uint4 *>(dst[k] + (t & ~3) * 32 * YB) = q;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(patch + r * PP + (t & 1) * 32 + 8 * g + 4 * h) = v[g];
+        __builtin_amdgcn_sched_barrier(0);
+        if ((t & 1) && !(BGNN_DIAG && (a.dbg & 1))) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(patch + ((lane >> 4) + 4 * k) * PP + (lane & 15) * 4);
+            *reinterpret_cast<float4 *>(dst[k] + (t - 1) * 32 * YB) = v4;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    if (ATT) {
+    if constexpr (AMF) {
+      // lane (r, h): registers 0-3 = the hi parts of head 0-3's src (h = 0) / dst (h = 1) dot, registers 4-7 the lo parts
+      const int64_t row = row0 + r;
+      const int H = a.H;
+      if (row < M) {
+        const float d0 = acca[0] + acca[4] + cbv[0], d1 = acca[1] + acca[5] + cbv[1], d2 = acca[2] + acca[6] + cbv[2],
+                    d3 = acca[3] + acca[7] + cbv[3];
+        float *p = a.asd + row * 2 * H + h * H;
+        if (H == 4) *reinterpret_cast<float4 *>(p) = make_float4(d0, d1, d2, d3);
+        else { p[0] = d0; if (H > 1) p[1] = d1; if (H > 2) p[2] = d2; }
+      }
+    }
+    if (ATT && !AMF) {
       const int64_t row = row0 + r;
       const int H = a.H, tph = a.C / 32;
       for (int hd = 0; hd < H; ++hd) {
@@ -473,7 +535,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 
 template <int NT, bool ATT, int SP = 0, bool FRONT = false>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
-  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + 8 * 32 * 68 + 2 * NT * 32 + 64 + NT * 32) * 4;
+  constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + (SP == 3 && ATT ? 1024 : 0) + 8 * (SP == 3 ? 32 * 64 : 32 * 68) +
+                                        2 * NT * 32 + 64 + NT * 32) * 4;
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
   auto kern = gemm_wres64_kernel<NT, ATT, SP, FRONT>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
