@@ -721,6 +721,33 @@ def test_config3_bf16_storage_distance_to_float64(conn, gpu_device):
         json.dump(row, open(os.path.join(out_dir, f"config3_accuracy_{conn}.json"), "w"), indent=1)
 
 
+@pytest.mark.parametrize("num_layers", [2, 3])
+def test_bf16_front_gemm_short_models_ragged_tile(num_layers, gpu_device):
+    """The bf16 front GEMM forms the attention dots as an extra MFMA tile and stores through a four-tile bf16 patch.  Two layers: its
+    output feeds the 256 -> 64 and heads instances directly (nothing in between averages an error out); three: one 256 -> 256
+    instance.  Ragged tile: the last 32-row group is short (rows beyond the node count go to the dump row).  Against the float64
+    forward, within the bf16 bound; the exact path on the same model within 1e-4.  (One layer is refused: bf16 storage needs >= 2.)"""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, m, _ = synthetic.synthetic_tile(93, 71, 17, "V1")
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(num_layers=num_layers, seed=77), og.x, og.edge_index, og.edge_attr)
+    model = _model(sd, num_layers=num_layers)
+    g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
+    ref64 = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr, dtype=torch.float64)
+    _set_matrix_path("exact_f32")
+    e_exact = _fp64_distance(model.predict(g), ref64)
+    _set_matrix_path("bf16")
+    out = model.predict(g)
+    e_bf16 = _fp64_distance(out, ref64)
+    print("bf16 front, %d layer(s): exact max %.2e, bf16 max %.2e rms %.2e" % (num_layers, e_exact[0], e_bf16[0], e_bf16[1]))
+    assert e_exact[0] < TOL
+    assert torch.isfinite(out["class_logits"]).all()
+    # (BF16_LOGIT_BOUND is calibrated on |logit| <= 0.25; these heads give larger logits: scale it)
+    bound = BF16_LOGIT_BOUND * max(1.0, float(ref64["class_logits"].abs().max()) / 0.25)
+    assert e_bf16[0] < bound and e_bf16[1] < bound / 4, (e_bf16, bound)
+
+
 def test_config3_bf16_batch_properties(gpu_device):
     """bf16 storage through the per-batch entry: tiles of a batch are independent (permuting them permutes the outputs bit
     for bit), invalid cells are exactly 0, the grids equal predict()'s per-node results, and the node count is right."""
