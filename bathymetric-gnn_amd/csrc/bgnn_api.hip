@@ -724,6 +724,7 @@ static void graph_free(bgnn_graph *g) {
   P.release(g->d_node_id); P.release(g->d_cell_of_node);
   P.release(g->d_counts); P.release(g->d_x8); P.release(g->d_local_std); P.release(g->d_nbr);
   P.release(g->d_eattr); P.release(g->d_rowptr); P.release(g->d_edge_perm);
+  P.release(g->d_slope); P.release(g->d_node_depth); P.release(g->d_tile_dist); P.release(g->d_atlas_tile_of);
   P.release(g->d_atlas);
   delete g;
 }
@@ -918,8 +919,18 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
   GALLOC(g->d_x8, float, cells * 8)
   GALLOC(g->d_local_std, float, cells)
   GALLOC(g->d_nbr, int32_t, cells * g->K)
-  GALLOC(g->d_eattr, float, cells * g->K * g->ED)
+  // default edge feature list on a stencil the fused kernels know: compact edge storage (graph_build.hip, FeatureArgs)
+  g->compact_edges = g->ED == 3 && (g->K == 4 || g->K == 8 || g->K == 16) && opts->edge_features[0] == BGNN_EF_DISTANCE &&
+                     opts->edge_features[1] == BGNN_EF_DEPTH_DIFFERENCE && opts->edge_features[2] == BGNN_EF_SLOPE;
+  if (g->compact_edges) {
+    GALLOC(g->d_slope, float, cells * g->K)
+    GALLOC(g->d_node_depth, float, cells)
+    GALLOC(g->d_tile_dist, float4, g->n_tiles)
+  } else {
+    GALLOC(g->d_eattr, float, cells * g->K * g->ED)
+  }
   if (g->atlas_h) GALLOC(g->d_atlas, int32_t, (size_t)g->atlas_h * g->atlas_w)
+  if (g->atlas_h && g->compact_edges) GALLOC(g->d_atlas_tile_of, int32_t, (size_t)g->atlas_h * g->atlas_w)
 #undef GALLOC
   if (rc == BGNN_OK && !uniform) rc = ctx_upload(ctx, blockh.data(), blockh.size(), g->d_tables);
   if (rc == BGNN_OK && uniform && !hit) rc = ctx_upload(ctx, g->h_tiles.data(), sizeof(BgnnTileMeta) * g->n_tiles, g->d_tiles);

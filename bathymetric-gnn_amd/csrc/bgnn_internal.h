@@ -197,7 +197,15 @@ struct bgnn_graph {
   // the export, the edge counts, the generic aggregate and the non-attention backbones do -- and writing it was 32 (k = 8) / 64
   // (k = 16) of the feature kernel's 188 / 380 bytes per node
   mutable bool nbr_valid = false;
-  float *d_eattr = nullptr;           // grid: [rows][K][ED] ; generic: [E][ED]
+  // grid graphs with the default edge feature list are built COMPACT (graph_build.hip, FeatureArgs): slopes, node depths and the
+  // tiles' edge lengths; the fused layer kernels read those, d_eattr is expanded on demand (ensure_edge_attrs)
+  bool compact_edges = false;
+  mutable bool eattr_valid = false;
+  float *d_slope = nullptr;           // [rows][K]
+  float *d_node_depth = nullptr;      // [rows]
+  float4 *d_tile_dist = nullptr;      // [n_tiles]
+  int32_t *d_atlas_tile_of = nullptr; // canvas: grid index of every canvas cell (with d_atlas)
+  mutable float *d_eattr = nullptr;   // grid: [rows][K][ED] ; generic: [E][ED]
   int32_t *d_rowptr = nullptr;        // generic only [N+1]
   int32_t *d_edge_perm = nullptr;     // generic only
   int64_t n_nodes_host = -1;          // cached after a sync
@@ -240,7 +248,9 @@ struct ProfScope {
 int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts);
 int launch_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edge_attr, float *pos,
                         int64_t *valid_rows, int64_t *valid_cols, float *local_std, int64_t *batch);
-int ensure_stencil_table(const bgnn_graph *g);     // builds d_nbr of a grid graph if it has not been built yet (stream-ordered)
+int ensure_stencil_table(const bgnn_graph *g);
+    // builds d_nbr of a grid graph if it has not been built yet (stream-ordered)
+int ensure_edge_attrs(const bgnn_graph *g);      // full edge-attribute table of a compact graph, on demand (stream-ordered)
 int launch_graph_count_edges(bgnn_graph *g);
 int launch_graph_scatter(bgnn_graph *g, const float *node_values, float fill, float *grid);
 int launch_results_to_grids(bgnn_graph *g, const int64_t *cls, const float *conf, const float *corr,

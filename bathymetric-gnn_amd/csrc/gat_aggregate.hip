@@ -177,6 +177,7 @@ int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L,
   const int64_t max_rows = g->row_capacity;
   if (max_rows <= 0) return BGNN_OK;
   BGNN_TRY(ensure_stencil_table(g));
+  BGNN_TRY(ensure_edge_attrs(g));
   ProfScope ps(ctx, BGNN_K_AGGREGATE);
   AggArgs a{};
   a.xw = xw; a.asd = asd; a.nbr = g->d_nbr; a.eattr = g->d_eattr;

@@ -127,6 +127,7 @@ int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLay
                                const float *asd, float *out, int relu) {
   if (g->kind != 0 || (g->K != 4 && g->K != 8) || g->n_blocks2 <= 0) return BGNN_ERR_UNSUPPORTED;
   const int HC = L.heads * C;
+  BGNN_TRY(ensure_edge_attrs(g));
   TiledArgs a{};
   a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items2;
   a.tb.bh = g->bh2; a.tb.bw = g->bw2; a.tb.n_blocks = g->n_blocks2;

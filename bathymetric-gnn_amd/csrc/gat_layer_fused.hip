@@ -65,7 +65,11 @@ struct FusedArgs {
   const int32_t *cell_map; // ragged-batch canvas: original cell of each node (the grids are written through it); else nullptr
   const void *xw;         // [rows][HC]   this layer's lin(x): f32, or bf16 with SP = 3
   const float *asd;       // [rows][2H]
-  const float *eattr;     // [rows][K][3]
+  const float *eattr;     // [rows][K][3]   (persistent form only; the per-block kernels rebuild the attributes from the compact storage:)
+  const float *slope;     // [rows][K]      slope attribute of every stencil slot (graph_build.hip, FeatureArgs)
+  const float *node_depth;   // [rows]      depth of every node: depth difference = nan_to_num(depth[target] - depth[source])
+  const float4 *tile_dist;   // [n_tiles]   (|dx|, |dy|, diagonal) edge lengths of a tile's unit offsets
+  const int32_t *tile_of_cell;   // canvas walk: grid index of every canvas cell (else nullptr: the block's tile)
   const float *V;         // [H][3]
   const float *scale;     // [HC] folded bias + BatchNorm
   const float *shift;
@@ -152,6 +156,12 @@ template <int K, int HWID, int... B>
 __device__ __forceinline__ void halo_ids(uint32_t hid_lo, int (&nb)[K], std::integer_sequence<int, B...>) {
   using S = HaloSlot<K, HWID>;
   ((nb[B] = lds_read1i<S::rel(B) * 4>(hid_lo)), ...);
+}
+template <int K, int HWID, int... B>
+__device__ __forceinline__ void halo_depths(uint32_t hdp_lo, float (&ds)[K + 1], std::integer_sequence<int, B...>) {
+  using S = HaloSlot<K, HWID>;
+  ((ds[B] = lds_read1<S::rel(B) * 4>(hdp_lo)), ...);
+  ds[K] = lds_read1<S::MAXOFF * 4>(hdp_lo);                          // the cell's own depth
 }
 template <int H, int K, int HWID, int... B>
 __device__ __forceinline__ void halo_alpha_src(uint32_t has_lo, float (&hs)[K + 1], std::integer_sequence<int, B...>) {
@@ -498,7 +508,7 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   // (floats) past the four store patches, which start at image A, and past the 8 rows (128 floats) image A's last MFMA over-reads
   // (WDB: at the same offset from the slab image, i.e. inside W chunk buffer 0, which the last -- odd -- slab does not use)
   static constexpr int ATT_OFF = SLAB1 + 128 > 4 * 32 * TILED_PITCH ? SLAB1 + 128 : 4 * 32 * TILED_PITCH;
-  static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * H, RB = 2 * HC + (EPI == EPI_NEXT ? (ATT_LATE ? 0 : 2 * NC) : HEADW_LATE ? 0 : HEADW);
+  static constexpr int RA = HAS_IN_ALPHA ? 0 : HR * (H + 1), RB = 2 * HC + (EPI == EPI_NEXT ? (ATT_LATE ? 0 : 2 * NC) : HEADW_LATE ? 0 : HEADW);
   static constexpr int RSZ = RA > RB ? RA : RB;
   // ODD pitch (in dwords): the gather reads one coefficient per cell with ds_read_b32, whose 32-lane groups bank on (a / 4) mod 32 --
   // with the round-2 pitch of 36 dwords the 32 cells of a group fell on 8 banks (4-way conflict on every coefficient read)
@@ -506,7 +516,7 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   // attention coefficients: [128 cells][APITCH] f32 (sparse, every head); bf16 storage path: the CURRENT head's coefficients as
   // four wave-private dense [32 cells][window rows] bf16 matrices (the aggregation's MFMA B operand) -- see AggWindow
   static constexpr int ALPHA = SP == 3 ? 4 * 32 * AggWindow<K>::PITCH / 4 : 128 * APITCH;
-  static_assert(!HAS_IN_ALPHA || HR * H + (HID_IN_ALPHA ? HR : 0) <= ALPHA, "the alpha_src table (and the halo ids) fit the dense-alpha region");
+  static_assert(!HAS_IN_ALPHA || HR * (H + 1) + (HID_IN_ALPHA ? HR : 0) <= ALPHA, "the alpha_src and depth tables (and the halo ids) fit the dense-alpha region");
   static_assert(!DBUF || (4 * 32 * TILED_PITCH <= ATT_OFF && ATT_OFF + 2 * NC <= SLAB), "patches | att vectors share the slab region");
   static_assert(!WDB || (4 * 32 * TILED_PITCH <= ATT_OFF && ATT_OFF + 2 * NC <= SLAB + WBUF / 2), "patches | att vectors fit slab + W chunk buffer 0");
   static_assert(!HEADW_LATE || HEADW <= SLAB, "the heads' weight table fits the slab region");
@@ -555,7 +565,8 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   int *minid = cid + (Lds::HID_IN_ALPHA ? 128 : HR);   // [4]
   float *alx = reinterpret_cast<float *>(minid + 4) + Lds::ALIGN;   // [128][APITCH]  alpha[cell][head][K+1]; bf16 path: dense (AggWindow)
   float *has = Lds::HAS_IN_ALPHA ? alx : rreg;         // [HR][H]   (phase A; bf16 path: inside the not yet written dense-alpha region)
-  int *hid = Lds::HID_IN_ALPHA ? reinterpret_cast<int *>(alx + HR * H) : reinterpret_cast<int *>(rreg + RSZ);   // [HR]
+  float *hdp = has + HR * H;                           // [HR]      depth of the halo rows' nodes (phase A: depth differences)
+  int *hid = Lds::HID_IN_ALPHA ? reinterpret_cast<int *>(alx + HR * (H + 1)) : reinterpret_cast<int *>(rreg + RSZ);   // [HR]
 
 #if BGNN_DIAG
   unsigned long long t_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -624,7 +635,11 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   const int gr_h = pos.r0 + hr_t - RAD, gc_h = pos.c0 + hc_t - RAD;
   const int gr_m = pos.r0 + tr, gc_m = pos.c0 + tc;
   const int raw_h = node_at(cell_index(gr_h, gc_h));
-  const int raw_m = node_at(cell_index(gr_m, gc_m));
+  const uint32_t cell_m = cell_index(gr_m, gc_m);
+  const int raw_m = node_at(cell_m);
+  // whose edge lengths: the block's tile, or (canvas walk) the grid this cell belongs to -- a canvas array read beside the ids
+  int tile_m = pos.tile;
+  if (a.tile_of_cell) tile_m = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.tile_of_cell) + (cell_m << 2));
   // DMA piece p moves chunk (p * NTH + tid) % CPR of halo row (p * NTH + tid) / CPR: the row advances by NTH / CPR per piece
   static_assert(NTH % CPR == 0, "pieces advance by whole halo rows");
   constexpr int RSTEP = NTH / CPR, RSTEP_R = RSTEP / HW_, RSTEP_C = RSTEP % HW_;
@@ -686,9 +701,15 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // Round 2, complete BEFORE slab 0's DMA is queued (hipcc only ever waits vmcnt(0) with an LDS-DMA in flight): alpha_src of
   // this thread's halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...).  Unconditional as well:
   // rows without a node read row 0 and are masked afterwards.
-  float eraw[K * 3], adv[NHL], hasv[H];
+  // Edge attributes come COMPACT (graph_build.hip, FeatureArgs): the K slopes of the own node, the node depths of the halo rows
+  // (depth difference = one float32 subtraction, as the feature kernel takes it) and the three edge lengths of the tile -- a third
+  // of the bytes and registers of the [K][3] block this round used to load (k = 16: 64 + 4 + 16 instead of 192 bytes per node).
+  float eraw[K], adv[NHL], hasv[H], hdep;
+  float4 tdist;
   {
     const uint64_t hrow = (uint32_t)(hid_v >= 0 ? hid_v : 0), mrow = (uint32_t)(my_pre >= 0 ? my_pre : 0);   // (zero-extended: one v_mad_u64_u32 each)
+    hdep = a.node_depth[hrow];
+    tdist = a.tile_dist[tile_m];
     if constexpr (H % 4 == 0) {
 #pragma unroll
       for (int q = 0; q < H / 4; ++q) {
@@ -699,9 +720,9 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
       for (int hh = 0; hh < H; ++hh) hasv[hh] = a.asd[hrow * 2 * H + hh];
     }
-    const float4 *ep = reinterpret_cast<const float4 *>(a.eattr + mrow * K * 3);
+    const float4 *ep = reinterpret_cast<const float4 *>(a.slope + mrow * K);
 #pragma unroll
-    for (int i = 0; i < K * 3 / 4; ++i) {
+    for (int i = 0; i < K / 4; ++i) {
       const float4 q = ep[i];
       eraw[4 * i] = q.x; eraw[4 * i + 1] = q.y; eraw[4 * i + 2] = q.z; eraw[4 * i + 3] = q.w;
     }
@@ -770,6 +791,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     hid[tid] = hid_v;
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hid_v >= 0 ? hasv[hh] : -__builtin_inff();   // (-inf: an absent source drops out of the softmax)
+    hdp[tid] = hid_v >= 0 ? hdep : 0.0f;
   }
   if (Lds::HID_IN_ALPHA && hl == 0) cid[cell] = my_pre < 0 ? -1 : my_pre;
   {   // (phase A's register operands are complete as well before the DMA is queued: no wait behind it later)
@@ -778,9 +800,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
     for (int i = 0; i < NHL; ++i) sink += adv[i];
 #pragma unroll
-    for (int i = 0; i < K * 3; ++i) sink += eraw[i];
+    for (int i = 0; i < K; ++i) sink += eraw[i];
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) sink += hasv[hh];
+    sink += hdep + tdist.x + tdist.y + tdist.z;
     asm volatile("" ::"v"(sink));
   }
   BGNN_STAMP(11)   // round 2 arrived, halo tables written
@@ -829,9 +852,11 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         const int hh = hl + i * 2 < H ? hl + i * 2 : 0;
         halo_alpha_src<H, K, HW_>(has0 + (uint32_t)((self_a - S::MAXOFF) * H + hh) * 4u, hs[i], std::make_integer_sequence<int, K>{});
       }
+      float dsrc[K + 1];
+      halo_depths<K, HW_>(lds_addr(hdp) + (uint32_t)(self_a - S::MAXOFF) * 4u, dsrc, std::make_integer_sequence<int, K>{});
       lds_reads_done();
       EdgeTerms<K> et;
-      edge_terms<K>(nb, eraw, et);
+      edge_terms_compact<K>(nb, eraw, dsrc, tdist.x, tdist.y, tdist.z, et);
       if constexpr (NHL == 2 && H % 2 == 0 && H >= 4) {
         attention_head_pair<K, false>(et, hs[0], hs[1], adv[0], adv[1], vpre[0], vpre[1], part[0], part[1]);
       } else {
@@ -1753,19 +1778,22 @@ static int launch_by_stencil(bgnn_ctx *ctx, const bgnn_graph *g, int sp, const F
 }
 
 static bool fused_supported(const bgnn_graph *g, int C, int ED) {
-  return g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->n_blocks3 > 0 && C == 64 && ED == 3 && g->max_w <= 8192;
+  // (compact_edges: the default edge feature list -- another list of three runs on the unfused kernels, from the full table)
+  return g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->n_blocks3 > 0 && C == 64 && ED == 3 && g->max_w <= 8192 &&
+         g->compact_edges;
 }
 
 static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, const void *xw, const float *asd, int relu) {
   a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items3;
   a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
-  a.node_id = g->d_node_id; a.cell_map = nullptr;
+  a.node_id = g->d_node_id; a.cell_map = nullptr; a.tile_of_cell = nullptr;
   if (g->d_atlas) {                  // ragged batch: walk the shelf-packed canvas (one "tile") instead of per-grid blocks
     a.tb.tiles = g->d_atlas_tile; a.tb.items2 = nullptr;
     a.tb.bh = g->atlas_h / 8; a.tb.bw = g->atlas_w / 16; a.tb.n_blocks = a.tb.bh * a.tb.bw;
-    a.node_id = g->d_atlas; a.cell_map = g->d_cell_of_node;
+    a.node_id = g->d_atlas; a.cell_map = g->d_cell_of_node; a.tile_of_cell = g->d_atlas_tile_of;
   }
   a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
+  a.slope = g->d_slope; a.node_depth = g->d_node_depth; a.tile_dist = g->d_tile_dist;
   a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
   a.dbg = BGNN_DIAG ? g->ctx->opts.diag_mask : 0;
   a.stamps = BGNN_DIAG && g->ctx->opts.diag_stamps ? g->ctx->stamps : nullptr;
@@ -1791,7 +1819,11 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   // big uniform batches on the exact path: the persistent form of the 256 -> 256 instance (bit-identical results)
   if (split == 0 && HC == 256 && NC == 256 && C == 64 && (g->K == 8 || g->K == 4) && g->uni_h && !g->d_atlas && ctx->opts.fused_persistent &&
       a.tb.n_blocks >= 8 * ctx->num_cus)
+  {
+    BGNN_TRY(ensure_edge_attrs(g));                 // (the persistent form DMAs the full [K][3] blocks into LDS)
+    a.eattr = g->d_eattr;
     return g->K == 8 ? launch_persist<8>(ctx, a, g->uni_h, g->uni_w) : launch_persist<4>(ctx, a, g->uni_h, g->uni_w);
+  }
 #define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
   BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
 #undef BGNN_FUSED_CASE

@@ -278,6 +278,37 @@ __device__ __forceinline__ void edge_terms(const int (&nb)[K], const float (&era
   for (int f = 0; f < 3; ++f) t.mean[f] = sum[f] * rc;
 }
 
+// the same terms from the COMPACT edge storage (graph_build.hip, FeatureArgs): slot b's attributes are (length of its offset,
+// nan_to_num(depth[target] - depth[source]), slope) -- the length is one of the tile's three unit lengths (x, y, diagonal), exactly
+// doubled for a dilated slot; the depth difference is the float32 subtraction the feature kernel takes.  Bit for bit the values
+// of the full table, in the same summation order.
+template <int K>
+__device__ __forceinline__ void edge_terms_compact(const int (&nb)[K], const float (&slope)[K], const float (&dsrc)[K + 1], float len_x,
+                                                   float len_y, float len_d, EdgeTerms<K> &t) {
+  using Off = StencilOffsets<K>;
+  float sum[3] = {0.f, 0.f, 0.f};
+  int deg = 0;
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    constexpr float FMAX = 3.4028234663852886e38f;
+    const int adr = Off::dr[b] < 0 ? -Off::dr[b] : Off::dr[b], adc = Off::dc[b] < 0 ? -Off::dc[b] : Off::dc[b];
+    const float unit = adc == 0 ? len_y : adr == 0 ? len_x : len_d;
+    const float len = (adr > 1 || adc > 1) ? unit + unit : unit;
+    const float dz = dsrc[K] - dsrc[b];
+    const float dzc = __builtin_fminf(__builtin_fmaxf(dz, -FMAX), FMAX);       // np.nan_to_num: +-inf -> +-FLT_MAX ...
+    t.present[b] = nb[b] >= 0;
+    t.e[b][0] = t.present[b] ? len : 0.0f;
+    t.e[b][1] = t.present[b] ? (dz != dz ? 0.0f : dzc) : 0.0f;                  // ... NaN -> 0
+    t.e[b][2] = slope[b];                                                      // (0 where the source is absent: written so)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) sum[f] += t.e[b][f];
+    deg += t.present[b] ? 1 : 0;
+  }
+  const float rc = __builtin_amdgcn_rcpf((float)(deg > 0 ? deg : 1));
+#pragma unroll
+  for (int f = 0; f < 3; ++f) t.mean[f] = sum[f] * rc;
+}
+
 __device__ __forceinline__ float leaky02(float x) {
   float r;
   const float y = 0.2f * x;

@@ -454,12 +454,34 @@ struct FeatureArgs {
   float *x8;
   float *node_local_std;
   int32_t *nbr;
-  float *eattr;
+  float *eattr;           // [rows][K][ED], or nullptr: COMPACT edge storage (below)
+  // compact edge storage (the default edge feature list [distance, depth_difference, slope], K = 4 / 8 / 16): of a node's K x 3
+  // attributes only the slopes are stored -- the distance of slot b depends on the tile's resolution alone (tile_dist: the lengths
+  // of the x, y and diagonal unit offsets; a dilated slot is exactly twice its unit slot) and the depth difference is one float32
+  // subtraction of two node depths.  The fused layer kernels rebuild the attributes from these (bit for bit); the full table is
+  // expanded on demand (ensure_edge_attrs) for the export and the unfused kernels.
+  float *slope;           // [rows][K]
+  float *node_depth;      // [rows]
+  float4 *tile_dist;      // [n_tiles]  (|dx|, |dy|, diagonal, 0) as float32
   int F;
   int feat_ids[8];
   int ED;
   int edge_ids[4];
 };
+
+// length of stencil offset (dr, dc) at resolution (rx, ry), as the float32 edge attribute (graph_construction.py:340-352)
+__device__ __forceinline__ double edge_length(int dr, int dc, double rx, double ry) {
+  const double dx = (double)dc * rx;                   // (tgt_c - src_c) * res_x
+  const double dy = (double)dr * ry;
+  return sqrt(dx * dx + dy * dy);
+}
+__device__ __forceinline__ float edge_length_f32(double d) { return (d != d) ? 0.0f : (float)d; }
+__device__ __forceinline__ void write_tile_dist(const FeatureArgs &a, const BgnnWorkItem &it, const BgnnTileMeta &t) {
+  // (every workgroup of the tile's first row band writes the same three values)
+  if (a.tile_dist && threadIdx.x == 0 && it.r0 == 0)
+    a.tile_dist[it.tile] = make_float4(edge_length_f32(edge_length(0, -1, t.rx, t.ry)), edge_length_f32(edge_length(-1, 0, t.rx, t.ry)),
+                                       edge_length_f32(edge_length(-1, -1, t.rx, t.ry)), 0.0f);
+}
 
 __device__ __forceinline__ float filled_at(const FeatureArgs &a, int64_t i) {
   // depth_filled = nan_to_num(where(valid, depth, local_mean), nan=0)   (:281-282)
@@ -477,11 +499,8 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
   const int ncell = it.nr * w;
   // the length of stencil offset b depends on the tile's resolution only: once per workgroup instead of a float64 sqrt per edge
   __shared__ double s_dist[16];
-  if ((int)threadIdx.x < st.K && threadIdx.x < 16) {
-    const double dx = (double)st.dc[threadIdx.x] * t.rx;       // (tgt_c - src_c) * res_x
-    const double dy = (double)st.dr[threadIdx.x] * t.ry;
-    s_dist[threadIdx.x] = sqrt(dx * dx + dy * dy);
-  }
+  if ((int)threadIdx.x < st.K && threadIdx.x < 16) s_dist[threadIdx.x] = edge_length(st.dr[threadIdx.x], st.dc[threadIdx.x], t.rx, t.ry);
+  write_tile_dist(a, it, t);
   __syncthreads();
   for (int li = threadIdx.x; li < ncell; li += blockDim.x) {
     const int r = it.r0 + li / w, c = li % w;
@@ -543,6 +562,7 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
     a.node_local_std[id] = nan_to_num_f32(lstd);
     // ---- in-edges: slot b <- source cell (r - dr[b], c - dc[b])  (:196-223, :329-376) ----
     const float dz_tgt = a.depth[idx];
+    if (a.node_depth) a.node_depth[id] = dz_tgt;
     auto edge_slot = [&](int b, int &sid, float (&ev)[4]) {
       const int sr = r - st.dr[b], sc = c - st.dc[b];
       sid = -1;
@@ -575,6 +595,7 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
       constexpr int KK = decltype(kk)::value;
       int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * KK);
       float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * (3 * KK));
+      float4 *sp = reinterpret_cast<float4 *>(a.slope + (int64_t)id * KK);
 #pragma unroll 1
       for (int half = 0; half < KK / 8; ++half) {
         int sids[8];
@@ -589,8 +610,13 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
 #pragma unroll
           for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
         }
+        if (a.eattr) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+          for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+        } else {                                         // compact: the slopes (attribute 2 of the default list) only
+#pragma unroll
+          for (int q = 0; q < 2; ++q) sp[half * 2 + q] = make_float4(evs[12 * q + 2], evs[12 * q + 5], evs[12 * q + 8], evs[12 * q + 11]);
+        }
       }
     };
     if constexpr (KV != 0) {
@@ -601,7 +627,8 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
         float ev[4];
         edge_slot(b, sid, ev);
         if (a.nbr) a.nbr[(int64_t)id * st.K + b] = sid;
-        for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f];
+        if (a.eattr) { for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f]; }
+        else a.slope[(int64_t)id * st.K + b] = ev[2];
       }
     }
   }
@@ -643,10 +670,8 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
   const int h = t.h, w = t.w;
   const int64_t tb = t.cell_off;
   const int tid = threadIdx.x;
-  if (tid < KV) {
-    const double dx = (double)st.dc[tid] * t.rx, dy = (double)st.dr[tid] * t.ry;
-    s_dist[tid] = sqrt(dx * dx + dy * dy);
-  }
+  if (tid < KV) s_dist[tid] = edge_length(st.dr[tid], st.dc[tid], t.rx, t.ry);
+  write_tile_dist(a, it, t);
   // slope of the edge source -> target with depth difference dz = depth[target] - depth[source], exactly as the form above
   auto slope_of = [&](float dz, double dist) -> float {
     double slope = 0.0;
@@ -760,8 +785,10 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
         xp[0] = make_float4(xo[0], xo[1], xo[2], xo[3]);
         xp[1] = make_float4(xo[4], xo[5], xo[6], xo[7]);
         a.node_local_std[id] = nan_to_num_f32(lstd);
+        if (a.node_depth) a.node_depth[id] = dz_tgt;
         int4 *np = reinterpret_cast<int4 *>(a.nbr + (int64_t)id * KV);
         float4 *ep = reinterpret_cast<float4 *>(a.eattr + (int64_t)id * (3 * KV));
+        float4 *sp = reinterpret_cast<float4 *>(a.slope + (int64_t)id * KV);
 #pragma unroll 1
         for (int half = 0; half < KV / 8; ++half) {
           int sids[8];
@@ -808,8 +835,13 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
 #pragma unroll
             for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
           }
+          if (a.eattr) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+            for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) sp[half * 2 + q] = make_float4(evs[12 * q + 2], evs[12 * q + 5], evs[12 * q + 8], evs[12 * q + 11]);
+          }
         }
       }
     }
@@ -941,8 +973,10 @@ static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_
 }
 
 // canvas cell of every grid cell: atlas[(row0 + r) * AW + col0 + c] = node id (gutters / free space stay -1)
+// (atlas_tile: the grid a canvas cell belongs to -- the fused kernels look the grid's edge lengths up by it; cleared to 0 beforehand,
+//  so that every canvas cell holds a valid grid index)
 __global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *pos, int atlas_w,
-                                                         const int32_t *node_id, int64_t cells, int32_t *atlas) {
+                                                         const int32_t *node_id, int64_t cells, int32_t *atlas, int32_t *atlas_tile) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= cells) return;
   const int id = node_id[i];
@@ -950,7 +984,38 @@ __global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *til
   const int t = find_tile(tiles, n_tiles, i);
   const BgnnTileMeta tm = tiles[t];
   const int rel = (int)(i - tm.cell_off), r = rel / tm.w, c = rel - r * tm.w;
-  atlas[(int64_t)(pos[2 * t] + r) * atlas_w + pos[2 * t + 1] + c] = id;
+  const int64_t at = (int64_t)(pos[2 * t] + r) * atlas_w + pos[2 * t + 1] + c;
+  atlas[at] = id;
+  if (atlas_tile) atlas_tile[at] = t;
+}
+
+// full edge-attribute table of a compact graph, on demand: attrs[node][b] = (length of slot b, nan_to_num(depth[node] - depth[source]),
+// slope[node][b]) where the source exists, zeros elsewhere -- the values the feature kernels write in their non-compact mode
+__global__ __launch_bounds__(256) void expand_edge_attrs_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *node_id, int64_t cells,
+                                                                Stencil st, const float *slope, const float *node_depth, float *eattr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cells) return;
+  const int id = node_id[i];
+  if (id < 0) return;
+  const BgnnTileMeta t = tiles[find_tile(tiles, n_tiles, i)];
+  const int li = (int)(i - t.cell_off), r = li / t.w, c = li - r * t.w;
+  const float dz_tgt = node_depth[id];
+  for (int b = 0; b < st.K; ++b) {
+    const int sr = r - st.dr[b], sc = c - st.dc[b];
+    int sid = -1;
+    if (sr >= 0 && sr < t.h && sc >= 0 && sc < t.w) {
+      sid = node_id[(int64_t)t.cell_off + (int64_t)sr * t.w + sc];
+      if (sid < 0) sid = -1;
+    }
+    float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+    if (sid >= 0) {
+      e0 = edge_length_f32(edge_length(st.dr[b], st.dc[b], t.rx, t.ry));
+      e1 = nan_to_num_f32(dz_tgt - node_depth[sid]);
+      e2 = slope[(int64_t)id * st.K + b];
+    }
+    float *e = eattr + ((int64_t)id * st.K + b) * 3;
+    e[0] = e0; e[1] = e1; e[2] = e2;
+  }
 }
 
 // stencil id table on demand: nbr[node][b] = node id of the cell at -offset[b] (the SOURCE of the block-b in-edge), -1 if absent --
@@ -985,6 +1050,22 @@ int ensure_stencil_table(const bgnn_graph *g) {
   return BGNN_OK;
 }
 
+int ensure_edge_attrs(const bgnn_graph *g) {
+  if (g->kind != 0 || !g->compact_edges || g->eattr_valid || g->total_cells <= 0) return BGNN_OK;
+  bgnn_ctx *ctx = g->ctx;
+  if (!g->d_eattr) {
+    void *p = nullptr;
+    BGNN_TRY(ctx->pool.alloc((size_t)g->total_cells * g->K * 3 * sizeof(float), &p));
+    g->d_eattr = (float *)p;
+  }
+  const Stencil st = make_stencil(g->K);
+  hipLaunchKernelGGL(expand_edge_attrs_kernel, dim3((unsigned)((g->total_cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles,
+                     g->n_tiles, g->d_node_id, (int64_t)g->total_cells, st, g->d_slope, g->d_node_depth, g->d_eattr);
+  BGNN_HIP_CHECK(hipGetLastError());
+  g->eattr_valid = true;
+  return BGNN_OK;
+}
+
 int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts) {
   const Stencil st = make_stencil(opts->connectivity);
   const int64_t cells = g->total_cells;
@@ -1005,8 +1086,9 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
   }
   if (g->d_atlas) {
     BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas, 0xff, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
+    if (g->d_atlas_tile_of) BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas_tile_of, 0, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(atlas_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles, g->n_tiles,
-                       g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas);
+                       g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas, g->d_atlas_tile_of);
   }
   // 2. box statistics
   double *vs, *vc, *vq;
@@ -1037,7 +1119,8 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     a.tiles = g->d_tiles; a.items = g->d_items; a.depth = tiles->depth; a.mask = tiles->mask;
     a.unc = tiles->uncertainty; a.local_mean = lmean; a.local_std = lstd; a.node_id = g->d_node_id;
     a.x8 = g->d_x8; a.node_local_std = g->d_local_std; a.nbr = nullptr; a.eattr = g->d_eattr;    // (stencil id table: on demand)
-    g->nbr_valid = false;
+    a.slope = g->d_slope; a.node_depth = g->d_node_depth; a.tile_dist = g->d_tile_dist;            // (compact: d_eattr is null here)
+    g->nbr_valid = false; g->eattr_valid = !g->compact_edges;
     a.F = g->F; a.ED = g->ED;
     // final column list: requested features (uncertainty skipped when absent), then
     // uncertainty appended when given and not listed (:288-316)
@@ -1090,6 +1173,7 @@ int launch_graph_export(bgnn_graph *g, float *x, int64_t *edge_index, float *edg
   }
   if (edge_index || edge_attr) {
     BGNN_TRY(ensure_stencil_table(g));
+    if (edge_attr) BGNN_TRY(ensure_edge_attrs(g));
     const int KS = g->K + (g->include_self_loops ? 1 : 0);
     EdgeValue ev{g->d_tiles, g->n_tiles, g->K, KS, g->d_node_id, g->d_nbr};
     const int64_t n = (int64_t)g->total_cells * KS;
