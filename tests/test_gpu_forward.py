@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from _calibration import assert_mixed, calibrate_heads
+from conftest import ulp_diff_f32
 from oracle import gat_cpu, graph_cpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -970,3 +971,49 @@ def test_edge_dim_none_gatconv_without_edge_features(gpu_device):
     sd3 = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og.x, og.edge_index, og.edge_attr)
     ref3 = gat_cpu.predict(sd3, og.x, og.edge_index, og.edge_attr)
     assert (ref3["confidence"] - ref["confidence"]).abs().max().item() > 1e-3
+
+
+def test_compact_edge_storage_against_the_full_table(gpu_device):
+    """Graphs with the default edge feature list are built COMPACT (slopes + node depths + tile edge lengths; the fused kernels
+    rebuild the attributes).  (i) After a fused forward, the attribute table expanded on demand for the export equals the oracle's
+    edge_attr bit for bit -- NaN / inf / nodata depths inside the mask included, two resolutions, the dilated stencil; (ii) a
+    PERMUTED edge feature list is built with the full table and runs on the unfused kernels: same 1e-4 bar against the oracle with
+    the same permutation."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    rng = np.random.default_rng(5)
+    for conn, res in (("8-connected", (0.5, 2.0)), ("16-dilated", (3.0, 0.25)), ("4-connected", (1.0, 1.0))):
+        d, m, _ = synthetic.synthetic_tile(45, 70, 9, "V1")
+        d = d.copy()
+        wild = rng.random(d.shape) < 0.01
+        d[wild & m] = rng.choice(np.array([np.inf, -np.inf, 3.0e38, -3.0e38], np.float32), int((wild & m).sum()))
+        og = graph_cpu.build_graph(d, m, None, res, connectivity=conn)
+        g = GraphBuilder(connectivity=conn).build_graph(d, m, None, res)
+        sd = synthetic.synthetic_state_dict(seed=3)
+        model = _model(sd)
+        out = model.predict(g)                                   # fused kernels (compact storage) first ...
+        ea = g.edge_attr.cpu().numpy()                           # ... then the table, expanded on demand
+        assert np.array_equal(g.edge_index.cpu().numpy(), og.edge_index)
+        assert ulp_diff_f32(ea[:, :2], og.edge_attr[:, :2]).max() == 0 and ulp_diff_f32(ea[:, 2], og.edge_attr[:, 2]).max() <= 1
+        assert out["class_logits"].shape[0] == og.x.shape[0]
+        # the attributes the fused kernels REBUILT (huge / non-finite depth differences included) against the unfused kernels,
+        # which read the expanded table: same logits, NaN where either has NaN
+        from bathymetric_gnn_amd import runtime as rt
+        ctx = rt.get_context(gpu_device)
+        ctx.set_option("fused", 0)
+        try:
+            ref = model.predict(g)
+        finally:
+            ctx.set_option("fused", 1)
+        # (depths of 3e38 make logits of ~1e36: the two kernel families sum in different orders, so the comparison is relative)
+        a_, b_ = out["class_logits"], ref["class_logits"]
+        assert torch.equal(torch.isfinite(a_), torch.isfinite(b_))
+        ok = torch.isfinite(a_)
+        assert ((a_[ok] - b_[ok]).abs() / (b_[ok].abs() + 1.0)).max().item() < 1e-3
+    d, m, _ = synthetic.synthetic_tile(64, 48, 12, "V1")
+    ef = ["slope", "distance", "depth_difference"]
+    og = graph_cpu.build_graph(d, m, None, (0.5, 0.5), edge_feature_names=ef)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=8), og.x, og.edge_index, og.edge_attr)
+    model = _model(sd)
+    g = GraphBuilder(edge_features=ef).build_graph(d, m, None, (0.5, 0.5))
+    _compare(model.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
