@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   //   round 1: node id of this thread's halo row (HR <= NTH: one row per thread), of this lane's own cell, and of
   //            the <= NPIECE halo rows whose chunks this thread moves by DMA (CPR lanes share a row);
   //   -> slab 0's DMA is issued straight from those registers (no LDS round trip, no barrier);
-  //   round 2: alpha_src of the halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...)
+  //   round 2: alpha_src and node depth of the halo row; the own node's K slopes, alpha_dst (heads hl, hl + 2, ...) and the tile's edge lengths
   //            -- consumed in phase A, so their latency hides behind the halo bookkeeping.
   static_assert(HR <= NTH, "one halo row per thread");
   constexpr int NHL = (H + 1) / 2;                      // heads per lane
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     }
   }
   // Round 2, complete BEFORE slab 0's DMA is queued (hipcc only ever waits vmcnt(0) with an LDS-DMA in flight): alpha_src of
-  // this thread's halo row; the own node's edge-attribute block and alpha_dst (heads hl, hl + 2, ...).  Unconditional as well:
+  // this thread's halo row (and its node's depth); the own node's slopes and alpha_dst (heads hl, hl + 2, ...).  Unconditional as well:
   // rows without a node read row 0 and are masked afterwards.
   // Edge attributes come COMPACT (graph_build.hip, FeatureArgs): the K slopes of the own node, the node depths of the halo rows
   // (depth difference = one float32 subtraction, as the feature kernel takes it) and the three edge lengths of the tile -- a third
