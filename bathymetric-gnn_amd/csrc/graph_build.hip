@@ -334,6 +334,23 @@ __global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles,
   }
 }
 
+// finalisation of one cell: (sums / 5.0) * 25.0 -> mean, std in float64, then float32 (graph_construction.py:408-432).  Taken by the
+// horizontal pass as it writes a chunk out (it used to be a launch of its own over three float64 arrays written and read back:
+// 48 B per cell and one launch -- of a dozen per ragged batch -- less)
+__device__ __forceinline__ void stats_finalise(double hs, double hn, double hq2, float *local_mean, float *local_std, int64_t i) {
+  // uniform_filter(...) * 25.0   (:408-425)
+  const double sum_vals = (hs / 5.0) * 25.0;
+  const double count = (hn / 5.0) * 25.0;
+  const double sum_sq = (hq2 / 5.0) * 25.0;
+  const double safe = count > 1.0 ? count : 1.0;       // np.maximum(count, 1.0)
+  const double mean = sum_vals / safe;
+  const double mean_sq = sum_sq / safe;
+  double var = mean_sq - mean * mean;
+  var = var > 0.0 ? var : 0.0;                          // np.maximum(variance, 0.0) (NaN -> NaN in numpy; inputs finite)
+  local_mean[i] = (float)mean;
+  local_std[i] = (float)sqrt(var);
+}
+
 constexpr int STAT_CH = 16;
 
 // horizontal pass: 64 rows per 256-thread workgroup.  Outputs are produced in chunks of 16 columns (l = 1 + chunk + j); the
@@ -341,7 +358,7 @@ constexpr int STAT_CH = 16;
 // row), divided by 5.0 there and handed to the row's thread (wave 0) through a double-buffered LDS tile; the raw horizontal
 // sums go back the same way, so both directions are coalesced and nothing but the additions is left on the serial chain.
 __global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
-                                                      const double *vq, double *hs, double *hn, double *hq2) {
+                                                      const double *vq, float *local_mean, float *local_std) {
   constexpr int P = STAT_CH + 1;                       // pitch in doubles: (34 r) mod 64 banks are distinct over 32 lanes
   __shared__ double tile[2][3][64 * P];
   const BgnnTileMeta t = tiles[blockIdx.y];
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles,
       s += a; n += b; q += d;
       hv[2 - c] = a; hc[2 - c] = b; hq[2 - c] = d;
     }
-    if (tid < nrow) { hs[base] = s; hn[base] = n; hq2[base] = q; }
+    if (tid < nrow) stats_finalise(s, n, q, local_mean, local_std, base);
   }
   int buf = 0;
   for (int l0 = 1; l0 < w; l0 += STAT_CH, buf ^= 1) {
@@ -408,28 +425,10 @@ __global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles,
       const int rr = lr + 16 * k, cc = l0 + lc;
       if (rr < nrow && cc < w) {
         const int64_t o = base0 + (int64_t)rr * w + cc;
-        hs[o] = tl[0][rr * P + lc]; hn[o] = tl[1][rr * P + lc]; hq2[o] = tl[2][rr * P + lc];
+        stats_finalise(tl[0][rr * P + lc], tl[1][rr * P + lc], tl[2][rr * P + lc], local_mean, local_std, o);
       }
     }
   }
-}
-
-// finalisation, one thread per cell: (sums / 5.0) * 25.0 -> mean, std in float64, then float32 (graph_construction.py:408-432)
-__global__ __launch_bounds__(256) void stats_final_kernel(const double *hs, const double *hn, const double *hq2, int64_t cells,
-                                                          float *local_mean, float *local_std) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= cells) return;
-  // uniform_filter(...) * 25.0   (:408-425)
-  const double sum_vals = (hs[i] / 5.0) * 25.0;
-  const double count = (hn[i] / 5.0) * 25.0;
-  const double sum_sq = (hq2[i] / 5.0) * 25.0;
-  const double safe = count > 1.0 ? count : 1.0;       // np.maximum(count, 1.0)
-  const double mean = sum_vals / safe;
-  const double mean_sq = sum_sq / safe;
-  double var = mean_sq - mean * mean;
-  var = var > 0.0 ? var : 0.0;                          // np.maximum(variance, 0.0) (NaN -> NaN in numpy; inputs finite)
-  local_mean[i] = (float)mean;
-  local_std[i] = (float)sqrt(var);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1095,7 +1094,7 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
   float *lmean, *lstd;
   {
     void *p;
-    BGNN_TRY(ctx_workspace(ctx, 0, (size_t)cells * sizeof(double) * 6, &p));
+    BGNN_TRY(ctx_workspace(ctx, 0, (size_t)cells * sizeof(double) * 3, &p));
     vs = (double *)p; vc = vs + cells; vq = vc + cells;
     BGNN_TRY(ctx_workspace(ctx, 1, (size_t)cells * sizeof(float) * 2, &p));
     lmean = (float *)p; lstd = lmean + cells;
@@ -1106,11 +1105,8 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     ProfScope ps(ctx, BGNN_K_STATS);
     hipLaunchKernelGGL(stats_v_kernel, dim3((max_w + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
                        tiles->depth, tiles->mask, vs, vc, vq);
-    double *hs = vq + cells, *hn = hs + cells, *hq2 = hn + cells;
     hipLaunchKernelGGL(stats_h_kernel, dim3((max_h + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
-                       vs, vc, vq, hs, hn, hq2);
-    hipLaunchKernelGGL(stats_final_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, hs, hn, hq2, cells,
-                       lmean, lstd);
+                       vs, vc, vq, lmean, lstd);
   }
   // 3. features + neighbour table + edge attributes
   {
