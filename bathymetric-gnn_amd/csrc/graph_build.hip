@@ -655,8 +655,10 @@ template <> struct FeatStencil<16> {
   static constexpr int dc[16] = {-1, 0, 1, -1, 1, -1, 0, 1, -2, 0, 2, -2, 2, -2, 0, 2};
 };
 
-template <int KV>
-__global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Stencil st) {
+// COMPACT (compact edge storage, FeatureArgs): only the slopes are written -- the attribute selection by edge_ids, the float32 length
+// and the nan_to_num'ed depth difference of every slot drop out of pass 2, and no id table is written
+template <int KV, bool COMPACT = false>
+__global__ __launch_bounds__(256, (COMPACT ? 4 : 1)) void features_tiled_kernel(FeatureArgs a, Stencil st) {
   using FS = FeatStencil<KV>;
   constexpr int R = KV == 16 ? 2 : 1, CR = 8, CW = 64, SW = CW + 2 * R, SH = CR + 2 * R, NS = SH * SW;
   constexpr int NF = KV / 2;                                    // forward slots per cell: b % 8 >= 4
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
   const int h = t.h, w = t.w;
   const int64_t tb = t.cell_off;
   const int tid = threadIdx.x;
-  if (tid < KV) s_dist[tid] = edge_length(st.dr[tid], st.dc[tid], t.rx, t.ry);
+  if (tid < KV) s_dist[tid] = edge_length(FS::dr[tid], FS::dc[tid], t.rx, t.ry);   // (the compile-time table: `st` indexed by a lane would have to live in memory)
   write_tile_dist(a, it, t);
   // slope of the edge source -> target with depth difference dz = depth[target] - depth[source], exactly as the form above
   auto slope_of = [&](float dz, double dist) -> float {
@@ -816,30 +818,39 @@ __global__ __launch_bounds__(256) void features_tiled_kernel(FeatureArgs a, Sten
                   sl = slope_of(dz, dist);
                 }
               }
-              float vals[3];
+              if constexpr (COMPACT) {
+                e2 = sl;
+              } else {
+                float vals[3];
 #pragma unroll
-              for (int f = 0; f < 3; ++f) {
-                const int eid = a.edge_ids[f];
-                float v = 0.0f;
-                if (eid == BGNN_EF_DISTANCE) { const double d = dist; v = (d != d) ? 0.0f : (float)d; }
-                else if (eid == BGNN_EF_DEPTH_DIFFERENCE) v = nan_to_num_f32(dz);
-                else if (eid == BGNN_EF_SLOPE) v = sl;
-                vals[f] = v;
+                for (int f = 0; f < 3; ++f) {
+                  const int eid = a.edge_ids[f];
+                  float v = 0.0f;
+                  if (eid == BGNN_EF_DISTANCE) { const double d = dist; v = (d != d) ? 0.0f : (float)d; }
+                  else if (eid == BGNN_EF_DEPTH_DIFFERENCE) v = nan_to_num_f32(dz);
+                  else if (eid == BGNN_EF_SLOPE) v = sl;
+                  vals[f] = v;
+                }
+                e0 = vals[0]; e1 = vals[1]; e2 = vals[2];
               }
-              e0 = vals[0]; e1 = vals[1]; e2 = vals[2];
             }
             evs[3 * bb] = e0; evs[3 * bb + 1] = e1; evs[3 * bb + 2] = e2;
           }
-          if (a.nbr) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
-          }
-          if (a.eattr) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
-          } else {
+          if constexpr (COMPACT) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) sp[half * 2 + q] = make_float4(evs[12 * q + 2], evs[12 * q + 5], evs[12 * q + 8], evs[12 * q + 11]);
+          } else {
+            if (a.nbr) {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) np[half * 2 + q] = make_int4(sids[4 * q], sids[4 * q + 1], sids[4 * q + 2], sids[4 * q + 3]);
+            }
+            if (a.eattr) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) sp[half * 2 + q] = make_float4(evs[12 * q + 2], evs[12 * q + 5], evs[12 * q + 8], evs[12 * q + 11]);
+            }
           }
         }
       }
@@ -1133,7 +1144,10 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     // than the thread-per-cell form there.  (features_tiled = 0: always the thread-per-cell form -- the statement the tiled one is
     // tested against; 2: the tiled form for every shape, for those tests.)
     const bool tiled = ctx->opts.features_tiled == 2 || (ctx->opts.features_tiled == 1 && g->uni_w >= 64 && g->uni_h >= 8);
-    if (st.K == 8 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    const bool compact = g->compact_edges && !a.nbr;
+    if (st.K == 8 && a.ED == 3 && tiled && compact) hipLaunchKernelGGL((features_tiled_kernel<8, true>), dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 16 && a.ED == 3 && tiled && compact) hipLaunchKernelGGL((features_tiled_kernel<16, true>), dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 8 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 16 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 8 && a.ED == 3) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 16 && a.ED == 3) hipLaunchKernelGGL(features_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
