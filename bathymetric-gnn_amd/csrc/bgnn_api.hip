@@ -1153,7 +1153,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       const int smode = sm == 3 ? 3 : sm == 2 && m->l0f_Wsp16 ? 2 : sm ? 1 : 0;
       const float *wsplit = sm == 3 ? m->l0f_Wbf : sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr;
       // extractor layer 1 runs inside the lin_0 GEMM (same instructions, h1 never leaves the registers) wherever that GEMM takes
-      // its W-resident form; below 65 536 rows (exact path) it keeps its own launch -- the results are bit-identical either way
+      // its W-resident form; below 32 768 rows (exact path) it keeps its own launch -- the results are bit-identical either way
       const bool front = hid == 64 && gemm_front_available(ctx, rows, L0.heads * hid, smode);
       BGNN_REQUIRE(front || sm != 3, "matrix_path = bf16 needs fused_front = 1");
       if (!front) BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));

@@ -552,10 +552,16 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
 
 // (split_mode 3: Y receives bf16 [M][ldy], see gemm_wres64_kernel)
 // Can the K = 64 attention GEMM of this shape take the feature extractor's first Linear in front (X = the [M][8] feature table)?
+// From how many rows the exact path's K = 64 attention GEMM takes its W-resident form (and with it the extractor's first layer in
+// front: one launch instead of two).  32 768 so that a 50 000-node batch of refinement grids is covered (65 536 until round 3:
+// configs[3] 153 -> 157 M nodes/s on one context, 195 -> 203 M with two batches in flight); the results are bit-identical either way.
+#ifndef BGNN_WRES_MIN_ROWS
+#define BGNN_WRES_MIN_ROWS 32768
+#endif
 bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode) {
   if (!ctx->opts.fused_front || (NC != 64 && NC != 256)) return false;
   if (split_mode == 3) return true;                                  // bf16 output: always the W-resident form
-  return split_mode == 0 && !ctx->opts.gemm_no_wres && max_rows >= 65536;
+  return split_mode == 0 && !ctx->opts.gemm_no_wres && max_rows >= BGNN_WRES_MIN_ROWS;
 }
 
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
@@ -576,7 +582,7 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   // at EVERY batch size, so that a node's result does not depend on how many other nodes share its batch
   if (split_mode == 3) BGNN_REQUIRE(K == 64 && att_src && (NC == 64 || NC == 256) && Wt_split, "gemm: bf16 output needs the W-resident form");
   if (!(K == 64 && (!no_wres || split_mode == 3) && att_src && (NC == 64 || NC == 256))) Wt_split = nullptr;
-  if (K == 64 && (!no_wres || split_mode == 3) && (max_rows >= 65536 || Wt_split)) {    // W-resident persistent form
+  if (K == 64 && (!no_wres || split_mode == 3) && (max_rows >= BGNN_WRES_MIN_ROWS || Wt_split)) {    // W-resident persistent form
     switch (NC / 32) {
 #define BGNN_WRES_CASE(NT) case NT:                                                                                 \
         if (front_W0t) { if (split_mode == 3) a.Wt = Wt_split; return split_mode == 3 ? launch_wres64<NT, true, 3, true>(ctx, a) : launch_wres64<NT, true, 0, true>(ctx, a); } \
