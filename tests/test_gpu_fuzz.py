@@ -75,7 +75,10 @@ def test_fuzz_graph_build(conn, loops, gpu_device):
     assert n_nonempty > 30
 
 
-def test_fuzz_forward_and_ragged_batches(gpu_device):
+@pytest.mark.parametrize("conn", ["8-connected", "4-connected", "16-dilated"])
+def test_fuzz_forward_and_ragged_batches(conn, gpu_device):
+    """(Every stencil: the fused kernels rebuild the edge attributes from the compact storage -- unit and doubled (dilated) lengths at
+    anisotropic, non-power-of-two resolutions, per-grid lengths on the ragged canvas.)"""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder
     from bathymetric_gnn_amd.models import BathymetricGNN
@@ -84,7 +87,7 @@ def test_fuzz_forward_and_ragged_batches(gpu_device):
     model = BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     model.to(gpu_device).eval()
-    gb = GraphBuilder()
+    gb = GraphBuilder(connectivity=conn)
     tiles = []
     while len(tiles) < 24:
         d, m, _, res = _random_tile(rng, allow_defects=False)      # finite inputs: the logits bar is absolute
@@ -93,7 +96,7 @@ def test_fuzz_forward_and_ragged_batches(gpu_device):
     singles = []
     for d, m, res in tiles:
         g = gb.build_graph(d, m, None, res)
-        o = graph_cpu.build_graph(d, m, None, res)
+        o = graph_cpu.build_graph(d, m, None, res, connectivity=conn)
         out = model.predict(g)
         ref = gat_cpu.predict(sd, o.x, o.edge_index, o.edge_attr)
         assert (out["class_logits"].cpu() - ref["class_logits"]).abs().max().item() < TOL, (d.shape, int(m.sum()))
