@@ -1147,8 +1147,13 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       // is transposed through a wave-private LDS patch and written out as whole row segments: f32 128 bytes per row,
       // 8 rows per instruction; bf16 64 bytes per row, 16 rows per instruction.
       float *patch = slab + wave * (32 * TILED_PITCH);
-      constexpr int LPR = SP == 3 ? 4 : 8;              // lanes per stored row
-      constexpr int NSTORE = 32 * LPR / 64;             // store instructions per tile (2 / 4)
+      // bf16 storage: the patch holds TWO tiles side by side, already as bf16 -- [32 rows][128 B], 16-byte chunk c of row r at chunk
+      // c ^ (r & 7), the two 8-byte halves of a chunk swapped on rows with bit 3 set: conflict-free for the ds_write_b64 (16 consecutive
+      // lanes over 32 banks) and for the ds_read_b128 lane groups (MI355X_MICROARCH.md), half the LDS write bytes and read-backs of
+      // the float32 patch, and whole 128-byte lines per stored row instead of two 64-byte halves.
+      constexpr int LPR = 8;                            // lanes per stored row (f32: 128 B of one tile; bf16: 128 B of a tile pair)
+      constexpr int NSTORE = 32 * LPR / 64;             // store instructions per tile (f32) / tile pair (bf16)
+      static_assert(SP != 3 || EPI != EPI_NEXT || NT % 2 == 0, "bf16 tiles are stored in pairs");
       char *prow[NSTORE];                               // output row of patch row (lane / LPR) + (64 / LPR) k, column chunk lane % LPR
 #pragma unroll
       for (int k = 0; k < NSTORE; ++k) {
@@ -1174,17 +1179,27 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
           const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
           ps[t / TPH] += vlo * (f32x2){s4[g].x, s4[g].y}; ps[t / TPH] += vhi * (f32x2){s4[g].z, s4[g].w};
           pd[t / TPH] += vlo * (f32x2){d4[g].x, d4[g].y}; pd[t / TPH] += vhi * (f32x2){d4[g].z, d4[g].w};
-          *reinterpret_cast<float4 *>(patch + r * TILED_PITCH + 8 * g + 4 * hl) = v;
+          if constexpr (SP == 3) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            char *pb = reinterpret_cast<char *>(patch) + r * 128 + ((hl ^ ((r >> 3) & 1)) << 3);
+            *reinterpret_cast<bf16x4 *>(pb + ((((t & 1) * 4 + g) ^ (r & 7)) << 4)) = o;
+          } else {
+            *reinterpret_cast<float4 *>(patch + r * TILED_PITCH + 8 * g + 4 * hl) = v;
+          }
         }
         asm volatile("" : "+v"(ps[t / TPH]), "+v"(pd[t / TPH]));   // the dots are due HERE (not sunk below the stores)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SP == 3) {
+          if (t & 1) {
 #pragma unroll
-          for (int k = 0; k < NSTORE; ++k) {            // 8 consecutive columns -> 8 bf16 = one 16-byte store
-            const float *pp = patch + (lane / LPR + (64 / LPR) * k) * TILED_PITCH + (lane % LPR) * 8;
-            const float4 lo = *reinterpret_cast<const float4 *>(pp), hi = *reinterpret_cast<const float4 *>(pp + 4);
-            const bf16x8 o = to_bf16x8((f32x4){lo.x, lo.y, lo.z, lo.w}, (f32x4){hi.x, hi.y, hi.z, hi.w});
-            *reinterpret_cast<bf16x8 *>(prow[k] + t * 64) = o;
+            for (int k = 0; k < NSTORE; ++k) {          // row (lane >> 3) + 8 k: (row >> 3) & 1 == k & 1, the half swap is compile-time
+              const int row = (lane >> 3) + 8 * k;
+              uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(patch) + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+              if (k & 1) q = make_uint4(q.z, q.w, q.x, q.y);
+              *reinterpret_cast<uint4 *>(prow[k] + (t - 1) * 64) = q;
+            }
           }
         } else {
 #pragma unroll
