@@ -1209,14 +1209,27 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      // the node's [alpha_src (H2) | alpha_dst (H2)] row leaves as 16-byte (H2 = 4) / 8-byte (H2 = 1, 2) pieces instead of 2 H2 scalar
+      // stores that each touched 32 different lines
+      float srow[H2 > 0 ? H2 : 1], drow_[H2 > 0 ? H2 : 1];
 #pragma unroll
       for (int hd = 0; hd < H2; ++hd) {
         const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
-        const float s_ = sl + __shfl_xor(sl, 32);
-        const float d_ = dl + __shfl_xor(dl, 32);
-        if (id >= 0 && hl == 0) {
-          a.asd_out[(int64_t)id * 2 * H2 + hd] = s_;
-          a.asd_out[(int64_t)id * 2 * H2 + H2 + hd] = d_;
+        srow[hd] = sl + __shfl_xor(sl, 32);
+        drow_[hd] = dl + __shfl_xor(dl, 32);
+      }
+      if (id >= 0 && hl == 0) {
+        float *ao = a.asd_out + (int64_t)id * 2 * H2;
+        if constexpr (H2 == 4) {
+          *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], srow[2], srow[3]);
+          *reinterpret_cast<float4 *>(ao + 4) = make_float4(drow_[0], drow_[1], drow_[2], drow_[3]);
+        } else if constexpr (H2 == 2) {
+          *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], drow_[0], drow_[1]);
+        } else if constexpr (H2 == 1) {
+          *reinterpret_cast<float2 *>(ao) = make_float2(srow[0], drow_[0]);
+        } else {
+#pragma unroll
+          for (int hd = 0; hd < H2; ++hd) { ao[hd] = srow[hd]; ao[H2 + hd] = drow_[hd]; }
         }
       }
     } else {
@@ -1712,14 +1725,27 @@ __global__ __launch_bounds__(256, 1) void gat_layer_persist_kernel(FusedArgs a, 
         for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(prow[k] + t * 128) = o4[k];
         __builtin_amdgcn_sched_barrier(0);
       }
+      // the node's [alpha_src (H2) | alpha_dst (H2)] row leaves as 16-byte (H2 = 4) / 8-byte (H2 = 1, 2) pieces instead of 2 H2 scalar
+      // stores that each touched 32 different lines
+      float srow[H2 > 0 ? H2 : 1], drow_[H2 > 0 ? H2 : 1];
 #pragma unroll
       for (int hd = 0; hd < H2; ++hd) {
         const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
-        const float s_ = sl + __shfl_xor(sl, 32);
-        const float d_ = dl + __shfl_xor(dl, 32);
-        if (id >= 0 && hl == 0) {
-          a.asd_out[(int64_t)id * 2 * H2 + hd] = s_;
-          a.asd_out[(int64_t)id * 2 * H2 + H2 + hd] = d_;
+        srow[hd] = sl + __shfl_xor(sl, 32);
+        drow_[hd] = dl + __shfl_xor(dl, 32);
+      }
+      if (id >= 0 && hl == 0) {
+        float *ao = a.asd_out + (int64_t)id * 2 * H2;
+        if constexpr (H2 == 4) {
+          *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], srow[2], srow[3]);
+          *reinterpret_cast<float4 *>(ao + 4) = make_float4(drow_[0], drow_[1], drow_[2], drow_[3]);
+        } else if constexpr (H2 == 2) {
+          *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], drow_[0], drow_[1]);
+        } else if constexpr (H2 == 1) {
+          *reinterpret_cast<float2 *>(ao) = make_float2(srow[0], drow_[0]);
+        } else {
+#pragma unroll
+          for (int hd = 0; hd < H2; ++hd) { ao[hd] = srow[hd]; ao[H2 + hd] = drow_[hd]; }
         }
       }
     }
