@@ -163,11 +163,13 @@ __device__ __forceinline__ void halo_depths(uint32_t hdp_lo, float (&ds)[K + 1],
   ((ds[B] = lds_read1<S::rel(B) * 4>(hdp_lo)), ...);
   ds[K] = lds_read1<S::MAXOFF * 4>(hdp_lo);                          // the cell's own depth
 }
+// (the table is [H][HR] -- head-major: the 32 cells of a read then sit in consecutive dwords; as [HR][H] they were H dwords apart,
+//  i.e. on 32 / H banks: a 4-way conflict on every one of the (K + 1) x heads-per-lane reads of phase A)
 template <int H, int K, int HWID, int... B>
 __device__ __forceinline__ void halo_alpha_src(uint32_t has_lo, float (&hs)[K + 1], std::integer_sequence<int, B...>) {
   using S = HaloSlot<K, HWID>;
-  ((hs[B] = lds_read1<S::rel(B) * H * 4>(has_lo)), ...);
-  hs[K] = lds_read1<S::MAXOFF * H * 4>(has_lo);
+  ((hs[B] = lds_read1<S::rel(B) * 4>(has_lo)), ...);
+  hs[K] = lds_read1<S::MAXOFF * 4>(has_lo);
 }
 
 // MFMA phase of one slab: 8 groups of (2 k rows x NT tiles).  Group M covers k rows 8*(M/2) + 2*(M&1) + {0,1}
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   int *cid = reinterpret_cast<int *>(rreg + RSZ);      // [128] node id of each block cell (HID_IN_ALPHA only)
   int *minid = cid + (Lds::HID_IN_ALPHA ? 128 : HR);   // [4]
   float *alx = reinterpret_cast<float *>(minid + 4) + Lds::ALIGN;   // [128][APITCH]  alpha[cell][head][K+1]; bf16 path: dense (AggWindow)
-  float *has = Lds::HAS_IN_ALPHA ? alx : rreg;         // [HR][H]   (phase A; bf16 path: inside the not yet written dense-alpha region)
+  float *has = Lds::HAS_IN_ALPHA ? alx : rreg;         // [H][HR]   (phase A; bf16 path: inside the not yet written dense-alpha region)
   float *hdp = has + HR * H;                           // [HR]      depth of the halo rows' nodes (phase A: depth differences)
   int *hid = Lds::HID_IN_ALPHA ? reinterpret_cast<int *>(alx + HR * (H + 1)) : reinterpret_cast<int *>(rreg + RSZ);   // [HR]
 
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   if (tid < HR) {
     hid[tid] = hid_v;
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) has[tid * H + hh] = hid_v >= 0 ? hasv[hh] : -__builtin_inff();   // (-inf: an absent source drops out of the softmax)
+    for (int hh = 0; hh < H; ++hh) has[hh * HR + tid] = hid_v >= 0 ? hasv[hh] : -__builtin_inff();   // (-inf: an absent source drops out of the softmax)
     hdp[tid] = hid_v >= 0 ? hdep : 0.0f;
   }
   if (Lds::HID_IN_ALPHA && hl == 0) cid[cell] = my_pre < 0 ? -1 : my_pre;
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
       for (int i = 0; i < NHL; ++i) {
         const int hh = hl + i * 2 < H ? hl + i * 2 : 0;
-        halo_alpha_src<H, K, HW_>(has0 + (uint32_t)((self_a - S::MAXOFF) * H + hh) * 4u, hs[i], std::make_integer_sequence<int, K>{});
+        halo_alpha_src<H, K, HW_>(has0 + (uint32_t)(hh * HR + self_a - S::MAXOFF) * 4u, hs[i], std::make_integer_sequence<int, K>{});
       }
       float dsrc[K + 1];
       halo_depths<K, HW_>(lds_addr(hdp) + (uint32_t)(self_a - S::MAXOFF) * 4u, dsrc, std::make_integer_sequence<int, K>{});
