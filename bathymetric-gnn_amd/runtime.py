@@ -26,7 +26,7 @@ EDGE_FEATURE_IDS = {"distance": 0, "depth_difference": 1, "slope": 2}
 EF_ZERO = 3
 
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4
-ABI_VERSION = 4
+ABI_VERSION = 5
 MATRIX_PATHS = {"exact_f32": 0, "bf16x3": 1, "fp16x3": 2, "bf16": 3}
 
 
@@ -60,6 +60,7 @@ class Outputs(C.Structure):
 _SIGNATURES = {
     "bgnn_abi_version": (C.c_int, []),
     "bgnn_last_error": (C.c_char_p, []),
+    "bgnn_build_id": (C.c_char_p, []),
     "bgnn_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bgnn_ctx_destroy": (C.c_int, [C.c_void_p]),
     "bgnn_ctx_synchronize": (C.c_int, [C.c_void_p]),
@@ -125,6 +126,11 @@ def load_library(path: Optional[str] = None):
             raise ImportError(f"{p}: ABI version {lib.bgnn_abi_version()} != {ABI_VERSION}")
         _lib = lib
         return lib
+
+
+def build_id() -> str:
+    """The kernel-source hash the loaded library was built from (``bgnn_build_id``)."""
+    return load_library().bgnn_build_id().decode()
 
 
 def check(rc: int):

@@ -113,10 +113,73 @@ def cpu_baseline(n_runs, tile, sd, seed0, connectivity="8-connected"):
     med = float(np.median(rates))
     return {"value": med, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
             "min": rates[0], "max": rates[-1], "runs": n_runs,
+            "sample_short": f"median of {n_runs} runs (1 warm-up) of one {tile}x{tile} tile (k={k}, fp32): numpy graph build + torch CPU "
+                            f"forward + scatter, {wall:.0f} s; os.cpu_count()={os.cpu_count()}",
             "sample": f"median of {n_runs} runs (after 1 warm-up run) of one {tile}x{tile} tile each (k={k}, 4-layer GAT, fp32): "
                       f"numpy graph build + torch CPU forward + scatter; {wall:.1f} s wall for the timed runs "
                       f"({sum(r[2] for r in runs):.1f} s of it graph build); spread {rates[0]:.0f} .. {rates[-1]:.0f} nodes/s; "
                       f"os.cpu_count()={os.cpu_count()}"}
+
+
+LINE_BUDGET = 4000           # bytes of the ONE stdout line (the driver keeps about 8 KB of stdout's tail)
+
+
+def kernel_source_sha(csrc=None):
+    """sha256 over the kernel sources (csrc/*.hip, *.h, sorted by name): what `bgnn_build_id()` of a library built from this tree
+    returns, and what tools/summarise_profiles.py stamps into profiles/pmc_traffic.json."""
+    import hashlib
+    csrc = csrc or os.path.join(ROOT, "bathymetric-gnn_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")) and name != "build_id.hip":
+            h.update(name.encode()); h.update(b"\0")
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_table(build_id):
+    """profiles/pmc_traffic.json (rocprofv3 --pmc passes, collected separately) -- or {} when it was collected on other
+    kernels than the ones the loaded library was built from (then roofline.traffic stays null rather than going stale)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return {}
+    if not build_id or t.get("_kernel_source_sha") != build_id:
+        return {}
+    return t
+
+
+def compact_line(line, budget=LINE_BUDGET):
+    """The stdout line within `budget` bytes: optional keys are dropped (least important first) until it fits; the contract
+    keys, roofline and cpu_baseline are never dropped."""
+    out = dict(line)
+    for k in ("matrix_path", "path", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
+        if len(json.dumps(out)) <= budget:
+            break
+        out.pop(k, None)
+    if len(json.dumps(out)) > budget and isinstance(out.get("cpu_baseline"), dict):
+        out["cpu_baseline"] = {k: v for k, v in out["cpu_baseline"].items() if k != "sample"} | {"sample": "see detail file"}
+    if len(json.dumps(out)) > budget:
+        out["config"] = {"workload": str(out["config"].get("workload", ""))[:200]}
+    return out
+
+
+def emit(line, detail, detail_path):
+    """Full record (line + detail) to the side file and to stderr; ONE compact JSON line to stdout, last."""
+    full = dict(line); full.update(detail)
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+        with open(detail_path, "w") as fh:
+            json.dump(full, fh, indent=1)
+        line["detail"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+    except OSError as e:
+        line["detail"] = f"not written ({e.__class__.__name__}); see stderr"
+    print("bench detail: " + json.dumps(full), file=sys.stderr, flush=True)
+    out = compact_line(line)
+    s = json.dumps(out)
+    assert len(s) <= LINE_BUDGET and s.startswith("{"), len(s)
+    sys.stdout.flush()
+    print(s, flush=True)
 
 
 # ---- launching ------------------------------------------------------------------------------------------------------------
@@ -488,24 +551,23 @@ class Bench:
                                           "standalone K4 (LDS-tiled gather-softmax-aggregate + BN + ReLU)")
             roofs["gemm_mfma"] = roof("gemm_f32_kernel", "gemm", "mfma", am["gemm_flops"], "all K3 GEMMs, exact f32 MFMA")
         roofs = {k: v for k, v in roofs.items() if v}
-        # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); attach to the workload it was collected on
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        # PMC traffic is collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh -> profiles/pmc_traffic.json, stamped
+        # with the kernel-source hash it was collected on); attached only to the workload AND the kernels it was collected on
         pmc_key = None
         if wl["kind"] == "tiles" and (wl["B"], wl["S"], self.layers) == (128, 256, 4):
             pmc_key = ":c3" if (wl["deg"] == 16 and bf16) else None if (wl["deg"] != 8 or bf16) else ":split" if split else ""
-        if os.path.exists(pmc) and pmc_key is not None:
-            try:
-                t = json.load(open(pmc))
-                for v in roofs.values():
-                    e = t.get(v["kernel"] + pmc_key) if pmc_key else None
-                    if pmc_key == ":c3" and e is None:
-                        continue
-                    v["traffic"] = (e or t.get(v["kernel"], {})).get("hbm_bytes_per_launch")
-                    if v["traffic"] is not None:
-                        v["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                               "command, collected separately (not measured by this run)")
-            except Exception:
-                pass
+        t = pmc_traffic_table(self.rt.build_id()) if pmc_key is not None else {}
+        for v in roofs.values():
+            e = t.get(v["kernel"] + pmc_key) if pmc_key else t.get(v["kernel"])
+            if not e:
+                continue
+            v["traffic"] = e.get("hbm_bytes_per_launch")
+            if v["traffic"] is not None:
+                # HBM bytes by the counters / the launch's own duration, against the 8 TB/s roof: the fraction of the roof the
+                # kernel really moves (`frac` prices SURVEY 8(d)'s fixed algorithmic figure, which the compact edge storage undercuts)
+                v["traffic_frac"] = v["traffic"] / (v["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                v["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
+                                       f"kernels {t.get('_kernel_source_sha')} (= this library), collected separately, not by this run")
         if "fused_mfma" in roofs:
             dominant = roofs["fused_hbm"] if (split or bf16) else roofs["fused_mfma"]   # 16-bit MFMA paths: memory-side bound
         elif roofs:
@@ -517,7 +579,7 @@ class Bench:
         nodes_all = m["nodes_all_ranks_per_step"]
         return {"value": nodes_all * steps / m["elapsed"], "unit": "nodes/s", "ms_per_step": m["elapsed"] / steps * 1e3,
                 "steps": steps, "warmup": m["warmup"], "workload": wl["name"], "nodes_per_step_per_gpu": wl["nodes_per_step"],
-                "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                "roofline": {k: dominant.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac",
                                                            "kernel", "avg_launch_ms")},
                 "rooflines": roofs, "kernels": kernels,
                 "kernel_events": "inside the timed region" if wl["events_in_timed_region"] else "separate pass of the same steps (timed steps ran bare)"}
@@ -566,6 +628,9 @@ def main():
                          "batch's kernels overlaps the head of the next one's (two is what NativeVRProcessor keeps in flight, "
                          "and the fastest: 203 M nodes/s against 193 M with four)")
     ap.add_argument("--survey-size", type=int, default=20000, help="survey workload: side of the square survey in cells (config 5: 60000)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="side file for the full record (rooflines of every kernel class, per-kernel times, the side measurements "
+                         "in full); stdout carries ONE compact line")
     ap.add_argument("--extras-survey-size", type=int, default=20000, help="side of the config5 survey measured beside the default headline")
     args = ap.parse_args()
 
@@ -612,125 +677,170 @@ def main():
                        "nodes_per_step_per_gpu": wl["nodes_per_step"],
                        "parallelism": (f"tile-sharded x{world}, no collective" if wl["kind"] != "survey" else
                                        f"row bands x{world}, halo tile rows point-to-point ({wl['halo_bytes_all_ranks'] / 1e9:.2f} GB per step), no collective")},
-            "roofline": rep["roofline"], "rooflines": rep["rooflines"], "kernels": rep["kernels"],
-            "kernel_events": rep["kernel_events"],
+            "roofline": rep["roofline"],
             "path": "unfused" if wl["unfused"] else "fused",
             "matrix_path": "bf16 storage + bf16 MFMA (BASELINE configs[2])" if wl["bf16"] else f"{wl['split']} split (opt-in)" if wl["split"] else "exact f32",
         }
+        # Everything beyond the contract goes to the DETAIL record (side file + stderr): the stdout line stays small enough for
+        # the driver's tail of stdout (round 3's 23 KB line lost its head there).
+        detail = {"rooflines": rep["rooflines"], "kernels": rep["kernels"], "kernel_events": rep["kernel_events"]}
         if wl["kind"] == "survey":
             line["survey"] = {k: wl[k] for k in ("size", "tiles_total", "tiles_processed", "tiles_skipped", "halo_bytes_all_ranks")}
         extras = not args.no_extras and world == 1
         default_headline = wl["kind"] == "tiles" and not wl["unfused"] and not wl["bf16"] and not wl["split"]
+
+        def guarded(key, fn):
+            """One side measurement: its failure is recorded under its key, the headline still prints."""
+            try:
+                return fn()
+            except Exception as e:                                   # noqa: BLE001 -- any failure of an extra must not lose the line
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                detail[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                line[key] = {"error": f"{type(e).__name__}: {e}"[:120]}
+                torch.cuda.empty_cache()
+                return None
+
+        # The CPU baseline first: it is part of the contract and needs nothing of the GPU.
+        if extras and not args.no_cpu_baseline and wl["kind"] == "tiles":
+            def _cpu():
+                cb = cpu_baseline(args.cpu_runs, S, bench.model(7)[1], 100, wl["conn"])
+                detail["cpu_baseline"] = cb
+                line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind")}
+                line["cpu_baseline"]["sample"] = cb["sample_short"]
+                line["gpu_over_cpu"] = rep["value"] / cb["value"]
+            guarded("cpu_baseline", _cpu)
         if extras and wl["kind"] == "tiles" and not wl["unfused"]:
-            eng, (depth, mask), (d_t, m_t) = wl["eng"], wl["host"], wl["dev_in"]
-            ctx = eng.ctx
-            scope = ctx.options(**wl["options"])
-            scope.__enter__()
-            # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
-            # D2H on three streams, two slots in flight.  Reported beside `value`, never as it.
-            from bathymetric_gnn_amd.models.pipeline import HostTilePipeline
-            hp = HostTilePipeline(eng, B, S, S, resolution=(0.5, 0.5))
-            for _ in range(2):
-                hp.submit(depth, mask)
-            list(hp.drain())
-            n_pc = max(4, min(args.steps, 10))
-            torch.cuda.synchronize(dev); t1 = time.perf_counter()
-            got = 0
-            for _ in range(n_pc):
-                got += hp.submit(depth, mask) is not None
-            got += len(list(hp.drain()))
-            t_pc = time.perf_counter() - t1
-            assert got == n_pc
-            line["pcie_inclusive"] = {"value": wl["nodes_per_step"] * n_pc / t_pc, "unit": "nodes/s", "ms_per_step": t_pc / n_pc * 1e3,
-                                      "steps": n_pc, "bytes_per_cell": {"h2d": 5, "d2h": 12},
-                                      "note": "host numpy tiles in, host grids out: pinned double-buffered staging, H2D / "
-                                              "compute / D2H overlapped on three streams (HostTilePipeline)"}
-            del hp
-            if B > 1:
-                # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
-                d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
-                hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)
-                out1 = torch.empty((3, S * S), dtype=torch.float32, device=dev)
-                for _ in range(5):
-                    eng.infer_device(hw1, res1, d1, m1, None, out=out1)
-                torch.cuda.synchronize(dev); t3 = time.perf_counter()
-                n_one = 50
-                for _ in range(n_one):
-                    eng.infer_device(hw1, res1, d1, m1, None, out=out1)
-                torch.cuda.synchronize(dev); t_one = (time.perf_counter() - t3) / n_one
-                line["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
-                                       "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
-            scope.__exit__(None, None, None)
+            def _pcie_and_single():
+                eng, (depth, mask), (d_t, m_t) = wl["eng"], wl["host"], wl["dev_in"]
+                ctx = eng.ctx
+                with ctx.options(**wl["options"]):
+                    # The same batch handed over as HOST arrays (the reference's boundary): pinned staging, H2D / compute /
+                    # D2H on three streams, two slots in flight.  Reported beside `value`, never as it.
+                    from bathymetric_gnn_amd.models.pipeline import HostTilePipeline
+                    hp = HostTilePipeline(eng, B, S, S, resolution=(0.5, 0.5))
+                    for _ in range(2):
+                        hp.submit(depth, mask)
+                    list(hp.drain())
+                    n_pc = max(4, min(args.steps, 10))
+                    torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                    got = 0
+                    for _ in range(n_pc):
+                        got += hp.submit(depth, mask) is not None
+                    got += len(list(hp.drain()))
+                    t_pc = time.perf_counter() - t1
+                    assert got == n_pc
+                    detail["pcie_inclusive"] = {"value": wl["nodes_per_step"] * n_pc / t_pc, "unit": "nodes/s", "ms_per_step": t_pc / n_pc * 1e3,
+                                                "steps": n_pc, "bytes_per_cell": {"h2d": 5, "d2h": 12},
+                                                "note": "host numpy tiles in, host grids out: pinned double-buffered staging, H2D / "
+                                                        "compute / D2H overlapped on three streams (HostTilePipeline)"}
+                    line["pcie_inclusive"] = {"value": detail["pcie_inclusive"]["value"], "ms_per_step": detail["pcie_inclusive"]["ms_per_step"]}
+                    del hp
+                    if B > 1:
+                        # BASELINE configs[1]: ONE 256 x 256 tile per step (latency-bound: 65 536 nodes cannot fill 256 CUs)
+                        d1 = d_t[: S * S].clone(); m1 = m_t[: S * S].clone()
+                        hw1 = np.array([[S, S]], np.int32); res1 = np.full((1, 2), 0.5)
+                        out1 = torch.empty((3, S * S), dtype=torch.float32, device=dev)
+                        for _ in range(5):
+                            eng.infer_device(hw1, res1, d1, m1, None, out=out1)
+                        torch.cuda.synchronize(dev); t3 = time.perf_counter()
+                        n_one = 50
+                        for _ in range(n_one):
+                            eng.infer_device(hw1, res1, d1, m1, None, out=out1)
+                        torch.cuda.synchronize(dev); t_one = (time.perf_counter() - t3) / n_one
+                        detail["single_tile"] = {"value": int(mask[0].sum()) / t_one, "unit": "nodes/s", "ms_per_tile": t_one * 1e3, "steps": n_one,
+                                                 "note": f"configs[1]: one {S}x{S} tile per step (back-to-back launches, inputs resident in HBM)"}
+                        line["single_tile"] = {"value": detail["single_tile"]["value"], "ms_per_tile": t_one * 1e3}
+            guarded("pcie_inclusive", _pcie_and_single)
         if extras and default_headline:
             # Opt-in matrix paths, reported BESIDE the headline (never as it): hi/lo operand splits on the 16-bit matrix cores with
             # float32 accumulation.  Same inputs, same timing protocol; the distance of their class logits to the exact-f32 path
             # is measured on one tile of the batch.
-            from bathymetric_gnn_amd.data import GraphBuilder as _GB
-            model = bench.model(7)[0]
-            ctx = wl["eng"].ctx
-            g1 = _GB(device=dev).build_graph(wl["host"][0][0], wl["host"][1][0], None, (0.5, 0.5))
-            lg_exact = model.predict(g1)["class_logits"].clone()
-            for key, env, instr in (("split_bf16x3", "bf16x3", "v_mfma_f32_32x32x16_bf16"),
-                                    ("split_fp16x3", "fp16x3", "v_mfma_f32_32x32x16_f16")):
-                ctx.set_option("matrix_path", env)
-                try:
-                    lg_split = model.predict(g1)["class_logits"]
-                    for _ in range(2):
-                        wl["step"]()
-                    n_sp = max(4, min(args.steps, 10))
-                    torch.cuda.synchronize(dev); t2 = time.perf_counter()
-                    for _ in range(n_sp):
-                        wl["step"]()
-                    torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
-                finally:
-                    ctx.set_option("matrix_path", "exact_f32")
-                line[key] = {"value": wl["nodes_per_step"] * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
-                             "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
-                             "note": f"matrix_path={env}: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
-                                     "opt-in, not the headline"}
-            del g1
+            def _splits():
+                from bathymetric_gnn_amd.data import GraphBuilder as _GB
+                model = bench.model(7)[0]
+                ctx = wl["eng"].ctx
+                g1 = _GB(device=dev).build_graph(wl["host"][0][0], wl["host"][1][0], None, (0.5, 0.5))
+                lg_exact = model.predict(g1)["class_logits"].clone()
+                for key, env, instr in (("split_bf16x3", "bf16x3", "v_mfma_f32_32x32x16_bf16"),
+                                        ("split_fp16x3", "fp16x3", "v_mfma_f32_32x32x16_f16")):
+                    ctx.set_option("matrix_path", env)
+                    try:
+                        lg_split = model.predict(g1)["class_logits"]
+                        for _ in range(2):
+                            wl["step"]()
+                        n_sp = max(4, min(args.steps, 10))
+                        torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                        for _ in range(n_sp):
+                            wl["step"]()
+                        torch.cuda.synchronize(dev); t_sp = time.perf_counter() - t2
+                    finally:
+                        ctx.set_option("matrix_path", "exact_f32")
+                    detail[key] = {"value": wl["nodes_per_step"] * n_sp / t_sp, "unit": "nodes/s", "ms_per_step": t_sp / n_sp * 1e3,
+                                   "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
+                                   "note": f"matrix_path={env}: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
+                                           "opt-in, not the headline"}
+            guarded("split_paths", _splits)
             # ---- the other single-GPU BASELINE configs, same protocol (rank 0, N = 1), each with its own roofline ----------
             k_x, w_x = max(4, min(args.steps, 10)), 2
 
             def side(w, steps=k_x, warmup=w_x, extra=None):
-                r = bench.report(w, bench.measure(w, steps, warmup))
+                try:
+                    r = bench.report(w, bench.measure(w, steps, warmup))
+                finally:
+                    if "close" in w:
+                        w["close"]()
                 r["dtype"] = dtype_name(w)
                 r["higher_is_better"] = True
                 if extra:
                     r.update(extra)
-                if "close" in w:
-                    w["close"]()
                 return r
 
-            c3 = bench.tiles(128, 256, "V0", "16-dilated", matrix_path="bf16")
-            line["config3"] = side(c3, extra={"config": "BASELINE configs[2]: batch of 128 x 256x256 tiles, k=16, bf16 node features"})
-            del c3
+            def brief(r, short_dtype, workload):
+                """What the stdout line keeps of a side measurement."""
+                rf = r["roofline"]
+                return {"value": r["value"], "ms_per_step": r["ms_per_step"], "dtype": short_dtype, "workload": workload,
+                        "roofline": {"bound": rf.get("bound"), "frac": rf.get("frac"), "kernel": rf.get("kernel")}}
+
+            def _c3():
+                c3 = bench.tiles(128, 256, "V0", "16-dilated", matrix_path="bf16")
+                detail["config3"] = side(c3, extra={"config": "BASELINE configs[2]: batch of 128 x 256x256 tiles, k=16, bf16 node features"})
+                line["config3"] = brief(detail["config3"], "bf16", "configs[2]: 128 x 256x256 tiles, k=16 (16-dilated), bf16 activations")
+            guarded("config3", _c3)
             torch.cuda.empty_cache()
-            grids = bench.syn.vr_grid_stream(args.vr_grids, seed0=1000)
-            v1 = side(bench.vr(args.vr_grids, args.vr_budget, 1, grids=grids))
-            v2 = side(bench.vr(args.vr_grids, args.vr_budget, 2, grids=grids))
-            v4 = side(bench.vr(args.vr_grids, args.vr_budget, 4, grids=grids))
-            line["config4"] = {"config": "BASELINE configs[3]: VR-BAG mixed refinement grids (3x3..50x50), 4096-grid stream, "
-                                         f"{args.vr_budget}-node batches (scripts/inference_native.py:128)",
-                               "value": v1["value"], "unit": "nodes/s", "ms_per_step": v1["ms_per_step"], "roofline": v1["roofline"],
-                               "note": "value = ONE library context / HIP stream: what one synchronous NativeVRProcessor.flush_batch after the "
-                                       "other gives; two_contexts = two batches in flight, what the processor's submit_batch / collect_batch "
-                                       "(run_refinements' default) keeps on the GPU; four_contexts = the same batches dealt over 4 contexts",
-                               "one_context": v1, "two_contexts": v2, "four_contexts": v4,
-                               "processor_api": bench.vr_processor_api(args.vr_budget)}
-            del grids
+
+            def _c4():
+                grids = bench.syn.vr_grid_stream(args.vr_grids, seed0=1000)
+                v1 = side(bench.vr(args.vr_grids, args.vr_budget, 1, grids=grids))
+                v2 = side(bench.vr(args.vr_grids, args.vr_budget, 2, grids=grids))
+                v4 = side(bench.vr(args.vr_grids, args.vr_budget, 4, grids=grids))
+                detail["config4"] = {"config": "BASELINE configs[3]: VR-BAG mixed refinement grids (3x3..50x50), 4096-grid stream, "
+                                               f"{args.vr_budget}-node batches (scripts/inference_native.py:128)",
+                                     "value": v1["value"], "unit": "nodes/s", "ms_per_step": v1["ms_per_step"], "roofline": v1["roofline"],
+                                     "note": "value = ONE library context / HIP stream: what one synchronous NativeVRProcessor.flush_batch after the "
+                                             "other gives; two_contexts = two batches in flight, what the processor's submit_batch / collect_batch "
+                                             "(run_refinements' default) keeps on the GPU; four_contexts = the same batches dealt over 4 contexts",
+                                     "one_context": v1, "two_contexts": v2, "four_contexts": v4}
+                line["config4"] = brief(v1, "f32", f"configs[3]: {args.vr_grids} VR refinement grids (3x3..50x50), {args.vr_budget}-node batches, one context")
+                line["config4"]["one_context"] = v1["value"]
+                line["config4"]["two_contexts"] = v2["value"]
+                api = bench.vr_processor_api(args.vr_budget)
+                detail["config4"]["processor_api"] = api
+                line["config4"]["processor_api"] = {k: api[k]["value"] for k in ("synchronous", "pipelined")}
+            guarded("config4", _c4)
             torch.cuda.empty_cache()
-            sv = bench.survey(args.extras_survey_size)
-            line["config5"] = side(sv, steps=1, warmup=0, extra={
-                "config": f"BASELINE configs[4] at {args.extras_survey_size}x{args.extras_survey_size} on ONE GPU (the full 60000x60000 survey runs "
-                          "in tests/test_gpu_survey.py and with --workload survey --survey-size 60000)",
-                "survey": {k: sv[k] for k in ("size", "tiles_total", "tiles_processed", "tiles_skipped")}})
-            del sv
+
+            def _c5():
+                sv = bench.survey(args.extras_survey_size)
+                detail["config5"] = side(sv, steps=1, warmup=0, extra={
+                    "config": f"BASELINE configs[4] at {args.extras_survey_size}x{args.extras_survey_size} on ONE GPU (the full 60000x60000 survey runs "
+                              "in tests/test_gpu_survey.py and with --workload survey --survey-size 60000)",
+                    "survey": {k: sv[k] for k in ("size", "tiles_total", "tiles_processed", "tiles_skipped")}})
+                line["config5"] = brief(detail["config5"], "f32",
+                                        f"configs[4] at {args.extras_survey_size}^2 on one GPU: {sv['tiles_total']} overlapping 512x512 tiles, cut + classify + stitch on device")
+            guarded("config5", _c5)
             torch.cuda.empty_cache()
-        if extras and not args.no_cpu_baseline and wl["kind"] == "tiles":
-            line["cpu_baseline"] = cpu_baseline(args.cpu_runs, S, bench.model(7)[1], 100, wl["conn"])
-            line["gpu_over_cpu"] = rep["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        emit(line, detail, args.detail)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BGNN_ABI_VERSION 4
+#define BGNN_ABI_VERSION 5
 
 #define BGNN_OK 0
 #define BGNN_ERR_INVALID (-1)     /* bad argument (-> ValueError in the Python mirror)   */
@@ -42,6 +42,10 @@ typedef struct bgnn_graph bgnn_graph;
 
 int bgnn_abi_version(void);
 const char *bgnn_last_error(void);
+/* Identity of the kernels inside this library: the first 16 hex digits of the sha256 over its kernel sources (the .hip and .h files under csrc/,
+ * sorted by name), stamped at build time ("unknown" for a build outside __graft_entry__.build()).  Measurement tooling uses it to
+ * refuse counter data collected on other kernels (bench.py: roofline.traffic); no reference counterpart. */
+const char *bgnn_build_id(void);
 
 /* ---- context: one per GPU worker --------------------------------------------------- */
 /* stream == NULL: the context creates and owns a non-blocking HIP stream; otherwise it

@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
   RESOLVE(bgnn_graph_export); RESOLVE(bgnn_graph_scatter); RESOLVE(bgnn_forward); RESOLVE(bgnn_forward_train); RESOLVE(bgnn_infer_tiles);
   RESOLVE(bgnn_stitch_tiles); RESOLVE(bgnn_cut_tiles); RESOLVE(bgnn_tile_valid_counts); RESOLVE(bgnn_vr_unpack);
   RESOLVE(bgnn_vr_apply); RESOLVE(bgnn_feature_extractor); RESOLVE(bgnn_heads);
-  RESOLVE(bgnn_ctx_set_option); RESOLVE(bgnn_ctx_get_option);
+  RESOLVE(bgnn_ctx_set_option); RESOLVE(bgnn_ctx_get_option); RESOLVE(bgnn_build_id);
   *(void **)(&abi) = dlsym(lib, "bgnn_abi_version");
   *(void **)(&wcount) = dlsym(lib, "bgnn_model_weight_count");
   *(void **)(&ctx_create) = dlsym(lib, "bgnn_ctx_create");

@@ -34,6 +34,19 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert lib.bgnn_abi_version() == int(re.search(r"#define BGNN_ABI_VERSION (\d+)", HEADER).group(1))
 
 
+def test_build_id_is_the_kernel_source_hash(lib):
+    """bgnn_build_id() of a library built by __graft_entry__.build() = the hash of the kernel sources in the tree = what bench.py
+    compares profiles/pmc_traffic.json's stamp against before it attaches counter traffic to a roofline."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    import bench
+    from bathymetric_gnn_amd import runtime
+    assert __graft_entry__.kernel_source_sha() == bench.kernel_source_sha()
+    __graft_entry__.build()                       # no-op when up to date
+    assert runtime.build_id() == bench.kernel_source_sha() and len(runtime.build_id()) == 16
+
+
 def test_struct_layouts():
     from bathymetric_gnn_amd import runtime as rt
     assert C.sizeof(rt.ModelDesc) == 36

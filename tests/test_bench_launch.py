@@ -115,3 +115,75 @@ def test_every_workload_is_accepted_under_gpus_n(workload):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload],
                        env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode != 0 and b"WORLD_SIZE=4" in r.stderr
+
+
+# ---- the ONE stdout line: size budget, what may be dropped, where the rest goes -----------------------------------------------
+def _representative_line():
+    """A line with every key the default run produces, with worst-case-long strings."""
+    rf = {"bound": "mfma", "achieved": 104.71234567890123, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.6656855415060472,
+          "traffic": 13474343608.0, "traffic_frac": 0.27012345678901234, "kernel": "gat_layer_fused_kernel", "avg_launch_ms": 6.251234567890123}
+    brief = {"value": 812345678.1234567, "ms_per_step": 10.323456789012345, "dtype": "bf16", "workload": "w" * 120,
+             "roofline": {"bound": "hbm", "frac": 0.4512345678901234, "kernel": "gat_layer_fused_kernel"}}
+    return {"metric": "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)", "value": 303612345.1234567,
+            "unit": "nodes/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 27.63123456789012, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "x" * 200, "tiles_per_gpu": 128, "tile": 256, "nodes_per_step_per_gpu": 8388608,
+                       "parallelism": "tile-sharded x1, no collective"},
+            "roofline": rf, "path": "fused", "matrix_path": "exact f32",
+            "cpu_baseline": {"value": 15926.123456789, "unit": "nodes/s", "cores": 128, "kind": "port", "sample": "s" * 200},
+            "gpu_over_cpu": 19065.12345678901,
+            "pcie_inclusive": {"value": 291234567.1234567, "ms_per_step": 28.712345678901234},
+            "single_tile": {"value": 171234567.1234567, "ms_per_tile": 0.39123456789012345},
+            "config3": dict(brief), "config5": dict(brief),
+            "config4": dict(brief, one_context=157123456.12345678, two_contexts=203123456.12345678,
+                            processor_api={"synchronous": 15123456.123456789, "pipelined": 16123456.123456789}),
+            "detail": "gpurun_out/bench_detail.json"}
+
+
+def test_default_line_fits_the_stdout_budget_with_every_key():
+    line = _representative_line()
+    out = bench.compact_line(line)
+    assert out == line, "nothing had to be dropped"
+    assert len(json.dumps(out)) < 4096 and bench.LINE_BUDGET <= 4096
+
+
+def test_compact_line_drops_optional_keys_but_never_the_contract():
+    line = _representative_line()
+    line["config3"]["workload"] = "y" * 3000
+    out = bench.compact_line(line)
+    assert len(json.dumps(out)) <= bench.LINE_BUDGET
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out
+    line["config"]["workload"] = "z" * 9000
+    out = bench.compact_line(line)
+    assert len(json.dumps(out)) <= bench.LINE_BUDGET and "roofline" in out and "cpu_baseline" in out
+
+
+def test_emit_writes_detail_to_side_file_and_one_line_to_stdout(tmp_path, capsys):
+    line = _representative_line()
+    detail = {"rooflines": {"a": {"note": "n" * 5000}}, "kernels": {"fused": {"ms_per_step": 1.0}}, "config4": {"one_context": {"big": "b" * 9000}}}
+    side = tmp_path / "sub" / "detail.json"
+    bench.emit(line, detail, str(side))
+    cap = capsys.readouterr()
+    lines = [ln for ln in cap.out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{") and len(lines[0]) <= bench.LINE_BUDGET
+    j = json.loads(lines[0])
+    assert "rooflines" not in j and j["roofline"]["frac"] == line["roofline"]["frac"] and j["detail"] == str(side)
+    full = json.load(open(side))
+    assert full["rooflines"]["a"]["note"].startswith("n") and full["value"] == line["value"]
+    assert full["config4"]["one_context"]["big"].startswith("b")        # detail's full config4 wins over the line's brief one
+    assert "bench detail: {" in cap.err
+
+
+def test_pmc_traffic_is_refused_for_other_kernels(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json carries the kernel-source hash it was collected on; a library built from other sources gets no
+    `traffic` (null) instead of a stale one."""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "pmc_traffic.json").write_text(json.dumps({"_kernel_source_sha": "abc", "gat_layer_fused_kernel": {"hbm_bytes_per_launch": 1.0}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic_table("abc")["gat_layer_fused_kernel"]["hbm_bytes_per_launch"] == 1.0
+    assert bench.pmc_traffic_table("other") == {} and bench.pmc_traffic_table(None) == {}
+    (prof / "pmc_traffic.json").write_text(json.dumps({"gat_layer_fused_kernel": {"hbm_bytes_per_launch": 1.0}}))      # unstamped (rounds 1-3)
+    assert bench.pmc_traffic_table("abc") == {}

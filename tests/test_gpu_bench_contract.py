@@ -1,6 +1,7 @@
 """bench.py's ONE JSON line on a GPU, at small sizes: the driver's contract keys and a roofline whose fraction stays within (0, 1] --
-for the tile, configs[2], VR and survey workloads (each as its own child process, as the driver runs it; `--no-extras`: the default
-line's extras -- config3 / config4 / config5, cpu_baseline -- are what the round's evidence runs exercise)."""
+for the tile, configs[2], VR and survey workloads (each as its own child process, as the driver runs it), and the DEFAULT command
+shape (extras on: cpu_baseline, config3 / config4 / config5 at small sizes): exactly one stdout line, under 4 KB, that starts with
+`{` -- round 3's default line was 23 KB and the driver's tail of stdout lost its head."""
 import json
 import os
 import subprocess
@@ -39,3 +40,31 @@ def test_bench_line_contract(args, gpu_device):
     rf = j["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and 0 < rf["frac"] <= 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+def test_default_command_shape_prints_one_small_line(gpu_device, tmp_path):
+    """What the driver runs (`python bench.py --gpus 1 --steps K --warmup W`: every extra on), at small sizes."""
+    side = tmp_path / "detail.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tiles", "8",
+                        "--vr-grids", "300", "--extras-survey-size", "2048", "--cpu-runs", "1", "--detail", str(side)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), r.stdout[-500:]
+    assert len(out_lines[0]) < 4096
+    j = json.loads(out_lines[0])
+    for k in CONTRACT + ["cpu_baseline", "config3", "config4", "config5"]:
+        assert k in j, k
+    for k in ("config3", "config4", "config5"):
+        assert "error" not in j[k], j[k]
+        assert j[k]["value"] > 0 and j[k]["ms_per_step"] > 0 and j[k]["dtype"] in ("f32", "bf16")
+        assert j[k]["roofline"]["bound"] in ("hbm", "mfma") and 0 < j[k]["roofline"]["frac"] <= 1.0
+    assert j["config4"]["two_contexts"] > 0 and j["config4"]["processor_api"]["pipelined"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "nodes/s" and cb["sample"]
+    rf = j["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and "traffic" in rf and rf["kernel"] == "gat_layer_fused_kernel"
+    # the rest is in the side file (and on stderr), not on stdout
+    full = json.load(open(side))
+    assert "rooflines" in full and "kernels" in full and "one_context" in full["config4"] and "rooflines" in full["config3"]
+    assert "bench detail: {" in r.stderr

@@ -6,17 +6,19 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench_fused.json
-python3 $R/bench.py --unfused --no-cpu-baseline > $O/bench_unfused.json
-python3 $R/bench.py --split-bf16 --no-cpu-baseline > $O/bench_split.json
-python3 $R/bench.py --split-f16 --no-cpu-baseline > $O/bench_split_f16.json
-python3 $R/bench.py --workload c3 --no-cpu-baseline > $O/bench_c3.json
-python3 $R/bench.py --bf16 --no-cpu-baseline > $O/bench_bf16_k8.json
-python3 $R/bench.py --workload vr --vr-budget 50000 --vr-streams 1 > $O/bench_vr_50k_1ctx.json
-python3 $R/bench.py --workload vr --vr-budget 50000 --vr-streams 2 > $O/bench_vr_50k_2ctx.json
-python3 $R/bench.py --workload vr --vr-budget 50000 --vr-streams 4 > $O/bench_vr_50k.json
-python3 $R/bench.py --workload vr --vr-budget 1000000 --vr-streams 1 > $O/bench_vr_1M.json
-python3 $R/bench.py --workload survey --survey-size 20000 --steps 2 --warmup 0 > $O/bench_survey_20000.json
+# the kernels these profiles are collected on (bench.py refuses PMC traffic stamped with another id)
+python3 -c "import sys; sys.path.insert(0, '$R'); from bathymetric_gnn_amd import runtime; print(runtime.build_id())" > $O/build_id.txt
+python3 $R/bench.py --detail $O/bench_fused.detail.json > $O/bench_fused.json 2> $O/bench_fused.stderr
+python3 $R/bench.py --unfused --no-cpu-baseline --detail $O/bench_unfused.detail.json > $O/bench_unfused.json 2> $O/bench_unfused.stderr
+python3 $R/bench.py --split-bf16 --no-cpu-baseline --detail $O/bench_split.detail.json > $O/bench_split.json 2> $O/bench_split.stderr
+python3 $R/bench.py --split-f16 --no-cpu-baseline --detail $O/bench_split_f16.detail.json > $O/bench_split_f16.json 2> $O/bench_split_f16.stderr
+python3 $R/bench.py --workload c3 --no-cpu-baseline --detail $O/bench_c3.detail.json > $O/bench_c3.json 2> $O/bench_c3.stderr
+python3 $R/bench.py --bf16 --no-cpu-baseline --detail $O/bench_bf16_k8.detail.json > $O/bench_bf16_k8.json 2> $O/bench_bf16_k8.stderr
+python3 $R/bench.py --workload vr --vr-budget 50000 --vr-streams 1 --detail $O/bench_vr_50k_1ctx.detail.json > $O/bench_vr_50k_1ctx.json 2> $O/bench_vr_50k_1ctx.stderr
+python3 $R/bench.py --workload vr --vr-budget 50000 --vr-streams 2 --detail $O/bench_vr_50k_2ctx.detail.json > $O/bench_vr_50k_2ctx.json 2> $O/bench_vr_50k_2ctx.stderr
+python3 $R/bench.py --workload vr --vr-budget 50000 --vr-streams 4 --detail $O/bench_vr_50k.detail.json > $O/bench_vr_50k.json 2> $O/bench_vr_50k.stderr
+python3 $R/bench.py --workload vr --vr-budget 1000000 --vr-streams 1 --detail $O/bench_vr_1M.detail.json > $O/bench_vr_1M.json 2> $O/bench_vr_1M.stderr
+python3 $R/bench.py --workload survey --survey-size 20000 --steps 2 --warmup 0 --detail $O/bench_survey_20000.detail.json > $O/bench_survey_20000.json 2> $O/bench_survey_20000.stderr
 for mode in fused unfused split c3; do
   flag=""; [ $mode = unfused ] && flag="--unfused"; [ $mode = split ] && flag="--split-bf16"; [ $mode = c3 ] && flag="--workload c3"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${mode}_stats -- python3 $R/bench.py --no-extras --steps 5 --warmup 1 $flag > /dev/null 2>&1

@@ -81,8 +81,14 @@ def main():
                                ("bench_vr_1M", "bench_vr_budget1M"), ("bench_c3", "bench_c3_k16_bf16"), ("bench_bf16_k8", "bench_bf16_k8")):
         p = os.path.join(a.src, src_name + ".json")
         if os.path.exists(p):
+            # the stdout line is compact since round 4; the full record (rooflines of every kernel class, side measurements in
+            # full) is the --detail side file of the same run.  Both are kept: <name>.json = full record, <name>_line.json = stdout.
             line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
-            json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{dst_name}.json"), "w"), indent=1)
+            d = os.path.join(a.src, src_name + ".detail.json")
+            full = json.load(open(d)) if os.path.exists(d) else json.loads(line)
+            json.dump(full, open(os.path.join(dst, f"{tag}_{dst_name}.json"), "w"), indent=1)
+            if os.path.exists(d):
+                open(os.path.join(dst, f"{tag}_{dst_name}_line.json"), "w").write(line + "\n")
 
     all_k, classes = {}, {}
     for mode, label in (("fused", "fused, exact f32"), ("unfused", "unfused"), ("split", "fused, bf16x3"),
@@ -111,6 +117,9 @@ def main():
                 if mode == "unfused" and cls != "gat_aggregate_tiled_kernel":
                     continue
                 classes[key] = {"hbm_bytes_per_launch": tot / n, "launches_sampled": n, "path": label}
+    bid = os.path.join(a.src, "build_id.txt")
+    if os.path.exists(bid):
+        classes["_kernel_source_sha"] = open(bid).read().strip()      # bgnn_build_id() of the library that was profiled
     classes["_note"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
                         "(tools/collect_profiles.sh: bench.py, 128 tiles of 256x256; full-batch launches only), KiB -> bytes, "
                         "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; launch-weighted mean over the "
@@ -119,7 +128,7 @@ def main():
     json.dump(all_k, open(os.path.join(dst, f"{tag}_pmc_traffic_all.json"), "w"), indent=1)
     json.dump(classes, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     for k, v in classes.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e9:8.2f} GB/launch  ({v['launches_sampled']} launches, {v['path']})")
 
 
