@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   const int64_t stride = (int64_t)gridDim.x * NW * 32;
   int64_t row0 = (int64_t)blockIdx.x * NW * 32 + wave * 32;
   float4 ax[K / 8];
-  float4 xq;                                          // FRONT: features 4h..4h+3 of the lane's row
+  f32x4 xq;                                           // FRONT: features 4h..4h+3 of the lane's row
   float w0[2][4];                                     // FRONT: W0^T[4h + i][32 t + r], resident
   if constexpr (FRONT) {
 #pragma unroll
@@ -310,10 +310,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) w0[t][i] = a.W0t[(4 * h + i) * 64 + t * 32 + r];
   }
+  // An attention GEMM has no activation (GATConv's lin), and the fused front always carries the folded bias: known at compile time,
+  // so the epilogue's 4 x NT uniform branches and NT x 16 v_max are not in the loop at all.
+  const bool relu = ATT ? false : a.relu != 0;
+  const bool has_bias = FRONT ? true : a.bias != nullptr;
+  // FRONT: the next block's feature row is requested by an asm load the compiler does not track.  vmcnt is ONE in-order queue for
+  // loads and stores on gfx9: left to hipcc, the wait for that row at the top of the loop is vmcnt(0), i.e. for every row store of
+  // the block before it as well -- each wave then idles for HBM's write latency once per block.  The load is issued BEFORE the
+  // epilogue's NT / 2 x 8 row-segment stores (unconditional: rows past M go to the dump row), so `vmcnt(8 * (NT / 2))` at the top of
+  // the next block leaves exactly those stores in flight (the [alpha_src | alpha_dst] stores behind them, when issued, only make
+  // the wait wake up earlier than strictly possible).
+  constexpr int STORES_AFTER_X = 8 * (NT / 2);
   auto load_x = [&](int64_t rb) {
     const int64_t row = rb + r;
     if constexpr (FRONT) {
-      xq = *reinterpret_cast<const float4 *>(a.X + (row < M ? row : M - 1) * 8 + 4 * h);
+      const float *xp = a.X + (row < M ? row : M - 1) * 8 + 4 * h;
+      if constexpr (SP == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xq) : "v"(xp) : "memory");
+      else xq = *reinterpret_cast<const f32x4 *>(xp);
     } else {
       const float *xp = a.X + (row < M ? row : M - 1) * a.ldx + (SP ? 8 * h : 4 * h);
 #pragma unroll
@@ -321,8 +334,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
         ax[s] = *reinterpret_cast<const float4 *>(xp + (SP ? (s >> 1) * 16 + (s & 1) * 4 : s * 8));
     }
   };
-  if (row0 < M) load_x(row0);
-  for (; row0 < M; row0 += stride) {
+  if (row0 < M) {
+    load_x(row0);
+    if constexpr (FRONT && SP == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq));
+  }
+  for (bool first = true; row0 < M; row0 += stride, first = false) {
+    if constexpr (FRONT && SP == 0) {
+      if (!first) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xq) : "n"(STORES_AFTER_X));
+    }
     if constexpr (FRONT) {
       // extractor layer 1 on the spot: the instruction sequence of gemm_f32_kernel<2, false> (K = 8)
       f32x16 a1[2];
@@ -430,11 +449,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         v[g] = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-        if (a.bias) {
+        if (has_bias) {
           const float4 b = *reinterpret_cast<const float4 *>(biasl + t * 32 + 8 * g + 4 * h);
           v[g].x += b.x; v[g].y += b.y; v[g].z += b.z; v[g].w += b.w;
         }
-        if (a.relu) {
+        if (relu) {
           v[g].x = v[g].x > 0.f ? v[g].x : 0.f; v[g].y = v[g].y > 0.f ? v[g].y : 0.f;
           v[g].z = v[g].z > 0.f ? v[g].z : 0.f; v[g].w = v[g].w > 0.f ? v[g].w : 0.f;
         }

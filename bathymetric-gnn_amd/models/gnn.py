@@ -218,18 +218,26 @@ class BathymetricGNN(nn.Module):
         logger.info(f"Created BathymetricGNN: {gnn_type} with {num_gnn_layers} layers, {hidden_channels} hidden channels")
 
     # ---- weights -> library ------------------------------------------------------------------
-    def _desc(self) -> rt.ModelDesc:
+    def _edge_width(self, graph_edge_dim: Optional[int] = None) -> int:
+        """Columns of edge_attr the packed model is built for.  With ``edge_dim`` given it is that (a graph of another width is
+        refused by the library, as GATConv's lin_edge would refuse it); with ``edge_dim=None`` GATConv ignores edge_attr whatever
+        its width (reference models/gnn.py:93,130), so the width is the GRAPH's and the edge weights packed for it are zeros."""
+        if self.edge_dim is not None:
+            return int(self.edge_dim)
+        return int(graph_edge_dim) if graph_edge_dim else 3
+
+    def _desc(self, graph_edge_dim: Optional[int] = None) -> rt.ModelDesc:
         d = rt.ModelDesc()
         d.in_channels, d.hidden, d.num_layers = self.in_channels, self.hidden_channels, self.num_gnn_layers
-        # (edge_dim=None: the library is told the graph builder's 3 edge features and gets zero edge weights for them)
-        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, (self.edge_dim if self.edge_dim is not None else 3)
+        d.heads, d.num_classes, d.edge_dim = self.heads, self.num_classes, self._edge_width(graph_edge_dim)
         d.gnn_type = rt.GNN_TYPES[self.gnn_type]
         d.predict_correction = 1 if self.predict_correction else 0
         d.bn_eps = float(self.gnn.norms[0].module.eps)
         return d
 
-    def pack_weights(self) -> np.ndarray:
+    def pack_weights(self, graph_edge_dim: Optional[int] = None) -> np.ndarray:
         """Flat float32 blob in the order ``bgnn_model_weight_count`` documents (include/bgnn.h)."""
+        ed = self._edge_width(graph_edge_dim)
         sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy().ravel() for k, v in self.state_dict().items()
               if v.dtype.is_floating_point}
         parts = []
@@ -238,8 +246,8 @@ class BathymetricGNN(nn.Module):
         for l in range(self.num_gnn_layers):
             c, n = f"gnn.convs.{l}.", f"gnn.norms.{l}.module."
             if self.gnn_type == "GAT":
-                if self.edge_dim is None:        # no edge term: zero att_edge / lin_edge over the builder's 3 edge features
-                    att_e, lin_e = np.zeros_like(sd[c + "att_src"]), np.zeros(sd[c + "att_src"].size * 3, np.float32)
+                if self.edge_dim is None:        # no edge term: zero att_edge / lin_edge over however many edge features the graph has
+                    att_e, lin_e = np.zeros_like(sd[c + "att_src"]), np.zeros(sd[c + "att_src"].size * ed, np.float32)
                 else:
                     att_e, lin_e = sd[c + "att_edge"], sd[c + "lin_edge.weight"]
                 parts += [sd[c + "lin.weight"], sd[c + "att_src"], sd[c + "att_dst"], att_e, lin_e, sd[c + "bias"]]
@@ -261,7 +269,7 @@ class BathymetricGNN(nn.Module):
     def _drop_native(self, only_ctx_id=None):
         """Destroy the packed copies (all, or the one on the context with this id -- called when that context closes)."""
         for cid, (wctx, h) in list((self._native or {}).items()):
-            if only_ctx_id is not None and cid != only_ctx_id:
+            if only_ctx_id is not None and cid[0] != only_ctx_id:
                 continue
             ctx = wctx()
             try:
@@ -273,23 +281,25 @@ class BathymetricGNN(nn.Module):
         if only_ctx_id is None:
             self._native, self._native_key = {}, None
 
-    def native(self, ctx: rt.Context):
-        """The packed model on ``ctx`` (one per library context; rebuilt when a weight changes)."""
+    def native(self, ctx: rt.Context, graph_edge_dim: Optional[int] = None):
+        """The packed model on ``ctx`` (one per library context -- and, for ``edge_dim=None`` models, per edge_attr width of the
+        graphs they meet; rebuilt when a weight changes)."""
         key = self._weights_version()
         if self._native is None or self._native_key != key:
             self._drop_native()
             self._native_key = key
-        ent = self._native.get(id(ctx))
+        ed = self._edge_width(graph_edge_dim)
+        ent = self._native.get((id(ctx), ed))
         if ent is None:
-            blob = self.pack_weights()
-            desc = self._desc()
+            blob = self.pack_weights(ed)
+            desc = self._desc(ed)
             n = ctx.lib.bgnn_model_weight_count(C.byref(desc))
             if n != blob.size:
                 raise ValueError(f"weight blob has {blob.size} floats, library expects {n}")
             h = C.c_void_p()
             rt.check(ctx.lib.bgnn_model_create(ctx.handle, C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)),
                                                blob.size, C.byref(h)))
-            ent = self._native[id(ctx)] = (weakref.ref(ctx), h)
+            ent = self._native[(id(ctx), ed)] = (weakref.ref(ctx), h)
             me, cid = weakref.ref(self), id(ctx)
             ctx.on_close(lambda: me() is not None and me()._drop_native(cid))
         return ent[1]
@@ -315,7 +325,10 @@ class BathymetricGNN(nn.Module):
         ei = data.edge_index.detach().to(ctx.device, torch.int64).contiguous()
         ea = getattr(data, "edge_attr", None)
         if ea is None:
-            raise NotImplementedError("edge_attr=None is outside the built path")
+            if self.edge_dim is not None or self.gnn_type != "GAT":
+                raise NotImplementedError("edge_attr=None is outside the built path")
+            # GATConv(edge_dim=None) never looks at edge_attr (reference models/gnn.py:93,130,176): one column of zeros stands in
+            ea = torch.zeros((ei.shape[1], 1), dtype=torch.float32, device=ctx.device)
         ea = ea.detach().to(ctx.device, torch.float32).contiguous()
         h = C.c_void_p()
         ctx.begin()
@@ -359,7 +372,7 @@ class BathymetricGNN(nn.Module):
             o.auto_correct = extra["auto_correct"].data_ptr()
         if hidden is not None:
             o.hidden = hidden.data_ptr()
-        model_h = self.native(ctx)
+        model_h = self.native(ctx, g.edge_dim)
         if N > 0 and train:
             if N == 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size "

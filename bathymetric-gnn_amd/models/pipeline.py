@@ -55,7 +55,9 @@ def exchange_tile_results(mine: dict) -> dict:
         keys = [k for k in TILE_RESULT_CHANNELS if k in have] + sorted(have - set(TILE_RESULT_CHANNELS))
     shape = tuple(next(iter(mine.values()))[keys[0]].shape) if mine else (0, 0)
     # agree on (channel names are fixed by the caller) count, tile shape
-    meta = torch.tensor([len(mine), len(keys), shape[0], shape[1]], dtype=torch.int64, device=dev)
+    # (last entry: are this rank's channels the standard ones in the standard order?  A rank WITHOUT tiles can only unpack those.)
+    std = int(keys == list(TILE_RESULT_CHANNELS)[:len(keys)])
+    meta = torch.tensor([len(mine), len(keys), shape[0], shape[1], std], dtype=torch.int64, device=dev)
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
     metas = [m.cpu().numpy() for m in metas]
@@ -63,10 +65,15 @@ def exchange_tile_results(mine: dict) -> dict:
     nk, th, tw = (int(max(m[i] for m in metas)) for i in (1, 2, 3))
     if nmax == 0:
         return mine
-    assert all(m[0] == 0 or (m[1], m[2], m[3]) == (nk, th, tw) for m in metas), "tiles of one survey share one shape"
+    # Every check below reads only `metas`, which all ranks hold alike, and runs BEFORE the next collective: the ranks fail
+    # together instead of one raising while the others wait in the block all_gather.
+    if not all(m[0] == 0 or (m[1], m[2], m[3]) == (nk, th, tw) for m in metas):
+        raise ValueError("exchange_tile_results: tiles of one survey share one shape and one channel count")
+    if any(m[0] == 0 for m in metas) and (nk > len(TILE_RESULT_CHANNELS) or any(m[0] > 0 and m[4] == 0 for m in metas)):
+        raise ValueError(f"exchange_tile_results: a rank without tiles can only unpack the standard channels {TILE_RESULT_CHANNELS} "
+                         "in that order, and another rank packed something else")
     if not keys:                                           # this rank holds no tile: it still takes part in the collective,
         keys = list(TILE_RESULT_CHANNELS)[:nk]             # and unpacks in the same channel order the packing ranks used
-        assert nk <= len(TILE_RESULT_CHANNELS), "a rank without tiles can only name the standard result channels"
     idx = torch.full((nmax,), -1, dtype=torch.int64)
     blk = torch.zeros((nmax, nk, th, tw), dtype=torch.float32)
     for j, (i, r) in enumerate(sorted(mine.items())):
@@ -210,7 +217,7 @@ class TileBatchEngine:
         # `out`: a [3, cells] tensor, or three 1-D [cells] tensors (classification, confidence, correction)
         assert all(o.is_contiguous() and o.numel() == cells for o in (out[0], out[1], out[2]))
         tiles, keep = rt.make_tiles(hw, res, depth_t, mask_t, unc_t)
-        model_h = self.model.native(ctx)
+        model_h = self.model.native(ctx, int(self.graph_builder._opts.n_edge_features))
         ctx.begin()
         rt.check(ctx.lib.bgnn_infer_tiles(
             ctx.handle, model_h, C.byref(tiles), C.byref(self.graph_builder._opts),

@@ -213,7 +213,7 @@ def visible_gpu_count(env=None, sysfs="/sys/class/kfd/kfd/topology/nodes", dev_d
     return n
 
 
-def launch_plan(gpus, env, n_devices):
+def launch_plan(gpus, env, n_devices, share_gpu=False):
     """What `bench.py --gpus N` does with its process: ("worker", None) when a launcher (torch.distributed.run, or this
     file's own spawn) already set WORLD_SIZE; ("single", None) for N = 1; ("spawn", None) when N > 1 ranks must be
     started from here; ("error", reason) when that cannot work.  Pure function (unit-tested on CPU).  ``n_devices`` may be
@@ -227,6 +227,8 @@ def launch_plan(gpus, env, n_devices):
         return ("worker" if world > 1 else "single"), None
     if gpus == 1:
         return "single", None
+    if share_gpu:                # rehearsal: the N ranks all use device 0 (gloo transport), whatever the node has
+        return "spawn", None
     if callable(n_devices):
         n_devices = n_devices()
     if n_devices < gpus:
@@ -440,7 +442,21 @@ class Bench:
         halo = 0
         if world > 1:                # every halo tile row travels as [3][ntc][cells] results + ntc keep flags, float32
             halo = sum(len(p["need"]) for p in plan) * (3 * ntc * tile * tile + ntc) * 4
-        return {"kind": "survey", "step": step, "check": lambda: None, "nodes_per_step": n_proc * tile * tile,
+        def stitched_sha256():
+            """sha256 over the stitched [4, H, W] result of the last step, on rank 0 (None elsewhere): the bands of a sharded run
+            are gathered to rank 0 first (gather_bands_to_rank0), so that 1 rank and N ranks can be compared bit for bit."""
+            import hashlib
+            from bathymetric_gnn_amd.models.pipeline import gather_bands_to_rank0
+            if shard is None:
+                host = state["out"].cpu().numpy()
+            else:
+                band = state["out"][2] if hi > lo else None
+                host = gather_bands_to_rank0(plan, rank, band, S, device=self.dev)
+                if host is None:
+                    return None
+            return hashlib.sha256(np.ascontiguousarray(host).tobytes()).hexdigest()
+
+        return {"kind": "survey", "step": step, "check": lambda: None, "nodes_per_step": n_proc * tile * tile, "sha256": stitched_sha256,
                 "contexts": [pipe._engine.ctx], "options": {}, "deg": 8, "conn": "8-connected", "bf16": False, "split": None,
                 "unfused": False, "size": S, "tiles_total": ntr * ntc, "tiles_processed": n_proc, "tiles_skipped": n_skip,
                 "halo_bytes_all_ranks": halo, "events_in_timed_region": True, "scaling": "strong" if world > 1 else "weak",
@@ -491,10 +507,11 @@ class Bench:
                     c.set_option(k, v)
         nodes_all = wl["nodes_per_step"]
         if self.dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            rdev = torch.device("cpu") if self.dist.get_backend() == "gloo" else self.dev      # (gloo: the --share-gpu rehearsal)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            n = torch.tensor([wl["nodes_per_step"]], dtype=torch.int64, device=self.dev)
+            n = torch.tensor([wl["nodes_per_step"]], dtype=torch.int64, device=rdev)
             self.dist.all_reduce(n, op=self.dist.ReduceOp.SUM)
             nodes_all = int(n.item())
         return {"elapsed": elapsed, "prof": prof, "steps": steps, "warmup": warmup, "nodes_all_ranks_per_step": nodes_all}
@@ -628,6 +645,11 @@ def main():
                          "batch's kernels overlaps the head of the next one's (two is what NativeVRProcessor keeps in flight, "
                          "and the fastest: 203 M nodes/s against 193 M with four)")
     ap.add_argument("--survey-size", type=int, default=20000, help="survey workload: side of the square survey in cells (config 5: 60000)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the multi-rank path on a one-GPU box: with --gpus N the N ranks all use device 0 and talk over "
+                         "gloo (host-staged halo rows); the line says `rehearsal` and is no scaling measurement")
+    ap.add_argument("--checksum", action="store_true",
+                    help="survey workload: add the sha256 of the stitched result (rank 0; the bands of a sharded run gathered first)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="side file for the full record (rooflines of every kernel class, per-kernel times, the side measurements "
                          "in full); stdout carries ONE compact line")
@@ -636,20 +658,23 @@ def main():
 
     # N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (the device count comes from the KFD
     # topology in sysfs, not from the HIP runtime), wait for them and leave with their status.
-    mode, why = launch_plan(args.gpus, os.environ, visible_gpu_count)
+    mode, why = launch_plan(args.gpus, os.environ, visible_gpu_count, share_gpu=args.share_gpu)
     if mode == "error":
         raise SystemExit(f"bench.py: {why}")
     if mode == "spawn":
         raise SystemExit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # RCCL: the timing barrier / max; the survey workload's halo rows
+        if args.share_gpu:
+            dist.init_process_group("gloo")                # rehearsal: RCCL cannot put two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # RCCL: the timing barrier / max; the survey workload's halo rows
 
     bench = Bench(dev, rank, world, args.layers, dist)
     S, B = args.tile_size, args.tiles
@@ -662,6 +687,7 @@ def main():
     else:
         wl = bench.survey(args.survey_size)
     m = bench.measure(wl, args.steps, args.warmup)
+    sha = wl["sha256"]() if (args.checksum and "sha256" in wl) else None          # (every rank: the band gather is point-to-point)
 
     if rank == 0:
         rep = bench.report(wl, m)
@@ -686,6 +712,12 @@ def main():
         detail = {"rooflines": rep["rooflines"], "kernels": rep["kernels"], "kernel_events": rep["kernel_events"]}
         if wl["kind"] == "survey":
             line["survey"] = {k: wl[k] for k in ("size", "tiles_total", "tiles_processed", "tiles_skipped", "halo_bytes_all_ranks")}
+            if sha is not None:
+                line["survey"]["stitched_sha256"] = sha
+        if args.share_gpu and world > 1:
+            line["rehearsal"] = True
+            line["rehearsal_note"] = (f"{world} ranks share ONE GPU and talk over gloo (host-staged halo rows): a functional rehearsal of "
+                                      "the multi-rank code path, NOT a scaling measurement -- `value` earns no credit")
         extras = not args.no_extras and world == 1
         default_headline = wl["kind"] == "tiles" and not wl["unfused"] and not wl["bf16"] and not wl["split"]
 

@@ -116,3 +116,37 @@ def test_exchange_channel_order_on_a_rank_without_tiles():
         assert list(got[rank].keys()) == [5]
         for k, v in want.items():
             assert np.all(got[rank][5][k] == v), (rank, k, got[rank][5][k][0, 0])
+
+
+def _exchange_bad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bathymetric_gnn_amd.models.pipeline import exchange_tile_results
+    mine = {}
+    if rank == 0:          # a non-standard channel next to a rank that holds no tile: rank 1 could not name it
+        mine = {3: {"classification": np.zeros((4, 6), np.float32), "my_extra_layer": np.ones((4, 6), np.float32)}}
+    try:
+        exchange_tile_results(mine)
+        q.put((rank, "returned"))
+    except ValueError as e:
+        q.put((rank, "ValueError: " + str(e)[:60]))
+    dist.barrier()               # both ranks get here: nobody is left inside a collective
+    dist.destroy_process_group()
+
+
+def test_exchange_refuses_unknown_channels_on_every_rank_together():
+    """the channel check used to fire only on the rank WITHOUT tiles, after the metadata all_gather -- the other
+    ranks went on into the block all_gather and hung.  Now every rank raises from the same metadata, before the next collective."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_bad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert got[0].startswith("ValueError") and got[1].startswith("ValueError"), got
