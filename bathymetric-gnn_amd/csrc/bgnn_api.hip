@@ -694,6 +694,10 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.Wfp = l > 0 ? m->blob + o_wfp[l] : nullptr;
     Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
   }
+  for (int l = 0; l < L && gat; ++l) {                 // host copy of the folded edge vectors (model_canonical_V)
+    const int H = l == L - 1 ? 1 : d->heads;
+    m->h_V.insert(m->h_V.end(), pk.begin() + lo[l].V, pk.begin() + lo[l].V + (size_t)H * ED);
+  }
   m->head_hidden_total = HT;
   m->hd_W0sp = gat ? m->blob + o_hW0sp : nullptr;
   m->hd_W0sp16 = gat && f16_ok ? m->blob + o_hW0sp16 : nullptr;
@@ -708,7 +712,41 @@ int bgnn_model_destroy(bgnn_model *m) {
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
   (void)hipFree(m->blob);
+  for (auto &kv : m->v3_tables) (void)hipFree(kv.second);
   delete m;
+  return BGNN_OK;
+}
+
+// The edge vectors of every GAT layer over the canonical attributes (distance, depth_difference, slope) for a graph built with
+// another edge feature list: device table [layers][heads][3], V3[l][h][id] = sum over the list positions j with ids[j] == id of
+// V_l[h][j] ("zero" columns drop out, a repeated attribute adds up).  Made once per (model, list) and kept with the model.
+static int model_canonical_V(bgnn_model *m, const bgnn_graph *g, const float **out) {
+  const int ED = g->ED, heads = m->desc.heads;
+  uint32_t key = (uint32_t)ED;
+  for (int j = 0; j < 4; ++j) key = key * 8u + (uint32_t)(j < ED ? g->edge_ids[j] : 7);
+  for (auto &kv : m->v3_tables)
+    if (kv.first == key) { *out = kv.second; return BGNN_OK; }
+  const size_t L = m->layers.size();
+  std::vector<float> t(L * (size_t)heads * 3, 0.0f);
+  size_t off = 0;
+  for (size_t l = 0; l < L; ++l) {
+    const int H = m->layers[l].heads;
+    for (int h = 0; h < H; ++h)
+      for (int j = 0; j < ED; ++j) {
+        const int id = g->edge_ids[j];
+        if (id >= 0 && id < 3) t[(l * heads + h) * 3 + id] += m->h_V[off + (size_t)h * ED + j];
+      }
+    off += (size_t)H * ED;
+  }
+  float *d = nullptr;
+  BGNN_HIP_CHECK(hipMalloc((void **)&d, t.size() * sizeof(float)));
+  if (hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    set_error("hipMemcpy(canonical edge vectors) failed");
+    return BGNN_ERR_HIP;
+  }
+  m->v3_tables.emplace_back(key, d);
+  *out = d;
   return BGNN_OK;
 }
 
@@ -950,8 +988,12 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
   GALLOC(g->d_local_std, float, cells)
   GALLOC(g->d_nbr, int32_t, cells * g->K)
   // default edge feature list on a stencil the fused kernels know: compact edge storage (graph_build.hip, FeatureArgs)
-  g->compact_edges = g->ED == 3 && (g->K == 4 || g->K == 8 || g->K == 16) && opts->edge_features[0] == BGNN_EF_DISTANCE &&
-                     opts->edge_features[1] == BGNN_EF_DEPTH_DIFFERENCE && opts->edge_features[2] == BGNN_EF_SLOPE;
+  // every edge feature list is a selection / ordering of (distance, depth_difference, slope, zero): all of them are built compact
+  // (round 3: the default list only -- any other list carried the full table and ran on the unfused kernels)
+  g->compact_edges = g->K == 4 || g->K == 8 || g->K == 16;
+  for (int i = 0; i < 4; ++i) g->edge_ids[i] = i < g->ED ? opts->edge_features[i] : BGNN_EF_ZERO;
+  g->edge_default = g->ED == 3 && opts->edge_features[0] == BGNN_EF_DISTANCE && opts->edge_features[1] == BGNN_EF_DEPTH_DIFFERENCE &&
+                    opts->edge_features[2] == BGNN_EF_SLOPE;
   if (g->compact_edges) {
     GALLOC(g->d_slope, float, cells * g->K)
     GALLOC(g->d_node_depth, float, cells)
@@ -1080,9 +1122,9 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   // only on the fused stencil path of the default model shape and only in eval mode
   const bool bf16 = ctx->opts.matrix_path == 3 && !tr;
   if (bf16) {
-    BGNN_REQUIRE(gat && use_fused && g->kind == 0 && hid == 64 && d.heads == 4 && d.num_layers >= 2 && g->ED == 3 && !o->hidden,
+    BGNN_REQUIRE(gat && use_fused && g->kind == 0 && hid == 64 && d.heads == 4 && d.num_layers >= 2 && g->compact_edges && !o->hidden,
                  "matrix_path = bf16 (bf16 activation storage) runs on the fused stencil path of the default model shape only "
-                 "(GAT, hidden 64, heads 4, >= 2 layers, 3 edge features, graphs built by bgnn_graph_build)");
+                 "(GAT, hidden 64, heads 4, >= 2 layers, graphs built by bgnn_graph_build)");
   }   // the fused layers carry the folded eval statistics
   void *bnws = nullptr;
   if (tr) BGNN_TRY(ctx_workspace(ctx, 5, bn_train_workspace_bytes(maxw >= 256 ? 256 : maxw), &bnws));
@@ -1170,7 +1212,11 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   }
   // GNN backbone (gnn.py:173-188).  Invariant at the top of each iteration: X = lin_l(h_l), asdX = its dots.
   const size_t nl = gat ? m->layers.size() : 0;
+  // a graph built with another edge feature list than the default: the fused kernels take the edge vectors over the canonical three
+  const float *v3_all = nullptr;
+  if (gat && use_fused && g->kind == 0 && g->compact_edges && !g->edge_default) BGNN_TRY(model_canonical_V(m, g, &v3_all));
   for (size_t l = 0; l < nl; ++l) {
+    const float *V3 = v3_all ? v3_all + l * (size_t)d.heads * 3 : nullptr;
     const BgnnLayer &Leval = m->layers[l];
     BgnnLayer Ltrain = Leval;                          // training mode: out = aggregate + bias, BatchNorm afterwards
     Ltrain.scale = m->ones; Ltrain.shift = Leval.tr_bias;
@@ -1178,7 +1224,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     const int relu = L.concat ? 1 : 0;
     if (l + 1 < nl) {
       const BgnnLayer &Ln = m->layers[l + 1];
-      int rc = use_fused ? launch_fused_layer_next(ctx, g, L, Ln, hid, d.edge_dim, X, asdX, Y, asdY) : BGNN_ERR_UNSUPPORTED;
+      int rc = use_fused ? launch_fused_layer_next(ctx, g, L, Ln, hid, V3, X, asdX, Y, asdY) : BGNN_ERR_UNSUPPORTED;
       if (rc == BGNN_OK) { std::swap(X, Y); std::swap(asdX, asdY); continue; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
       BGNN_REQUIRE(!bf16, "matrix_path = bf16: no fused instance for layer %d of this model / graph", (int)l);
@@ -1189,7 +1235,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       BGNN_TRY(launch_gemm_f32(ctx, Y, Ln.d_in, Ln.Wt, nullptr, X, Ln.heads * hid, dm, rows, Ln.d_in, Ln.heads * hid, 0,
                                Ln.att_src, Ln.att_dst, asdX, Ln.heads, hid));
     } else {
-      int rc = use_fused ? launch_fused_layer_heads(ctx, g, m, L, hid, d.edge_dim, X, asdX, thr_auto, thr_review,
+      int rc = use_fused ? launch_fused_layer_heads(ctx, g, m, L, hid, V3, X, asdX, thr_auto, thr_review,
                                                     grids ? grids->norm_floor : 0.01f, o, grids ? grids->cls : nullptr,
                                                     grids ? grids->conf : nullptr, grids ? grids->corr : nullptr)
                          : BGNN_ERR_UNSUPPORTED;
@@ -1301,7 +1347,7 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
     o.predicted_class = (int64_t *)p;
     o.confidence = (float *)(o.predicted_class + rows);
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
-    const bool try_fused = ctx->opts.fused && g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->ED == 3 &&
+    const bool try_fused = ctx->opts.fused && g->kind == 0 && g->compact_edges &&
                            m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
     if (try_fused && g->d_atlas) {          // the canvas walk writes valid cells only: clear the grids (fill 0.0) first
       const size_t nb = (size_t)g->total_cells * sizeof(float);

@@ -167,6 +167,12 @@ struct bgnn_model {
   float *hd_W0sp = nullptr, *hd_W0sp16 = nullptr;   // hd_W0t as bf16 / float16 hi / lo split images
   float *hd_W1, *hd_b1;       // second layers packed: cls [classes][hid/2], conf [hid/2], corr [hid/2]; biases
   float *hd_tab = nullptr;    // fused heads epilogue's LDS image, [296]: b0 [96] | second-layer rows [<= 6][32] | their biases [8]
+  // The fused layer kernels rebuild a slot's attributes in the CANONICAL order (distance, depth_difference, slope).  For a graph built
+  // with another edge feature list (any selection / order / repetition of those three and "zero"), the folded edge vector
+  // V [heads][edge_dim] of every layer is re-expressed over the canonical three: V3[h][id] = sum of V[h][j] over the list positions j
+  // that hold attribute id.  One small device table [layers][heads][3] per list, made on first use (model_canonical_V).
+  std::vector<float> h_V;                             // host copy of every layer's V: [layers][heads_l][edge_dim]
+  std::vector<std::pair<uint32_t, float *>> v3_tables;   // (packed list, device table [layers][max heads][3])
 };
 
 struct bgnn_graph {
@@ -200,6 +206,8 @@ struct bgnn_graph {
   // grid graphs with the default edge feature list are built COMPACT (graph_build.hip, FeatureArgs): slopes, node depths and the
   // tiles' edge lengths; the fused layer kernels read those, d_eattr is expanded on demand (ensure_edge_attrs)
   bool compact_edges = false;
+  int32_t edge_ids[4] = {0, 1, 2, 3};  // the edge feature list the graph was built with (BGNN_EF_*), ED entries
+  bool edge_default = false;          // ... is [distance, depth_difference, slope]
   mutable bool eattr_valid = false;
   float *d_slope = nullptr;           // [rows][K]
   float *d_node_depth = nullptr;      // [rows]
@@ -271,9 +279,10 @@ int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L,
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                                const float *asd, float *out, int relu);
 // fused K4 + next K3 (EPI_NEXT) / K4(last) + K5 + K6 (EPI_HEADS); BGNN_ERR_UNSUPPORTED when no instance fits
-int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, int ED,
+// (V3: the layer's edge vector over the canonical three attributes, [heads][3] -- nullptr: L.V is that already, default list)
+int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
                             const void *xw, const float *asd, void *xw_next, float *asd_next);
-int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
+int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, const float *V3,
                              const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);
 int launch_degree_inv_sqrt(bgnn_ctx *ctx, const bgnn_graph *g, float *dinv);

@@ -1824,13 +1824,14 @@ static int launch_by_stencil(bgnn_ctx *ctx, const bgnn_graph *g, int sp, const F
   return g->K == 8 ? launch_inst<HC, 64, 8, NT, EPI, 2>(ctx, a) : launch_inst<HC, 64, 4, NT, EPI, 2>(ctx, a);
 }
 
-static bool fused_supported(const bgnn_graph *g, int C, int ED) {
-  // (compact_edges: the default edge feature list -- another list of three runs on the unfused kernels, from the full table)
-  return g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->n_blocks3 > 0 && C == 64 && ED == 3 && g->max_w <= 8192 &&
-         g->compact_edges;
+static bool fused_supported(const bgnn_graph *g, int C) {
+  // (compact_edges: slopes + node depths + tile edge lengths, from which the kernels rebuild the canonical attributes; any edge
+  //  feature list over distance / depth_difference / slope / zero is built that way -- the caller passes the layer's edge vector
+  //  re-expressed over the canonical three, model_canonical_V)
+  return g->kind == 0 && (g->K == 4 || g->K == 8 || g->K == 16) && g->n_blocks3 > 0 && C == 64 && g->max_w <= 8192 && g->compact_edges;
 }
 
-static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, const void *xw, const float *asd, int relu) {
+static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, const float *V3, const void *xw, const float *asd, int relu) {
   a.tb.tiles = g->d_tiles; a.tb.items2 = g->uni_h ? nullptr : g->d_items3;
   a.tb.bh = g->bh3; a.tb.bw = g->bw3; a.tb.n_blocks = g->n_blocks3;
   a.node_id = g->d_node_id; a.cell_map = nullptr; a.tile_of_cell = nullptr;
@@ -1839,7 +1840,7 @@ static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, c
     a.tb.bh = g->atlas_h / 8; a.tb.bw = g->atlas_w / 16; a.tb.n_blocks = a.tb.bh * a.tb.bw;
     a.node_id = g->d_atlas; a.cell_map = g->d_cell_of_node; a.tile_of_cell = g->d_atlas_tile_of;
   }
-  a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = L.V; a.scale = L.scale; a.shift = L.shift;
+  a.xw = xw; a.asd = asd; a.eattr = g->d_eattr; a.V = V3 ? V3 : L.V; a.scale = L.scale; a.shift = L.shift;
   a.slope = g->d_slope; a.node_depth = g->d_node_depth; a.tile_dist = g->d_tile_dist;
   a.relu = relu; a.zero_page = g->ctx->zero_page; a.dump = g->ctx->zero_page + 2048;
   a.dbg = BGNN_DIAG ? g->ctx->opts.diag_mask : 0;
@@ -1847,13 +1848,13 @@ static void fill_common(FusedArgs &a, const bgnn_graph *g, const BgnnLayer &L, c
 }
 
 // aggregate of layer L (width HC = L.heads*C) fused with the GEMM of the next layer `Ln`
-int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, int ED,
+int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
                             const void *xw, const float *asd, void *xw_next, float *asd_next) {
-  if (!fused_supported(g, C, ED)) return BGNN_ERR_UNSUPPORTED;
+  if (!fused_supported(g, C) || (!g->edge_default && !V3)) return BGNN_ERR_UNSUPPORTED;
   const int HC = L.heads * C, NC = Ln.heads * C;
   if (Ln.d_in != HC) return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
-  fill_common(a, g, L, xw, asd, L.concat ? 1 : 0);
+  fill_common(a, g, L, V3, xw, asd, L.concat ? 1 : 0);
   int split = ctx->opts.matrix_path;                                   // 0 exact, 1 bf16x3, 2 fp16x3 (opt-in), 3 bf16 storage
   if (split == 2 && !Ln.Wsp16) split = 1;                              // a weight beyond float16's range: bf16 split instead
   a.Wt = split == 3 ? Ln.Wbf : split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wfp;
@@ -1864,7 +1865,7 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   if (split == 3 && !main_shape) return BGNN_ERR_UNSUPPORTED;          // bf16 storage: the default model's shapes only
   if ((split == 1 || split == 2) && (!main_shape || g->K == 16)) { split = 0; a.Wt = Ln.Wfp; }   // other shapes: exact-f32 instances only
   // big uniform batches on the exact path: the persistent form of the 256 -> 256 instance (bit-identical results)
-  if (split == 0 && HC == 256 && NC == 256 && C == 64 && (g->K == 8 || g->K == 4) && g->uni_h && !g->d_atlas && ctx->opts.fused_persistent &&
+  if (split == 0 && HC == 256 && NC == 256 && C == 64 && (g->K == 8 || g->K == 4) && g->uni_h && !g->d_atlas && ctx->opts.fused_persistent && g->edge_default &&
       a.tb.n_blocks >= 8 * ctx->num_cus)
   {
     BGNN_TRY(ensure_edge_attrs(g));                 // (the persistent form DMAs the full [K][3] blocks into LDS)
@@ -1884,14 +1885,14 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
 }
 
 // aggregate of the LAST layer (HC = C, one head) fused with the heads (+ grids)
-int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, int ED,
+int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, const float *V3,
                              const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid) {
-  if (!fused_supported(g, C, ED) || L.heads != 1 || m->desc.num_classes > 4 || m->head_hidden_total != 96 || !m->hd_tab ||
+  if (!fused_supported(g, C) || (!g->edge_default && !V3) || L.heads != 1 || m->desc.num_classes > 4 || m->head_hidden_total != 96 || !m->hd_tab ||
       (m->desc.predict_correction ? 3 : 2) * (C / 2) > 96 || o->hidden)
     return BGNN_ERR_UNSUPPORTED;
   FusedArgs a{};
-  fill_common(a, g, L, xw, asd, L.concat ? 1 : 0);
+  fill_common(a, g, L, V3, xw, asd, L.concat ? 1 : 0);
   int split = ctx->opts.matrix_path;
   if (split == 2 && !m->hd_W0sp16) split = 1;
   if ((split == 1 || split == 2) && g->K == 16) split = 0;

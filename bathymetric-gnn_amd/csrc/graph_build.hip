@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
     // ---- in-edges: slot b <- source cell (r - dr[b], c - dc[b])  (:196-223, :329-376) ----
     const float dz_tgt = a.depth[idx];
     if (a.node_depth) a.node_depth[id] = dz_tgt;
-    auto edge_slot = [&](int b, int &sid, float (&ev)[4]) {
+    auto edge_slot = [&](int b, int &sid, float (&ev)[4], float &slope_f32) {     // slope_f32: the slot's slope whatever the list holds
       const int sr = r - st.dr[b], sc = c - st.dc[b];
       sid = -1;
       int64_t sidx = 0;
@@ -572,11 +572,13 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
         if (sid < 0) sid = -1;
       }
       ev[0] = ev[1] = ev[2] = ev[3] = 0.0f;
+      slope_f32 = 0.0f;
       if (sid >= 0) {
         const double dist = s_dist[b];
         const float dz = dz_tgt - a.depth[sidx];          // float32 subtract
         double slope = 0.0;
         if (dist > 0.0) slope = atan((double)dz / dist) * 57.29577951308232;   // np.degrees
+        slope_f32 = (slope != slope) ? 0.0f : (float)slope;
         for (int f = 0; f < a.ED; ++f) {
           const int eid = a.edge_ids[f];
           float v = 0.0f;
@@ -598,11 +600,11 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
 #pragma unroll 1
       for (int half = 0; half < KK / 8; ++half) {
         int sids[8];
-        float evs[24];
+        float evs[24], sls[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
           float ev[4];
-          edge_slot(half * 8 + b, sids[b], ev);
+          edge_slot(half * 8 + b, sids[b], ev, sls[b]);
           evs[3 * b] = ev[0]; evs[3 * b + 1] = ev[1]; evs[3 * b + 2] = ev[2];
         }
         if (a.nbr) {
@@ -612,9 +614,9 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
         if (a.eattr) {
 #pragma unroll
           for (int q = 0; q < 6; ++q) ep[half * 6 + q] = make_float4(evs[4 * q], evs[4 * q + 1], evs[4 * q + 2], evs[4 * q + 3]);
-        } else {                                         // compact: the slopes (attribute 2 of the default list) only
+        } else {                                         // compact: the slopes only
 #pragma unroll
-          for (int q = 0; q < 2; ++q) sp[half * 2 + q] = make_float4(evs[12 * q + 2], evs[12 * q + 5], evs[12 * q + 8], evs[12 * q + 11]);
+          for (int q = 0; q < 2; ++q) sp[half * 2 + q] = make_float4(sls[4 * q], sls[4 * q + 1], sls[4 * q + 2], sls[4 * q + 3]);
         }
       }
     };
@@ -623,11 +625,11 @@ __global__ __launch_bounds__(256) void features_kernel(FeatureArgs a, Stencil st
     } else {
       for (int b = 0; b < st.K; ++b) {
         int sid;
-        float ev[4];
-        edge_slot(b, sid, ev);
+        float ev[4], sl;
+        edge_slot(b, sid, ev, sl);
         if (a.nbr) a.nbr[(int64_t)id * st.K + b] = sid;
         if (a.eattr) { for (int f = 0; f < a.ED; ++f) a.eattr[((int64_t)id * st.K + b) * a.ED + f] = ev[f]; }
-        else a.slope[(int64_t)id * st.K + b] = ev[2];
+        else a.slope[(int64_t)id * st.K + b] = sl;
       }
     }
   }
@@ -1002,7 +1004,8 @@ __global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *til
 // full edge-attribute table of a compact graph, on demand: attrs[node][b] = (length of slot b, nan_to_num(depth[node] - depth[source]),
 // slope[node][b]) where the source exists, zeros elsewhere -- the values the feature kernels write in their non-compact mode
 __global__ __launch_bounds__(256) void expand_edge_attrs_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *node_id, int64_t cells,
-                                                                Stencil st, const float *slope, const float *node_depth, float *eattr) {
+                                                                Stencil st, const float *slope, const float *node_depth, float *eattr,
+                                                                int ED, int e0id, int e1id, int e2id, int e3id) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= cells) return;
   const int id = node_id[i];
@@ -1023,8 +1026,11 @@ __global__ __launch_bounds__(256) void expand_edge_attrs_kernel(const BgnnTileMe
       e1 = nan_to_num_f32(dz_tgt - node_depth[sid]);
       e2 = slope[(int64_t)id * st.K + b];
     }
-    float *e = eattr + ((int64_t)id * st.K + b) * 3;
-    e[0] = e0; e[1] = e1; e[2] = e2;
+    // the graph's edge feature list selects / orders the columns (graph_construction.py:355-371; unknown names are skipped upstream,
+    // BGNN_EF_ZERO keeps a column of zeros)
+    const int ids[4] = {e0id, e1id, e2id, e3id};
+    float *e = eattr + ((int64_t)id * st.K + b) * ED;
+    for (int f = 0; f < ED; ++f) e[f] = ids[f] == BGNN_EF_DISTANCE ? e0 : ids[f] == BGNN_EF_DEPTH_DIFFERENCE ? e1 : ids[f] == BGNN_EF_SLOPE ? e2 : 0.0f;
   }
 }
 
@@ -1065,12 +1071,13 @@ int ensure_edge_attrs(const bgnn_graph *g) {
   bgnn_ctx *ctx = g->ctx;
   if (!g->d_eattr) {
     void *p = nullptr;
-    BGNN_TRY(ctx->pool.alloc((size_t)g->total_cells * g->K * 3 * sizeof(float), &p));
+    BGNN_TRY(ctx->pool.alloc((size_t)g->total_cells * g->K * g->ED * sizeof(float), &p));
     g->d_eattr = (float *)p;
   }
   const Stencil st = make_stencil(g->K);
   hipLaunchKernelGGL(expand_edge_attrs_kernel, dim3((unsigned)((g->total_cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles,
-                     g->n_tiles, g->d_node_id, (int64_t)g->total_cells, st, g->d_slope, g->d_node_depth, g->d_eattr);
+                     g->n_tiles, g->d_node_id, (int64_t)g->total_cells, st, g->d_slope, g->d_node_depth, g->d_eattr, g->ED,
+                     g->edge_ids[0], g->edge_ids[1], g->edge_ids[2], g->edge_ids[3]);
   BGNN_HIP_CHECK(hipGetLastError());
   g->eattr_valid = true;
   return BGNN_OK;
@@ -1145,12 +1152,13 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     // tested against; 2: the tiled form for every shape, for those tests.)
     const bool tiled = ctx->opts.features_tiled == 2 || (ctx->opts.features_tiled == 1 && g->uni_w >= 64 && g->uni_h >= 8);
     const bool compact = g->compact_edges && !a.nbr;
-    if (st.K == 8 && a.ED == 3 && tiled && compact) hipLaunchKernelGGL((features_tiled_kernel<8, true>), dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
-    else if (st.K == 16 && a.ED == 3 && tiled && compact) hipLaunchKernelGGL((features_tiled_kernel<16, true>), dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    // (compact: only the slopes are written, whatever the edge feature list holds)
+    if (st.K == 8 && tiled && compact) hipLaunchKernelGGL((features_tiled_kernel<8, true>), dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 16 && tiled && compact) hipLaunchKernelGGL((features_tiled_kernel<16, true>), dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 8 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else if (st.K == 16 && a.ED == 3 && tiled) hipLaunchKernelGGL(features_tiled_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
-    else if (st.K == 8 && a.ED == 3) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
-    else if (st.K == 16 && a.ED == 3) hipLaunchKernelGGL(features_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 8 && (a.ED == 3 || compact)) hipLaunchKernelGGL(features_kernel<8>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
+    else if (st.K == 16 && (a.ED == 3 || compact)) hipLaunchKernelGGL(features_kernel<16>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
     else hipLaunchKernelGGL(features_kernel<0>, dim3(g->n_items), dim3(256), 0, ctx->stream, a, st);
   }
   BGNN_HIP_CHECK(hipGetLastError());

@@ -59,7 +59,8 @@ class RefinementGrid:
 
     @property
     def num_valid(self) -> int:
-        return int(np.sum(self.valid_mask))
+        nv = self.__dict__.get("_num_valid")             # set by the handler's iterator, which counts all grids in one pass
+        return int(np.sum(self.valid_mask)) if nv is None else nv
 
 
 def refinement_table(varres_metadata: np.ndarray):
@@ -186,26 +187,37 @@ class VRBagHandler:
 
     # ---- iteration (reference :243-298) -------------------------------------------------------------------
     def iterate_refinements(self, min_valid_ratio: float = 0.0) -> Generator[RefinementGrid, None, None]:
+        """Same grids, same order (row-major over the base grid, cells with a zero dimension skipped), same ``min_valid_ratio``
+        test as the reference's loop (:243-298).  What a grid needs is prepared for ALL grids in a few vectorised passes -- the
+        depth / uncertainty planes copied out of the interleaved records once, the valid-cell counts by one cumulative sum, the
+        metadata columns as Python lists -- so that per grid only the ``RefinementGrid`` itself is made: ``depth`` /
+        ``uncertainty`` are 2-D views of those private planes (not of the handler's records: writing into them does not touch the
+        BAG), and ``num_valid`` is known without another pass."""
+        tab = self.refinement_table()
+        n_grids = len(tab["cells"])
+        if n_grids == 0:
+            return
         ref = self.varres_refinements[0, :]
-        md = self.varres_metadata
-        for row in range(self.base_shape[0]):
-            for col in range(self.base_shape[1]):
-                meta = md[row, col]
-                dims_x, dims_y = int(meta["dimensions_x"]), int(meta["dimensions_y"])
-                if dims_x == 0 or dims_y == 0:
-                    continue
-                start = int(meta["index"])
-                sl = ref[start:start + dims_x * dims_y]
-                grid = RefinementGrid(
-                    base_row=row, base_col=col,
-                    depth=sl["depth"].reshape(dims_y, dims_x).copy(),
-                    uncertainty=sl["depth_uncrt"].reshape(dims_y, dims_x).copy(),
-                    resolution=(float(meta["resolution_x"]), float(meta["resolution_y"])),
-                    dimensions=(dims_y, dims_x),
-                    sw_corner=(float(meta["sw_corner_x"]), float(meta["sw_corner_y"])),
-                    start_index=start)
-                if grid.num_valid / grid.depth.size >= min_valid_ratio:
-                    yield grid
+        depth_all = np.ascontiguousarray(ref["depth"], dtype=np.float32)        # (a field view is strided: these are copies)
+        unc_all = np.ascontiguousarray(ref["depth_uncrt"], dtype=np.float32)
+        csum = np.zeros(depth_all.shape[0] + 1, np.int64)
+        np.cumsum((depth_all != np.float32(1.0e6)) & np.isfinite(depth_all), out=csum[1:])       # RefinementGrid.valid_mask
+        start = tab["index"]; cells = tab["cells"]
+        nvalid = (csum[start + cells] - csum[start]).tolist()
+        rows, cols = tab["base_row"].tolist(), tab["base_col"].tolist()
+        starts, ncell = start.tolist(), cells.tolist()
+        dys, dxs = tab["dims_y"].tolist(), tab["dims_x"].tolist()
+        rxs, rys = [float(v) for v in tab["res_x"]], [float(v) for v in tab["res_y"]]
+        sxs, sys_ = [float(v) for v in tab["sw_x"]], [float(v) for v in tab["sw_y"]]
+        for i in range(n_grids):
+            nv, n = nvalid[i], ncell[i]
+            if nv / n >= min_valid_ratio:
+                s0, dy, dx = starts[i], dys[i], dxs[i]
+                grid = RefinementGrid(base_row=rows[i], base_col=cols[i], depth=depth_all[s0:s0 + n].reshape(dy, dx),
+                                      uncertainty=unc_all[s0:s0 + n].reshape(dy, dx), resolution=(rxs[i], rys[i]),
+                                      dimensions=(dy, dx), sw_corner=(sxs[i], sys_[i]), start_index=s0)
+                grid.__dict__["_num_valid"] = nv
+                yield grid
 
     def copy_and_open_for_writing(self, output_path=None) -> "VRBagWriter":
         """File-backed: copy the BAG and open the copy (reference :300-316).  Array-backed (``from_arrays``):
@@ -275,6 +287,32 @@ class VRBagWriter:
             cur["depth_uncrt"] = corrected_uncertainty.flatten()
         self._refinements[0, s:s + n] = cur
         self._corrections_applied += int(np.sum((corrected_depth != grid.depth) & grid.valid_mask))
+
+    def update_refinements_bulk(self, grids, depth_flat: np.ndarray, uncertainty_flat: Optional[np.ndarray], changed: int = 0):
+        """``update_refinement_batch`` for many grids at once: ``depth_flat`` / ``uncertainty_flat`` hold the grids' corrected
+        values back to back (row-major each), ``changed`` the number of valid cells whose depth changed (what the per-grid calls
+        would have added to the corrections counter).  One scatter into the record array instead of a read-modify-write per grid;
+        array-backed writers only (a file-backed one takes the per-grid path)."""
+        if self._file is not None:                                   # pragma: no cover - needs h5py
+            off = 0
+            for g in grids:
+                n = g.dimensions[0] * g.dimensions[1]
+                self.update_refinement_batch(g, depth_flat[off:off + n].reshape(g.dimensions),
+                                             None if uncertainty_flat is None else uncertainty_flat[off:off + n].reshape(g.dimensions))
+                off += n
+            return
+        starts = np.fromiter((g.start_index for g in grids), np.int64, len(grids))
+        cells = np.fromiter((g.dimensions[0] * g.dimensions[1] for g in grids), np.int64, len(grids))
+        total = int(cells.sum())
+        if depth_flat.shape[0] != total:
+            raise ValueError(f"Shape mismatch: {depth_flat.shape[0]} corrected values for {total} cells")
+        offs = np.zeros(len(grids), np.int64); np.cumsum(cells[:-1], out=offs[1:])
+        idx = np.repeat(starts - offs, cells) + np.arange(total, dtype=np.int64)
+        rec = self._refinements[0]
+        rec["depth"][idx] = depth_flat
+        if uncertainty_flat is not None:
+            rec["depth_uncrt"][idx] = uncertainty_flat
+        self._corrections_applied += int(changed)
 
     def write_records(self, start: int, records: np.ndarray, corrections_applied: int = 0):
         """Bulk write-back used by the device path: ``records`` (structured or float32 [n, 2]) replace

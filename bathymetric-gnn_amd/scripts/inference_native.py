@@ -24,6 +24,70 @@ logger = logging.getLogger(__name__)
 Result = Tuple[np.ndarray, np.ndarray, np.ndarray]
 
 
+class _BatchSlot:
+    """Staging of ONE refinement-grid batch: a pinned host slab of {depth, depth_uncrt} records the grids are copied into as they are
+    queued (``add_to_batch``), the device buffers the batch is unpacked / classified in, and a pinned result buffer.  A slot is
+    taken when the first grid of a batch is queued and returns to the processor's pool when the batch has been collected."""
+
+    def __init__(self, dev, cells: int = 1 << 17):
+        self.dev = dev
+        self.cap = 0
+        self.copy = torch.cuda.Stream(dev)               # H2D of the records, D2H of the results: beside the engine's stream
+        self.up, self.down = torch.cuda.Event(), torch.cuda.Event()
+        self.mask_h = None                               # pinned uint8 [cap]: only for batches that mix nodata values
+        self._grow(cells)
+        self.reset()
+
+    def _grow(self, cells: int):
+        cap = max(int(cells), 2 * self.cap)
+        rec_h = torch.empty((cap, 2), dtype=torch.float32, pin_memory=True)
+        if self.cap:
+            rec_h[:self.n] = self.rec_h[:self.n]
+            if self.mask_h is not None:
+                m = torch.empty(cap, dtype=torch.uint8, pin_memory=True); m[:self.n] = self.mask_h[:self.n]; self.mask_h = m
+        self.rec_h, self.rec_np = rec_h, rec_h.numpy()
+        self.out_h = torch.empty((3, cap), dtype=torch.float32, pin_memory=True)
+        mk = lambda dt, shape: torch.empty(shape, dtype=dt, device=self.dev)
+        self.rec_t, self.depth_t, self.unc_t = mk(torch.float32, (cap, 2)), mk(torch.float32, cap), mk(torch.float32, cap)
+        self.mask_t, self.out_t = mk(torch.uint8, cap), mk(torch.float32, (3, cap))
+        self.cap = cap
+
+    def reset(self):
+        self.n = 0                                       # cells staged
+        self.hw, self.res = [], []                       # per grid: (h, w), (rx, ry)
+        self.has_unc = None
+        self.nodata = None
+        self.host_masks = False                          # True: masks were computed on the host (mixed nodata values)
+        self.engine = None
+
+    def stage(self, depth: np.ndarray, unc: Optional[np.ndarray], resolution, nodata: float, host_mask: Optional[np.ndarray]):
+        h, w = depth.shape
+        n = h * w
+        if self.n + n > self.cap:
+            self._grow(self.n + n)
+        if self.has_unc is None:
+            self.has_unc, self.nodata = unc is not None, float(nodata)
+        elif self.has_unc != (unc is not None):
+            raise ValueError("either every grid of a batch has an uncertainty layer or none has")
+        if float(nodata) != self.nodata and not self.host_masks:
+            # a grid with ANOTHER nodata value joins the batch: the device-side mask (one nodata per batch) no longer covers it --
+            # this batch's masks are made on the host from here on (the cells staged so far: one vectorised pass, their own nodata)
+            if self.mask_h is None or self.mask_h.numel() < self.cap:
+                self.mask_h = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
+            d0 = self.rec_np[:self.n, 0]
+            self.mask_h.numpy()[:self.n] = (d0 != np.float32(self.nodata)) & np.isfinite(d0)
+            self.host_masks = True
+        rec = self.rec_np[self.n:self.n + n]
+        np.copyto(rec[:, 0].reshape(h, w), depth, casting="same_kind")
+        if unc is not None:
+            np.copyto(rec[:, 1].reshape(h, w), unc, casting="same_kind")
+        if self.host_masks:
+            m = host_mask if host_mask is not None else ((depth != nodata) & np.isfinite(depth))
+            self.mask_h.numpy()[self.n:self.n + n] = m.reshape(-1)
+        self.hw.append((h, w)); self.res.append((float(resolution[0]), float(resolution[1])))
+        self.n += n
+
+
 class NativeVRProcessor:
     CLASS_NOISE = 2
     BATCH_NODE_BUDGET = 50000        # nodes to accumulate before a flush (reference :128)
@@ -43,13 +107,17 @@ class NativeVRProcessor:
             self.expected_in_channels = None
         self._engine = TileBatchEngine(model, graph_builder, device if (device is not None and torch.device(device).type == "cuda") else None,
                                        auto_correct_threshold, 0.6, CORRECTION_NORM_FLOOR)
-        self._batch = []             # (depth, valid_mask, uncertainty|None, resolution)
+        # The queued grids live in a pinned host slab (a _BatchSlot), not in a Python list of arrays: add_to_batch copies a grid's
+        # depth / uncertainty straight into the slab (the {depth, depth_uncrt} record layout bgnn_vr_unpack reads), the valid mask
+        # (depth != nodata and finite) is made ON THE DEVICE by that kernel, and a flush is one H2D, the kernels and one D2H.
+        self._fill: Optional[_BatchSlot] = None       # the batch being queued
+        self._free_slots: List[_BatchSlot] = []
         self._batch_node_count = 0
         # Two batches in flight (submit_batch / collect_batch): a 50 000-node batch is ONE round of workgroups per kernel, so its
         # twelve launches are a chain of latencies that leaves most of the GPU idle; the next batch runs on a second library
         # context (own HIP stream, own arenas) beside it.  flush_batch() stays the reference's synchronous call.
         self._engines = [self._engine]
-        self._inflight = []          # tickets in submission order: {"engine", "hw", "out"}
+        self._inflight: List[_BatchSlot] = []         # submitted batches, oldest first
         self._next_engine = 0
 
     # ---- helpers ---------------------------------------------------------------------------
@@ -71,6 +139,17 @@ class NativeVRProcessor:
                                  [it[2] for it in items] if has_unc else None, [it[3] for it in items])
         return [(r["classification"], r["confidence"], r["correction"]) for r in res]
 
+    def _uses_uncertainty(self, uncertainty) -> bool:
+        """Does a queued grid's uncertainty layer reach the model?  (:165-167: dropped for a 7-channel model; and only a model
+        whose width is the builder's column count WITH the uncertainty column can take it.)"""
+        if uncertainty is None:
+            return False
+        t = self.__dict__.get("_takes_unc")
+        if t is None:
+            t = self.__dict__["_takes_unc"] = (self.expected_in_channels != 7 and
+                                               self.model.in_channels == self.graph_builder.n_node_columns(True))
+        return t
+
     # ---- reference API ---------------------------------------------------------------------
     def process_grid(self, depth: np.ndarray, uncertainty: Optional[np.ndarray], resolution: tuple,
                      nodata: float = 1.0e6) -> Result:
@@ -80,14 +159,32 @@ class NativeVRProcessor:
             return self._empty(depth)
         return self._run([item])[0]
 
-    def add_to_batch(self, depth, uncertainty, resolution, nodata=1.0e6):
-        """Queue a grid (:249-269).  Returns None when queued, or the all-zero result tuple
-        immediately for a grid with no valid cell."""
-        item = self._prepare(depth, uncertainty, resolution, nodata)
-        if item is None:
+    def add_to_batch(self, depth, uncertainty, resolution, nodata=1.0e6, valid_count: Optional[int] = None):
+        """Queue a grid (:249-269).  Returns None when queued, or the all-zero result tuple immediately for a grid with no valid
+        cell.  The grid is copied into the batch's pinned staging slab here; nothing of it is kept by reference.
+
+        ``valid_count`` (optional, not in the reference's signature): the number of valid cells, when the caller already knows it
+        (``RefinementGrid.num_valid``) -- the per-grid mask / count pass over the array is then skipped, the mask itself being
+        made on the device at flush time."""
+        depth = np.asarray(depth)
+        if depth.dtype != np.float32:
+            depth = depth.astype(np.float32)
+        mask = None
+        if valid_count is None:
+            mask = (depth != nodata) & np.isfinite(depth)            # :160
+            valid_count = int(np.count_nonzero(mask))
+        if valid_count == 0:
             return self._empty(depth)
-        self._batch.append(item)
-        self._batch_node_count += int(np.count_nonzero(item[1]))
+        if self._fill is None:
+            self._fill = self._free_slots.pop() if self._free_slots else _BatchSlot(self._engine.ctx.device)
+            self._fill.reset()
+        unc = uncertainty if self._uses_uncertainty(uncertainty) else None
+        if unc is not None:
+            unc = np.asarray(unc)
+            if unc.shape != depth.shape:
+                raise ValueError(f"uncertainty shape {unc.shape} != depth shape {depth.shape}")
+        self._fill.stage(depth, unc, resolution, nodata, mask)
+        self._batch_node_count += int(valid_count)
         return None
 
     @property
@@ -96,16 +193,16 @@ class NativeVRProcessor:
 
     @property
     def batch_pending(self) -> bool:
-        return len(self._batch) > 0
+        return self._fill is not None and self._fill.n > 0
 
     def flush_batch(self) -> List[Result]:
         """Classify every queued grid in one fused pass (:281-342); results in insertion order.  Synchronous, like the
         reference's (batches still in flight from ``submit_batch`` are not disturbed: this one queues behind the first
         context's work and their results stay available to ``collect_batch``)."""
-        if not self._batch:
+        if not self.batch_pending:
             return []
-        items, self._batch, self._batch_node_count = self._batch, [], 0
-        return self._run(items)
+        slot = self._launch(self._engine)
+        return self._results_of(slot, *self._finish(slot))
 
     # ---- two batches in flight (MI355X-first extension of the batching API; run_refinements uses it) --------------------------
     MAX_IN_FLIGHT = 2
@@ -122,46 +219,96 @@ class NativeVRProcessor:
                                                  self._engine.review_threshold, self._engine.norm_floor, ctx=ctx))
         return self._engines[i]
 
+    def _launch(self, eng: TileBatchEngine) -> _BatchSlot:
+        """Everything of the queued batch that runs on the GPU, asynchronously: H2D of the record slab (copy stream), unpack +
+        valid mask (``bgnn_vr_unpack``), the fused classification (``bgnn_infer_tiles``), D2H of the three result planes into the
+        slot's pinned buffer (copy stream).  The caller's torch stream is not involved: nothing it does later waits for this."""
+        import ctypes as C
+        from .. import runtime as rt
+        slot, self._fill, self._batch_node_count = self._fill, None, 0
+        n, ctx = slot.n, eng.ctx
+        slot.engine = eng
+        slot.hw_np = np.array(slot.hw, np.int32).reshape(-1, 2)
+        slot.res_np = np.array(slot.res, np.float64).reshape(-1, 2)
+        with torch.cuda.stream(slot.copy):
+            slot.copy.wait_stream(ctx.stream)            # (the device buffers' previous batch is long collected; cheap and explicit)
+            slot.rec_t[:n].copy_(slot.rec_h[:n], non_blocking=True)
+            if slot.host_masks:
+                slot.mask_t[:n].copy_(slot.mask_h[:n], non_blocking=True)
+            slot.up.record(slot.copy)
+        ctx.stream.wait_event(slot.up)
+        unc_t = slot.unc_t[:n] if slot.has_unc else None
+        # (host masks -- a batch that mixes nodata values: the kernel's own mask goes to a scratch plane and is not used)
+        mask_out = slot.mask_t[:n]
+        if slot.host_masks:
+            if getattr(slot, "scratch_t", None) is None or slot.scratch_t.numel() < n:
+                slot.scratch_t = torch.empty(slot.cap, dtype=torch.uint8, device=slot.dev)
+            mask_out = slot.scratch_t[:n]
+        rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(slot.rec_t), n, C.c_float(slot.nodata), 0, None, C.c_double(0.0),
+                                        rt.ptr(slot.depth_t), rt.ptr(unc_t), rt.ptr(mask_out), None, None))
+        with torch.cuda.stream(ctx.stream):              # (ctx.begin() inside orders the engine behind ITS OWN stream: a no-op wait)
+            eng.infer_device(slot.hw_np, slot.res_np, slot.depth_t[:n], slot.mask_t[:n], unc_t,
+                             out=(slot.out_t[0, :n], slot.out_t[1, :n], slot.out_t[2, :n]), defer_end=True)
+        with torch.cuda.stream(slot.copy):
+            slot.copy.wait_stream(ctx.stream)
+            # (three CONTIGUOUS row copies = three plain hipMemcpyAsync.  One strided [3, n] copy_ goes through a temporary and a
+            #  CPU-side at::parallel_for: it is synchronous, and its OpenMP team -- 128 threads on the GPU box, spinning after the
+            #  region -- eats the container's CPU quota: the whole process then stalled ~90 ms at a time, anywhere)
+            for c in range(3):
+                slot.out_h[c, :n].copy_(slot.out_t[c, :n], non_blocking=True)
+            slot.down.record(slot.copy)
+        return slot
+
+    def _finish(self, slot: _BatchSlot):
+        """Wait for a launched batch; returns (flat results [3, cells] -- a FRESH array, one copy per batch --, hw) and puts the slot
+        back into the pool."""
+        slot.down.synchronize()
+        flat = np.array(slot.out_h.numpy()[:, :slot.n])
+        hw = slot.hw
+        slot.reset()
+        self._free_slots.append(slot)
+        return flat, hw
+
+    @staticmethod
+    def _results_of(slot, flat, hw) -> List[Result]:
+        """Per-grid (classification, confidence, correction): views of the batch's own result array (no per-grid copies)."""
+        results, off = [], 0
+        c0, c1, c2 = flat[0], flat[1], flat[2]
+        for h, w in hw:
+            e = off + h * w
+            results.append((c0[off:e].reshape(h, w), c1[off:e].reshape(h, w), c2[off:e].reshape(h, w)))
+            off = e
+        return results
+
     def submit_batch(self) -> Optional[int]:
         """Start classifying the queued grids WITHOUT waiting for the result: the batch is uploaded and its kernels are queued on
         one of two library contexts, alternately, so that it runs beside the batch submitted before it.  Returns the number of
         batches now in flight (None if nothing was queued).  Results come back, in submission order, from ``collect_batch``.
         At most ``MAX_IN_FLIGHT`` batches may be outstanding: collect the oldest first."""
-        if not self._batch:
+        if not self.batch_pending:
             return None
         if len(self._inflight) >= self.MAX_IN_FLIGHT:
             raise RuntimeError(f"{self.MAX_IN_FLIGHT} batches are already in flight: collect_batch() the oldest first")
-        items, self._batch, self._batch_node_count = self._batch, [], 0
-        eng = self._engine_for_next()
-        has_unc = any(it[2] is not None for it in items)
-        use_unc = [it[2] for it in items] if (has_unc and self.model.in_channels == self.graph_builder.n_node_columns(True)) else None
-        hw, res, d, m, u = self.graph_builder.upload_tiles([it[0] for it in items], [it[1] for it in items], use_unc, [it[3] for it in items])
-        out = eng.infer_device(hw, res, d, m, u, defer_end=True)     # asynchronous: nothing waits for this batch yet
-        self._inflight.append({"engine": eng, "hw": hw, "out": out, "keep": (d, m, u)})
+        self._inflight.append(self._launch(self._engine_for_next()))
         return len(self._inflight)
 
     @property
     def batches_in_flight(self) -> int:
         return len(self._inflight)
 
-    def _collect(self, index: int) -> List[Result]:
-        t = self._inflight.pop(index)
-        t["engine"].ctx.end()                        # the caller's stream now waits for that batch ...
-        out = t["out"].cpu().numpy()                 # ... and so does this copy
-        results, off = [], 0
-        for i in range(t["hw"].shape[0]):
-            h, w = int(t["hw"][i, 0]), int(t["hw"][i, 1])
-            n = h * w
-            results.append((out[0, off:off + n].reshape(h, w).copy(), out[1, off:off + n].reshape(h, w).copy(),
-                            out[2, off:off + n].reshape(h, w).copy()))
-            off += n
-        return results
+    def collect_batch_flat(self):
+        """Results of the OLDEST batch in flight as ONE array: (flat [3, cells] float32 -- classification, confidence, correction
+        of the batch's grids back to back, row-major --, [(h, w) per grid]); (None, []) when nothing is in flight."""
+        if not self._inflight:
+            return None, []
+        return self._finish(self._inflight.pop(0))
 
     def collect_batch(self) -> List[Result]:
         """Results of the OLDEST batch in flight (blocks until it is done); same per-grid tuples as ``flush_batch``."""
         if not self._inflight:
             return []
-        return self._collect(0)
+        slot = self._inflight.pop(0)
+        return self._results_of(slot, *self._finish(slot))
 
     # ---- whole-BAG device path (MI355X-first replacement of the main loop, :445-538) ---------------------
     def process_refinements(self, handler, writer=None, min_valid_ratio: float = 0.0,
@@ -276,8 +423,13 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
 
     ``pipelined`` (default): a full batch is SUBMITTED (``submit_batch``) and the loop goes on queueing the next one; the
     results of the batch before it are collected -- and applied, in the same grid order -- while the new one runs on the
-    processor's second library context.  Same results and statistics as the synchronous loop (``pipelined=False``: one
-    ``flush_batch`` per full batch, exactly the reference's control flow), grid for grid; the GPU just never waits for the host."""
+    processor's second library context.  The write-back arithmetic of a collected batch then runs ONCE over the batch's cells
+    (the same float32 operations as ``apply_one``, element for element, on the concatenated grids) and the corrected values go
+    back through the writer's bulk entry (``update_refinements_bulk``) where it has one: per grid the host only iterates and
+    queues.  Same records, same sink calls in the same order and the same counts as the synchronous loop
+    (``pipelined=False``: one ``flush_batch`` per full batch, exactly the reference's control flow, grid for grid);
+    ``total_confidence`` is summed per batch in float64 instead of per grid in numpy's float32 pairwise order (it feeds the
+    logged mean only): equal to ~1e-7 relative, not bit for bit."""
     thr = processor.auto_correct_threshold if auto_correct_threshold is None else auto_correct_threshold
     stats = {"grids_processed": 0, "cells_processed": 0, "cells_classified_noise": 0, "cells_corrected": 0,
              "total_confidence": 0.0}
@@ -308,6 +460,47 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
             else:
                 apply_one(grid, *batch[k]); k += 1
 
+    bulk = getattr(writer, "update_refinements_bulk", None)
+
+    def apply_flat(plist, flat, hw):
+        """apply_one over a whole collected batch at once: ``flat`` [3, cells] holds the batch's grids back to back."""
+        gl = [g for g, imm in plist if imm is None]
+        if gl:
+            assert len(gl) == len(hw)
+            depth = np.concatenate([g.depth.reshape(-1) for g in gl]) if len(gl) > 1 else gl[0].depth.reshape(-1).copy()
+            unc = np.concatenate([g.uncertainty.reshape(-1) for g in gl]) if len(gl) > 1 else gl[0].uncertainty.reshape(-1).copy()
+            cls, conf, corr = flat[0], flat[1], flat[2]
+            valid = (depth != 1.0e6) & np.isfinite(depth)              # RefinementGrid.valid_mask
+            noise = (cls == processor.CLASS_NOISE) & valid
+            applied = noise & (conf >= thr)
+            new_depth, new_unc = depth.copy(), unc.copy()
+            new_depth[applied] -= corr[applied]
+            new_unc[applied] *= 2.0 - conf[applied]
+            stats["cells_corrected"] += int(np.count_nonzero(applied))
+            stats["cells_processed"] += int(np.count_nonzero(valid))
+            stats["cells_classified_noise"] += int(np.count_nonzero(noise))
+            stats["total_confidence"] += float(np.sum(conf[valid], dtype=np.float64))
+            if bulk is not None:
+                bulk(gl, new_depth, new_unc, changed=int(np.count_nonzero((new_depth != depth) & valid)))
+        stats["grids_processed"] += len(plist)
+        if results_sink is None and bulk is not None:
+            return                                       # (grids without a valid cell: nothing changes, nothing to write)
+        k, off = 0, 0
+        for grid, immediate in plist:
+            if immediate is not None:
+                if results_sink is not None:
+                    results_sink(grid, *immediate)
+                if bulk is None:
+                    writer.update_refinement_batch(grid, grid.depth.copy(), grid.uncertainty.copy())
+                continue
+            h, w = hw[k]
+            e = off + h * w
+            if results_sink is not None:
+                results_sink(grid, flat[0, off:e].reshape(h, w), flat[1, off:e].reshape(h, w), flat[2, off:e].reshape(h, w))
+            if bulk is None:
+                writer.update_refinement_batch(grid, new_depth[off:e].reshape(h, w), new_unc[off:e].reshape(h, w))
+            k += 1; off = e
+
     def flush():
         if not pending:
             return
@@ -316,28 +509,41 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
 
     submitted = []                                      # pending lists of the batches in flight, oldest first
 
+    def collect_oldest():
+        plist = submitted.pop(0)
+        apply_flat(plist, *processor.collect_batch_flat())
+
     def submit():
         if not pending:
             return
         plist = list(pending); pending.clear()
         if processor.batch_pending:
             while processor.batches_in_flight >= processor.MAX_IN_FLIGHT:
-                apply_all(submitted.pop(0), processor.collect_batch())
+                collect_oldest()
             processor.submit_batch()
             submitted.append(plist)
             while len(submitted) > 1:                   # the batch before this one: collect and apply it while this one runs
-                apply_all(submitted.pop(0), processor.collect_batch())
+                collect_oldest()
         else:                                           # only grids without a valid cell: nothing to classify
             while submitted:
-                apply_all(submitted.pop(0), processor.collect_batch())
-            apply_all(plist, [])
+                collect_oldest()
+            apply_flat(plist, None, [])
 
-    for grid in handler.iterate_refinements(min_valid_ratio):
-        pending.append((grid, processor.add_to_batch(grid.depth, grid.uncertainty, grid.resolution, nodata=nodata)))
-        if processor.batch_ready:
-            submit() if pipelined else flush()
-    submit() if pipelined else flush()
-    while submitted:
-        apply_all(submitted.pop(0), processor.collect_batch())
+    if pipelined:
+        for grid in handler.iterate_refinements(min_valid_ratio):
+            # (the iterator already knows the valid-cell count: no second mask pass in add_to_batch)
+            pending.append((grid, processor.add_to_batch(grid.depth, grid.uncertainty, grid.resolution, nodata=nodata,
+                                                         valid_count=grid.num_valid if nodata == 1.0e6 else None)))
+            if processor.batch_ready:
+                submit()
+        submit()
+        while submitted:
+            collect_oldest()
+    else:
+        for grid in handler.iterate_refinements(min_valid_ratio):
+            pending.append((grid, processor.add_to_batch(grid.depth, grid.uncertainty, grid.resolution, nodata=nodata)))
+            if processor.batch_ready:
+                flush()
+        flush()
     stats["mean_confidence"] = stats["total_confidence"] / stats["cells_processed"] if stats["cells_processed"] > 0 else 0
     return stats

@@ -88,6 +88,25 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
             "fused_flops": fused_flops, "fused_bytes": fused_bytes, "front_flops": front_flops, "front_bytes": front_bytes}
 
 
+def plain_backbone_model(gnn_type, num_layers=4, hidden=64, in_ch=7, deg=8, classes=3):
+    """Compulsory HBM bytes per node and forward of the non-attention backbones (reference models/gnn.py:120-143; plain gather +
+    GEMM kernels, csrc/neighbor_reduce.hip + gemm_f32.hip): every kernel reads its inputs once and writes its outputs once, float32.
+    K = 64 GEMMs have 16 flop per byte -- below the 19.7 flop/B balance of the exact-f32 MFMA -- so both kernel classes are priced
+    by bytes.  ``agg``: the neighbour reductions (x row in, K stencil ids, out row; GCN + 4 B of deg^-1/2, GraphSAGE writes [mean | x]);
+    ``gemm``: every GEMM launch (extractor 2, backbone 1-2 per layer, the heads' first layers)."""
+    row = 4 * hidden
+    gemm = (32 + row) + (row + row) + (row + 4 * 3 * (hidden // 2))          # extractor layers, heads' first layers
+    agg = 0
+    for _ in range(num_layers):
+        if gnn_type == "GCN":
+            gemm += row + row; agg += row + 4 * deg + 4 + row
+        elif gnn_type == "GraphSAGE":
+            agg += row + 4 * deg + 2 * row; gemm += 2 * row + row
+        else:                                                                   # GIN
+            agg += row + 4 * deg + row; gemm += 2 * (row + row)
+    return {"agg_bytes": agg, "gemm_bytes": gemm}
+
+
 def cpu_baseline(n_runs, tile, sd, seed0, connectivity="8-connected"):
     """The CPU oracle (vectorised numpy graph build + fp32 torch forward issuing torch_geometric's op sequence + scatter)
     on ONE tile of the headline workload per run: one untimed warm-up run, then the MEDIAN of ``n_runs`` timed runs
@@ -153,7 +172,7 @@ def compact_line(line, budget=LINE_BUDGET):
     """The stdout line within `budget` bytes: optional keys are dropped (least important first) until it fits; the contract
     keys, roofline and cpu_baseline are never dropped."""
     out = dict(line)
-    for k in ("matrix_path", "path", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
+    for k in ("matrix_path", "path", "gnn_types", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
         if len(json.dumps(out)) <= budget:
             break
         out.pop(k, None)
@@ -283,14 +302,15 @@ class Bench:
         self.ctx = rt.get_context(dev)
         self.nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    def model(self, in_ch):
+    def model(self, in_ch, gnn_type="GAT"):
         from bathymetric_gnn_amd.models import BathymetricGNN
-        if in_ch not in self._models:
-            sd = self.syn.synthetic_state_dict(in_channels=in_ch, num_layers=self.layers, seed=1234)
-            m = BathymetricGNN(in_channels=in_ch, num_gnn_layers=self.layers, edge_dim=3, dropout=0.0)
+        key = (in_ch, gnn_type)
+        if key not in self._models:
+            sd = self.syn.synthetic_state_dict(in_channels=in_ch, num_layers=self.layers, seed=1234, gnn_type=gnn_type)
+            m = BathymetricGNN(in_channels=in_ch, num_gnn_layers=self.layers, gnn_type=gnn_type, edge_dim=3, dropout=0.0)
             m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-            self._models[in_ch] = (m.to(self.dev).eval(), sd)
-        return self._models[in_ch]
+            self._models[key] = (m.to(self.dev).eval(), sd)
+        return self._models[key]
 
     def barrier(self):
         if self.dist is not None:
@@ -298,10 +318,10 @@ class Bench:
         torch.cuda.synchronize(self.dev)
 
     # -- uniform tile batches: the headline (k = 8, f32) and configs[2] (k = 16, bf16 storage) ---------------------------
-    def tiles(self, B, S, variant, conn, matrix_path=None, unfused=False):
+    def tiles(self, B, S, variant, conn, matrix_path=None, unfused=False, gnn_type="GAT"):
         from bathymetric_gnn_amd.data import GraphBuilder
         from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
-        model, sd = self.model(7)
+        model, sd = self.model(7, gnn_type)
         gb = GraphBuilder(connectivity=conn, device=self.dev)
         eng = TileBatchEngine(model, gb, self.dev)
         ctx = eng.ctx
@@ -330,9 +350,9 @@ class Bench:
         return {"kind": "tiles", "step": step, "check": check, "nodes_per_step": nodes, "contexts": [ctx], "options": opts,
                 "deg": DEG[conn], "conn": conn, "bf16": bf16, "split": matrix_path if matrix_path in ("bf16x3", "fp16x3") else None,
                 "unfused": unfused, "B": B, "S": S, "eng": eng, "gb": gb, "host": (depth, mask), "dev_in": (d_t, m_t),
-                "events_in_timed_region": True, "scaling": "weak",
-                "name": (f"{B} tiles of {S}x{S} per GPU per step, {conn} (k={DEG[conn]}), {self.layers}-layer GAT "
-                         f"(hidden 64, heads 4), mask {variant}, inputs resident in HBM"
+                "events_in_timed_region": True, "scaling": "weak", "gnn_type": gnn_type,
+                "name": (f"{B} tiles of {S}x{S} per GPU per step, {conn} (k={DEG[conn]}), {self.layers}-layer {gnn_type} "
+                         f"(hidden 64{', heads 4' if gnn_type == 'GAT' else ''}), mask {variant}, inputs resident in HBM"
                          + (", layer activations stored as bf16 (bf16 MFMA, f32 softmax / aggregation / accumulation)" if bf16 else ""))}
 
     # -- configs[3]: ragged refinement grids, packed greedily in stream order until the node budget is reached -----------
@@ -539,7 +559,13 @@ class Bench:
 
         bf16, split = wl["bf16"], wl["split"]
         roofs = {}
-        if prof["fused"]["launches"]:
+        if wl.get("gnn_type", "GAT") != "GAT":
+            pm = plain_backbone_model(wl["gnn_type"], num_layers=self.layers, deg=wl["deg"])
+            roofs["aggregate_hbm"] = roof("neighbor_reduce_kernel", "aggregate", "hbm", pm["agg_bytes"],
+                                          f"{wl['gnn_type']}: neighbour reductions (x row + stencil ids in, reduced row out), priced by compulsory bytes")
+            roofs["gemm_hbm"] = roof("gemm_f32_kernel", "gemm", "hbm", pm["gemm_bytes"],
+                                     "every GEMM launch (K = 64 / 128: below the f32 MFMA's flop/B balance), priced by compulsory bytes")
+        elif prof["fused"]["launches"]:
             if bf16:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", am["fused_flops"],
                                            "bf16 MFMA, f32 accumulate: priced against the dense bf16 MFMA peak (the kernel is not matrix-bound)")
@@ -637,6 +663,9 @@ def main():
                          "grids packed by the reference's 50 000-node batch budget. survey: configs[4] -- one survey resident in HBM, "
                          "overlapping 512x512 tiles cut, classified and stitched on the device (row-band sharded under --gpus N)")
     ap.add_argument("--connectivity", default=None, choices=["4-connected", "8-connected", "16-dilated"])
+    ap.add_argument("--gnn-type", default="GAT", choices=["GAT", "GCN", "GraphSAGE", "GIN"],
+                    help="tiles workload: the backbone (reference models/gnn.py:120-143).  GAT is the hot path (fused kernels); the other "
+                         "three run on plain gather + GEMM kernels and are priced by their compulsory HBM bytes")
     ap.add_argument("--bf16", action="store_true", help="matrix_path = bf16 (bf16 activation storage + bf16 MFMA)")
     ap.add_argument("--vr-grids", type=int, default=4096)
     ap.add_argument("--vr-budget", type=int, default=50000)
@@ -681,7 +710,9 @@ def main():
     mp = "bf16" if (args.bf16 or args.workload == "c3") else "fp16x3" if args.split_f16 else "bf16x3" if args.split_bf16 else None
     if args.workload in ("tiles", "c3"):
         conn = args.connectivity or ("16-dilated" if args.workload == "c3" else "8-connected")
-        wl = bench.tiles(B, S, args.variant, conn, matrix_path=mp, unfused=args.unfused)
+        if args.gnn_type != "GAT" and (mp or args.unfused or args.workload == "c3"):
+            raise SystemExit("bench.py: --gnn-type other than GAT runs the plain exact-f32 kernels only")
+        wl = bench.tiles(B, S, args.variant, conn, matrix_path=mp, unfused=args.unfused, gnn_type=args.gnn_type)
     elif args.workload == "vr":
         wl = bench.vr(args.vr_grids, args.vr_budget, args.vr_streams)
     else:
@@ -692,7 +723,9 @@ def main():
     if rank == 0:
         rep = bench.report(wl, m)
         line = {
-            "metric": ("classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)" if wl["kind"] != "survey" else
+            "metric": ((f"classified tile-nodes/s (graph build + 4-layer {wl.get('gnn_type')} forward + scatter; plain gather + GEMM kernels)"
+                        if wl.get("gnn_type", "GAT") != "GAT" else
+                        "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)") if wl["kind"] != "survey" else
                        "classified tile-nodes/s (node evaluations of the survey's overlapping tiles: cut + graph build + GAT forward + stitch)"),
             "value": rep["value"], "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": wl["scaling"],
@@ -719,7 +752,10 @@ def main():
             line["rehearsal_note"] = (f"{world} ranks share ONE GPU and talk over gloo (host-staged halo rows): a functional rehearsal of "
                                       "the multi-rank code path, NOT a scaling measurement -- `value` earns no credit")
         extras = not args.no_extras and world == 1
-        default_headline = wl["kind"] == "tiles" and not wl["unfused"] and not wl["bf16"] and not wl["split"]
+        plain = wl.get("gnn_type", "GAT") != "GAT"
+        default_headline = wl["kind"] == "tiles" and not wl["unfused"] and not wl["bf16"] and not wl["split"] and not plain
+        if plain:
+            line["path"], line["matrix_path"] = "plain gather + GEMM", "exact f32"
 
         def guarded(key, fn):
             """One side measurement: its failure is recorded under its key, the headline still prints."""
@@ -734,7 +770,7 @@ def main():
                 return None
 
         # The CPU baseline first: it is part of the contract and needs nothing of the GPU.
-        if extras and not args.no_cpu_baseline and wl["kind"] == "tiles":
+        if extras and not args.no_cpu_baseline and wl["kind"] == "tiles" and not plain:
             def _cpu():
                 cb = cpu_baseline(args.cpu_runs, S, bench.model(7)[1], 100, wl["conn"])
                 detail["cpu_baseline"] = cb
@@ -742,7 +778,7 @@ def main():
                 line["cpu_baseline"]["sample"] = cb["sample_short"]
                 line["gpu_over_cpu"] = rep["value"] / cb["value"]
             guarded("cpu_baseline", _cpu)
-        if extras and wl["kind"] == "tiles" and not wl["unfused"]:
+        if extras and wl["kind"] == "tiles" and not wl["unfused"] and not plain:
             def _pcie_and_single():
                 eng, (depth, mask), (d_t, m_t) = wl["eng"], wl["host"], wl["dev_in"]
                 ctx = eng.ctx
@@ -861,6 +897,17 @@ def main():
                 line["config4"]["processor_api"] = {k: api[k]["value"] for k in ("synchronous", "pipelined")}
             guarded("config4", _c4)
             torch.cuda.empty_cache()
+
+            def _backbones():
+                detail["gnn_types"], line["gnn_types"] = {}, {}
+                for gt in ("GCN", "GraphSAGE", "GIN"):
+                    w = bench.tiles(B, S, args.variant, "8-connected", gnn_type=gt)
+                    r = side(w, steps=max(3, min(args.steps, 5)), warmup=1)
+                    detail["gnn_types"][gt] = r
+                    line["gnn_types"][gt] = {"value": r["value"], "frac": r["roofline"].get("frac"), "kernel": r["roofline"].get("kernel")}
+                    del w
+                    torch.cuda.empty_cache()
+            guarded("gnn_types", _backbones)
 
             def _c5():
                 sv = bench.survey(args.extras_survey_size)

@@ -135,6 +135,7 @@ def _representative_line():
             "pcie_inclusive": {"value": 291234567.1234567, "ms_per_step": 28.712345678901234},
             "single_tile": {"value": 171234567.1234567, "ms_per_tile": 0.39123456789012345},
             "config3": dict(brief), "config5": dict(brief),
+            "gnn_types": {k: {"value": 412345678.1234567, "frac": 0.3312345678901234, "kernel": "neighbor_reduce_kernel"} for k in ("GCN", "GraphSAGE", "GIN")},
             "config4": dict(brief, one_context=157123456.12345678, two_contexts=203123456.12345678,
                             processor_api={"synchronous": 15123456.123456789, "pipelined": 16123456.123456789}),
             "detail": "gpurun_out/bench_detail.json"}

@@ -29,7 +29,10 @@ def _line(args):
     ["--workload", "c3", "--tiles", "8", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
     ["--workload", "vr", "--vr-grids", "300", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
     ["--workload", "survey", "--survey-size", "2048", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
-], ids=["tiles", "c3", "vr", "survey"])
+    ["--gnn-type", "GCN", "--tiles", "8", "--steps", "2", "--warmup", "1", "--no-extras"],
+    ["--gnn-type", "GraphSAGE", "--tiles", "8", "--steps", "2", "--warmup", "1", "--no-extras"],
+    ["--gnn-type", "GIN", "--tiles", "8", "--steps", "2", "--warmup", "1", "--no-extras"],
+], ids=["tiles", "c3", "vr", "survey", "gcn", "sage", "gin"])
 def test_bench_line_contract(args, gpu_device):
     j = _line(args)
     for k in CONTRACT:
@@ -53,8 +56,11 @@ def test_default_command_shape_prints_one_small_line(gpu_device, tmp_path):
     assert len(out_lines) == 1 and out_lines[0].startswith("{"), r.stdout[-500:]
     assert len(out_lines[0]) < 4096
     j = json.loads(out_lines[0])
-    for k in CONTRACT + ["cpu_baseline", "config3", "config4", "config5"]:
+    for k in CONTRACT + ["cpu_baseline", "config3", "config4", "config5", "gnn_types"]:
         assert k in j, k
+    assert set(j["gnn_types"]) == {"GCN", "GraphSAGE", "GIN"}
+    for v in j["gnn_types"].values():
+        assert v["value"] > 0 and 0 < v["frac"] <= 1.0 and v["kernel"] in ("neighbor_reduce_kernel", "gemm_f32_kernel")
     for k in ("config3", "config4", "config5"):
         assert "error" not in j[k], j[k]
         assert j[k]["value"] > 0 and j[k]["ms_per_step"] > 0 and j[k]["dtype"] in ("f32", "bf16")
@@ -68,3 +74,22 @@ def test_default_command_shape_prints_one_small_line(gpu_device, tmp_path):
     full = json.load(open(side))
     assert "rooflines" in full and "kernels" in full and "one_context" in full["config4"] and "rooflines" in full["config3"]
     assert "bench detail: {" in r.stderr
+
+
+def test_multi_rank_code_path_rehearsal_two_ranks_share_the_gpu(gpu_device):
+    """The multi-rank path (`bench.py --gpus 2`: spawn_ranks, survey_rows_of_rank, the halo tile-row exchange, the band gather) on
+    REAL kernels, with both ranks on this box's one GPU and gloo as transport (`--share-gpu`: a clearly labelled rehearsal -- RCCL
+    cannot put two ranks on one device, and no 8-GPU node is available to builders).  No scaling claim: asserted are exit 0, one
+    JSON line that says `rehearsal`, halo bytes > 0, and a stitched survey bit-identical to the 1-rank run's (sha256 of [4, H, W])."""
+    base = ["--workload", "survey", "--survey-size", "2048", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline", "--checksum"]
+    one = _line(base)
+    two = _line(base + ["--gpus", "2", "--share-gpu"])
+    assert one["n_gpus"] == 1 and "rehearsal" not in one and one["survey"]["halo_bytes_all_ranks"] == 0
+    assert two["n_gpus"] == 2 and two["rehearsal"] is True and "NOT a scaling measurement" in two["rehearsal_note"]
+    assert two["scaling"] == "strong" and two["survey"]["halo_bytes_all_ranks"] > 0
+    assert two["survey"]["tiles_total"] == one["survey"]["tiles_total"] == 25
+    assert len(one["survey"]["stitched_sha256"]) == 64
+    assert two["survey"]["stitched_sha256"] == one["survey"]["stitched_sha256"]
+    # node evaluations of all ranks = the single rank's (every tile is classified exactly once)
+    assert two["config"]["nodes_per_step_per_gpu"] < one["config"]["nodes_per_step_per_gpu"]
+    assert abs(two["value"] * two["ms_per_step"] - one["value"] * one["ms_per_step"]) < 1e-6 * one["value"] * one["ms_per_step"]

@@ -207,7 +207,10 @@ def test_pipelined_grid_loop_equals_the_synchronous_one(gpu_device):
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     assert a[2] == b[2] and len(a[2]) > 30
     for k in a[1]:
-        assert a[1][k] == b[1][k], k
+        if k in ("total_confidence", "mean_confidence"):     # per batch in float64 vs per grid in float32 pairwise order (logged mean only)
+            assert abs(a[1][k] - b[1][k]) <= 1e-6 * max(1.0, abs(a[1][k])), k
+        else:
+            assert a[1][k] == b[1][k], k
     for s0 in a[3]:
         for x, y in zip(a[3][s0], b[3][s0]):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
@@ -226,3 +229,92 @@ def test_pipelined_grid_loop_equals_the_synchronous_one(gpu_device):
     assert proc.collect_batch() == [] and len(got) == 9
     for (c0, f0, r0), (c1, f1, r1) in zip(single, got):            # (same bar as the batched-vs-single comparison in test_gpu_forward)
         assert np.array_equal(c0, c1) and np.abs(f0 - f1).max() < 1e-6 and np.abs(r0 - r1).max() < 1e-6
+
+
+def test_staged_batches_device_mask_fresh_results_and_mixed_nodata(gpu_device):
+    """add_to_batch copies a grid into a pinned record slab and the valid mask is made on the device at flush time.  (i) The results
+    equal the per-grid path (host mask) -- with and without the `valid_count` hint, NaN / inf / nodata cells included; (ii) a queued
+    grid is COPIED at add time (changing the caller's array afterwards changes nothing); (iii) results are arrays of their own (a
+    later batch does not overwrite them); (iv) a batch that mixes nodata values falls back to host-made masks and still agrees;
+    (v) flush_batch() while two batches are in flight leaves those undisturbed."""
+    from bathymetric_gnn_amd import synthetic
+    proc = _processor(8)
+    grids = synthetic.vr_grid_stream(12, seed0=4100)
+    grids = [(d.copy(), u, r) for d, u, r in grids]
+    grids[2][0][0, 0] = np.nan; grids[2][0][-1, -1] = np.inf; grids[5][0][1, :] = 1.0e6
+    single = [proc.process_grid(d, u, r) for d, u, r in grids]
+
+    def same(a, b):
+        return all(np.array_equal(x[0], y[0]) and np.abs(x[1] - y[1]).max() < 1e-6 and np.abs(x[2] - y[2]).max() < 1e-6 for x, y in zip(a, b))
+
+    for hint in (False, True):
+        for d, u, r in grids:
+            nv = int(np.count_nonzero((d != 1.0e6) & np.isfinite(d))) if hint else None
+            assert proc.add_to_batch(d, u, r, valid_count=nv) is None
+        got = proc.flush_batch()
+        assert len(got) == 12 and same(single, got)
+    # (ii) copied at add time
+    d0 = grids[0][0].copy()
+    proc.add_to_batch(d0, grids[0][1], grids[0][2])
+    d0[:] = 123.0
+    r0 = proc.flush_batch()
+    assert same(single[:1], r0)
+    # (iii) results own their memory
+    keep = [tuple(x.copy() for x in t) for t in r0]
+    for d, u, r in grids[6:]:
+        proc.add_to_batch(d, u, r)
+    proc.flush_batch()
+    assert all(np.array_equal(a, b) for t, k in zip(r0, keep) for a, b in zip(t, k))
+    # (iv) mixed nodata values in one batch: a grid whose nodata is -9999 and which holds 1e6 as a REAL depth
+    dm = grids[3][0].copy(); dm[0, :] = -9999.0; dm[1, 1] = 1.0e6
+    want = proc.process_grid(dm, grids[3][1], grids[3][2], nodata=-9999.0)
+    other = proc.process_grid(dm, grids[3][1], grids[3][2])          # under the default nodata: row 0 valid, the 1e6 cell not
+    assert not same([want], [other])
+    proc.add_to_batch(grids[1][0], grids[1][1], grids[1][2])
+    proc.add_to_batch(dm, grids[3][1], grids[3][2], nodata=-9999.0)
+    proc.add_to_batch(grids[4][0], grids[4][1], grids[4][2])
+    got = proc.flush_batch()
+    assert same([single[1], want, single[4]], got)
+    assert float(np.abs(got[1][1][0, :]).max()) == 0.0               # row 0 (this grid's nodata) is invalid: zeros
+    # (v) flush while two batches are in flight
+    for lo in (0, 4):
+        for d, u, r in grids[lo:lo + 4]:
+            proc.add_to_batch(d, u, r)
+        proc.submit_batch()
+    for d, u, r in grids[8:]:
+        proc.add_to_batch(d, u, r)
+    third = proc.flush_batch()
+    first, second = proc.collect_batch(), proc.collect_batch()
+    assert same(single[:4], first) and same(single[4:8], second) and same(single[8:], third)
+    # an all-invalid grid never enters a batch
+    z = proc.add_to_batch(np.full((4, 5), 1.0e6, np.float32), None, (1.0, 1.0))
+    assert z is not None and all(float(np.abs(a).max()) == 0.0 and a.shape == (4, 5) for a in z) and not proc.batch_pending
+
+
+def test_pipelined_loop_with_a_foreign_writer_takes_the_per_grid_path(gpu_device):
+    """run_refinements(pipelined=True) applies a collected batch in one vectorised pass and writes back through the writer's bulk
+    entry; a writer WITHOUT one (the reference's writer has only update_refinement_batch) gets the per-grid calls, same end state."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import VRBagHandler
+    from bathymetric_gnn_amd.scripts.inference_native import run_refinements
+    proc = _processor(8)
+    proc.BATCH_NODE_BUDGET = 2500
+    md, ref = synthetic.synthetic_vr_bag(6, 6, seed=77, lo=3, hi=28, empty_fraction=0.1)
+    h = VRBagHandler.from_arrays(md, ref)
+
+    class PerGridOnly:
+        def __init__(self, w):
+            self.w, self.calls = w, 0
+
+        def update_refinement_batch(self, grid, d, u):
+            self.calls += 1
+            self.w.update_refinement_batch(grid, d, u)
+
+    w_bulk = h.copy_and_open_for_writing()
+    st_bulk = run_refinements(proc, h, w_bulk, 0.0, pipelined=True)
+    w_plain = PerGridOnly(h.copy_and_open_for_writing())
+    st_plain = run_refinements(proc, h, w_plain, 0.0, pipelined=True)
+    assert w_plain.calls == st_plain["grids_processed"] == h.num_refinement_cells
+    assert np.array_equal(w_bulk.refinements.view(np.uint32), w_plain.w.refinements.view(np.uint32))
+    assert w_bulk._corrections_applied == w_plain.w._corrections_applied
+    assert st_bulk == st_plain

@@ -134,3 +134,60 @@ def test_bad_arrays_rejected():
         VRBagHandler.from_arrays(md, np.zeros((1, 4), np.float32))
     assert VRBagHandler.from_arrays(md, ref[0]).varres_refinements.shape == ref.shape
     assert ref.dtype == VARRES_REFINEMENT_DTYPE
+
+
+def _iterate_like_the_reference(h, min_valid_ratio=0.0):
+    """The reference's loop, statement for statement (data/vr_bag.py:243-298): metadata cell by cell, one slice + reshape +
+    copy per grid, the valid ratio from the grid's own mask."""
+    ref, md = h.varres_refinements[0, :], h.varres_metadata
+    for row in range(md.shape[0]):
+        for col in range(md.shape[1]):
+            meta = md[row, col]
+            dx, dy = int(meta["dimensions_x"]), int(meta["dimensions_y"])
+            if dx == 0 or dy == 0:
+                continue
+            s = int(meta["index"])
+            sl = ref[s:s + dx * dy]
+            g = RefinementGrid(row, col, sl["depth"].reshape(dy, dx).copy(), sl["depth_uncrt"].reshape(dy, dx).copy(),
+                               (float(meta["resolution_x"]), float(meta["resolution_y"])), (dy, dx),
+                               (float(meta["sw_corner_x"]), float(meta["sw_corner_y"])), s)
+            if g.num_valid / g.depth.size >= min_valid_ratio:
+                yield g
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.3, 1.0])
+def test_vectorised_iterator_yields_what_the_reference_loop_yields(ratio):
+    md, ref = synthetic.synthetic_vr_bag(6, 7, seed=5, lo=3, hi=24, empty_fraction=0.15, sparse_fraction=0.2)
+    ref = ref.copy()
+    ref["depth"][0, 5] = np.nan; ref["depth"][0, 17] = np.inf           # non-finite depths are invalid cells too
+    h = VRBagHandler.from_arrays(md, ref)
+    a, b = list(_iterate_like_the_reference(h, ratio)), list(h.iterate_refinements(ratio))
+    assert len(a) == len(b) and (ratio < 1.0 or len(b) < h.num_refinement_cells)
+    for x, y in zip(a, b):
+        assert (x.base_row, x.base_col, x.start_index, x.dimensions, x.resolution, x.sw_corner) == \
+               (y.base_row, y.base_col, y.start_index, y.dimensions, y.resolution, y.sw_corner)
+        assert np.array_equal(x.depth.view(np.uint32), y.depth.view(np.uint32)) and np.array_equal(x.uncertainty, y.uncertainty)
+        assert y.depth.flags.c_contiguous and y.depth.dtype == np.float32
+        assert x.num_valid == y.num_valid == int(np.sum(y.valid_mask))
+    # the grids are views of private planes: writing into one does not touch the handler's records
+    before = h.varres_refinements.copy()
+    b[0].depth[:] = -1.0
+    assert np.array_equal(h.varres_refinements.view(np.uint8), before.view(np.uint8))
+
+
+def test_bulk_write_back_equals_the_per_grid_calls():
+    md, ref = synthetic.synthetic_vr_bag(5, 5, seed=8, lo=3, hi=15, empty_fraction=0.1)
+    h = VRBagHandler.from_arrays(md, ref)
+    grids = [g for i, g in enumerate(h.iterate_refinements()) if i % 3 != 1]       # a subset with gaps, in order
+    rng = np.random.default_rng(0)
+    new_d = [np.where(rng.random(g.shape) < 0.3, g.depth - np.float32(0.5), g.depth) for g in grids]
+    new_u = [g.uncertainty * np.float32(1.25) for g in grids]
+    w1, w2 = h.copy_and_open_for_writing(), h.copy_and_open_for_writing()
+    for g, d, u in zip(grids, new_d, new_u):
+        w1.update_refinement_batch(g, d, u)
+    changed = sum(int(np.sum((d != g.depth) & g.valid_mask)) for g, d in zip(grids, new_d))
+    w2.update_refinements_bulk(grids, np.concatenate([d.ravel() for d in new_d]), np.concatenate([u.ravel() for u in new_u]), changed=changed)
+    assert np.array_equal(w1.refinements.view(np.uint8), w2.refinements.view(np.uint8))
+    assert w1._corrections_applied == w2._corrections_applied == changed > 0
+    with pytest.raises(ValueError):
+        w2.update_refinements_bulk(grids, np.zeros(3, np.float32), None)
