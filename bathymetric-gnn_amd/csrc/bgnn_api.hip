@@ -1347,8 +1347,7 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
     o.predicted_class = (int64_t *)p;
     o.confidence = (float *)(o.predicted_class + rows);
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
-    const bool try_fused = ctx->opts.fused && g->kind == 0 && g->compact_edges &&
-                           m->desc.hidden == 64 && m->desc.num_classes <= 4 && m->head_hidden_total == 96;
+    const bool try_fused = fused_heads_available(ctx, g, m);
     if (try_fused && g->d_atlas) {          // the canvas walk writes valid cells only: clear the grids (fill 0.0) first
       const size_t nb = (size_t)g->total_cells * sizeof(float);
       if (classification && confidence == classification + g->total_cells && correction == confidence + g->total_cells) {

@@ -282,6 +282,7 @@ int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLay
 // (V3: the layer's edge vector over the canonical three attributes, [heads][3] -- nullptr: L.V is that already, default list)
 int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
                             const void *xw, const float *asd, void *xw_next, float *asd_next);
+bool fused_heads_available(const bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m);
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, const float *V3,
                              const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);

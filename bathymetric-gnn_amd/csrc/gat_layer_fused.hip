@@ -1884,6 +1884,16 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   return BGNN_ERR_UNSUPPORTED;
 }
 
+// Will launch_fused_layer_heads take this (model, graph)?  bgnn_infer_tiles asks BEFORE the forward: only then can the forward run
+// without per-node outputs (the last launch writes the grids itself).  Asked after the fact -- round 3 -- every model the fused tail
+// does not cover (GCN / GraphSAGE / GIN, other head counts) ran its whole forward twice.
+bool fused_heads_available(const bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m) {
+  if (!ctx->opts.fused || m->desc.gnn_type != BGNN_GNN_GAT || m->layers.empty()) return false;
+  const BgnnLayer &L = m->layers.back();
+  return fused_supported(g, m->desc.hidden) && L.heads == 1 && m->desc.num_classes <= 4 && m->head_hidden_total == 96 && m->hd_tab &&
+         (m->desc.predict_correction ? 3 : 2) * (m->desc.hidden / 2) <= 96;
+}
+
 // aggregate of the LAST layer (HC = C, one head) fused with the heads (+ grids)
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, const float *V3,
                              const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,

