@@ -199,6 +199,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.ragged_atlas = getenv("BGNN_NO_ATLAS") ? 0 : 1;
     o.fused_front = getenv("BGNN_NO_FUSED_FRONT") ? 0 : 1;
     o.fused_persistent = getenv("BGNN_PERSISTENT") ? 1 : 0;
+    o.bf16_two_phase = getenv("BGNN_NO_TWO_PHASE") ? 0 : 1;
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
@@ -213,7 +214,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
 static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
-      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent},
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent}, {"bf16_two_phase", &o.bf16_two_phase},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};

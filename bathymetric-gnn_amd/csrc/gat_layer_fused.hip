@@ -1773,6 +1773,454 @@ __global__ __launch_bounds__(256, 1) void gat_layer_persist_kernel(FusedArgs a, 
 #undef PTICK
 }
 
+// ---- two-phase form of the bf16 256 -> 256 instance (matrix_path = bf16, BASELINE configs[2]) ------------------------------------
+// The one-phase kernel above holds the [32 nodes x 256] accumulator (128 registers) NEXT TO everything the aggregation needs
+// (~230 VGPRs, 78 KB of LDS: two workgroups per CU), and on the bf16 path neither pipe is the bound -- a workgroup's life is a
+// chain of latencies that only MORE resident workgroups hide (the narrow instances gained 19 % going from two to three per CU).
+// This form never holds both at once:
+//   phase 1  for all 8 slabs: slab DMA -> aggregation MFMAs -> BatchNorm / ReLU -> the wave's [32 nodes x 32 ch] h slab as TWO
+//            bf16x8 operands, kept in registers (8 x 8 = 64 VGPRs for the whole 256-channel h row block); no weights, no accumulator;
+//   phase 2  four column passes of 64 columns (= one head of the next layer): the pass's whole W^T slice (16 k-steps x 2 tiles x
+//            1 KiB = 32 KB, LDS-DMA into the region the slab image and the alpha matrices no longer need) -> 32 MFMAs into 32
+//            accumulator registers -> attention dots + bf16 store of those 64 columns, under the next pass's W DMA.
+// ~160 VGPRs and 51 KB of LDS: THREE workgroups per CU.  Per accumulator the MFMAs run in the same k order as in the one-phase
+// kernel, the aggregation / BatchNorm / conversion code is the same: bit-identical results (tests/test_gpu_forward.py).
+template <int K>
+struct TwoPhaseLds {
+  using Geo = FusedGeom<K>;
+  using Win = AggWindow<K>;
+  static constexpr int HR = Geo::HR, H = 4, HC = 256, NC = 256;
+  static constexpr int SLAB_B = HR * 64;                 // bf16 slab image [HR][32 ch]
+  static constexpr int PAD_B = 512;                      // zeros: the k = 16 window's last MFMA reads 8 rows past the image (AggWindow)
+  static constexpr int ALPHA_B = 4 * 32 * Win::PITCH;    // four wave-private dense alpha matrices
+  static constexpr int SCSH_B = 2 * HC * 4;
+  static constexpr int P1_B = SLAB_B + PAD_B + ALPHA_B + SCSH_B;
+  static constexpr int W_B = 16 * 2 * 1024;              // one column pass of W^T
+  static constexpr int PATCH_B = 4 * 32 * 128;           // four wave-private two-tile bf16 store patches
+  static constexpr int ATT_B = 2 * NC * 4;
+  static constexpr int P2_B = W_B + PATCH_B + ATT_B;
+  static constexpr int SHARED_B = P1_B > P2_B ? P1_B : P2_B;
+  static constexpr int BYTES = SHARED_B + 128 * 4 + 16;  // + node id of each block cell + the canvas walk's "any node" flags
+  static_assert((SLAB_B + PAD_B) % 16 == 0, "the dense matrices start on a 16-byte boundary");
+  static_assert(HR * (H + 2) * 4 <= ALPHA_B, "alpha_src, depth and id tables of the halo fit the (not yet written) alpha region");
+  static_assert(SLAB_B + PAD_B + ALPHA_B <= W_B + PATCH_B, "scale / shift sit clear of the att vectors' landing zone");
+  static_assert(3 * BYTES <= 160 * 1024, "three workgroups per CU");
+};
+
+template <int K>
+__global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) {
+  constexpr int NTH = 256, HC = 256, C = 64, H = 4, NC = 256, NSLAB = 8, SPH = 2, NHL = 2;
+  using Geo = FusedGeom<K>;
+  using Lds = TwoPhaseLds<K>;
+  using Win = AggWindow<K>;
+  using Off = StencilOffsets<K>;
+  constexpr int HR = Geo::HR, HW_ = Geo::HW, RAD = Geo::R;
+  constexpr int ROWB = 64, CPR = 4;
+  extern __shared__ __attribute__((aligned(128))) float lds[];
+  char *base = reinterpret_cast<char *>(lds);
+  float *slab = lds;                                                             // phase 1
+  float *alx = reinterpret_cast<float *>(base + Lds::SLAB_B + Lds::PAD_B);       // phase 1: dense alpha; before that the halo tables
+  float *scsh = reinterpret_cast<float *>(base + Lds::SLAB_B + Lds::PAD_B + Lds::ALPHA_B);
+  float *has = alx;                                                              // [H][HR]
+  float *hdp = has + HR * H;                                                     // [HR]
+  int *hid = reinterpret_cast<int *>(hdp + HR);                                  // [HR]
+  char *wpass = base;                                                            // phase 2: [16 k-steps][2 tiles][1 KiB]
+  char *patches = base + Lds::W_B;                                               // phase 2: [4 waves][32 rows][128 B]
+  float *attl = reinterpret_cast<float *>(base + Lds::W_B + Lds::PATCH_B);       // phase 2: att_src | att_dst of the next layer
+  int *cid = reinterpret_cast<int *>(base + Lds::SHARED_B);                      // [128] node id of each block cell
+  int *minid = cid + 128;
+
+  const BlockPos pos = decode_block<FT_H>(a.tb);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hl = lane >> 5;
+  const int cell = wave * 32 + r;
+  const int tr = cell / TILE_W, tc = cell % TILE_W;
+  const int self_idx = (tr + RAD) * HW_ + tc + RAD;
+
+  // ---- prologue: the one-phase kernel's two load rounds (see there), without any weight traffic
+  static_assert(HR <= NTH, "one halo row per thread");
+  constexpr int NPIECE = (HR * CPR + NTH - 1) / NTH;
+  static_assert((NPIECE - 2) * NTH + NTH - 64 < HR * CPR, "every wave moves NPIECE or NPIECE - 1 pieces");
+  const uint32_t cbase = (uint32_t)pos.cell_off, uw = (uint32_t)pos.w, uh = (uint32_t)pos.h;
+  const int h1 = pos.h - 1, w1 = pos.w - 1;
+  auto cell_index = [&](int gr, int gc) -> uint32_t {
+    const int r_ = max(0, min(gr, h1)), c_ = max(0, min(gc, w1));
+    return cbase + __umul24((uint32_t)r_, uw) + (uint32_t)c_;
+  };
+  auto node_at = [&](uint32_t cl) -> int {
+    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.node_id) + (cl << 2));
+  };
+  auto in_tile = [&](int gr, int gc) -> bool { return (uint32_t)gr < uh && (uint32_t)gc < uw; };
+  const int hr_t = tid / HW_, hc_t = tid - hr_t * HW_;
+  const int gr_h = pos.r0 + hr_t - RAD, gc_h = pos.c0 + hc_t - RAD;
+  const int gr_m = pos.r0 + tr, gc_m = pos.c0 + tc;
+  const int raw_h = node_at(cell_index(gr_h, gc_h));
+  const uint32_t cell_m = cell_index(gr_m, gc_m);
+  const int raw_m = node_at(cell_m);
+  int tile_m = pos.tile;
+  if (a.tile_of_cell) tile_m = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.tile_of_cell) + (cell_m << 2));
+  static_assert(NTH % CPR == 0, "pieces advance by whole halo rows");
+  constexpr int RSTEP = NTH / CPR, RSTEP_R = RSTEP / HW_, RSTEP_C = RSTEP % HW_;
+  int drow[NPIECE], prow_r[NPIECE], prow_c[NPIECE];
+  {
+    const int row0 = tid / CPR;
+    int pr = row0 / HW_, pc = row0 - pr * HW_;
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      prow_r[p] = pr; prow_c[p] = pc;
+      drow[p] = node_at(cell_index(pos.r0 + pr - RAD, pos.c0 + pc - RAD));
+      pr += RSTEP_R; pc += RSTEP_C;
+      if (pc >= HW_) { pc -= HW_; pr += 1; }
+    }
+  }
+  float scv = a.scale[tid], shv = a.shift[tid];          // HC == NTH: one channel per thread
+  float vpre[NHL][3];
+#pragma unroll
+  for (int i = 0; i < NHL; ++i)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) vpre[i][f] = a.V[(hl + i * 2) * 3 + f];
+  int hid_v = (tid < HR && in_tile(gr_h, gc_h) && raw_h >= 0) ? raw_h : -1;
+  int my_pre = in_tile(gr_m, gc_m) ? raw_m : -1;
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) {
+    const bool row_ok = (p + 1) * NTH <= HR * CPR || prow_r[p] < FT_H + 2 * RAD;
+    if (!(row_ok && in_tile(pos.r0 + prow_r[p] - RAD, pos.c0 + prow_c[p] - RAD))) drow[p] = -1;
+  }
+  if (a.cell_map) {                  // canvas walk: blocks that hold only gutter / free space leave here (nothing is in flight yet)
+    const bool wave_any = __builtin_amdgcn_ballot_w64(my_pre >= 0) != 0;
+    if (lane == 0) minid[wave] = wave_any ? 1 : 0;
+    __syncthreads();
+    if ((minid[0] | minid[1] | minid[2] | minid[3]) == 0) return;
+  }
+  float eraw[K], adv[NHL], hasv[H], hdep;
+  float4 tdist;
+  {
+    const uint64_t hrow = (uint32_t)(hid_v >= 0 ? hid_v : 0), mrow = (uint32_t)(my_pre >= 0 ? my_pre : 0);
+    hdep = a.node_depth[hrow];
+    tdist = a.tile_dist[tile_m];
+    const float4 v4 = *reinterpret_cast<const float4 *>(a.asd + hrow * 2 * H);
+    hasv[0] = v4.x; hasv[1] = v4.y; hasv[2] = v4.z; hasv[3] = v4.w;
+    const float4 *ep = reinterpret_cast<const float4 *>(a.slope + mrow * K);
+#pragma unroll
+    for (int i = 0; i < K / 4; ++i) {
+      const float4 q = ep[i];
+      eraw[4 * i] = q.x; eraw[4 * i + 1] = q.y; eraw[4 * i + 2] = q.z; eraw[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) adv[i] = a.asd[mrow * 2 * H + H + hl + i * 2];
+  }
+  auto swz = [](int row) { return (row >> 2) & 3; };
+  static_assert(NSLAB * ROWB <= 4096, "the zero page covers a whole block's worth of slab offsets");
+  const char *xbase = reinterpret_cast<const char *>(a.xw);
+  const char *zp = reinterpret_cast<const char *>(a.zero_page);
+  const char *dbase[NPIECE];
+  {
+    const int cc = tid % CPR;
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      const int row = prow_r[p] * HW_ + prow_c[p];
+      const int c = cc ^ swz(row);
+      dbase[p] = drow[p] >= 0 ? xbase + ((uint64_t)(uint32_t)drow[p] * (uint32_t)(HC * 2) + (uint32_t)(c * 16)) : zp;
+    }
+  }
+  auto issue_slab = [&](int s) {
+    const int sb = s * ROWB;
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+      if ((p + 1) * NTH <= HR * CPR || p * NTH + tid < HR * CPR)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(dbase[p] + sb),
+                                         (__attribute__((address_space(3))) void *)(slab + (p * NTH + wave * 64) * 4), 16, 0, 0);
+    }
+  };
+  if (tid < HR) {
+    hid[tid] = hid_v;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) has[hh * HR + tid] = hid_v >= 0 ? hasv[hh] : -__builtin_inff();
+    hdp[tid] = hid_v >= 0 ? hdep : 0.0f;
+  }
+  if (hl == 0) cid[cell] = my_pre < 0 ? -1 : my_pre;
+  if (tid < Lds::PAD_B / 4) reinterpret_cast<float *>(base + Lds::SLAB_B)[tid] = 0.0f;   // (the rows read past the image: zeros)
+  {
+    float sink = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) sink += adv[i];
+#pragma unroll
+    for (int i = 0; i < K; ++i) sink += eraw[i];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) sink += hasv[hh];
+    sink += hdep + tdist.x + tdist.y + tdist.z + scv + shv;
+    asm volatile("" ::"v"(sink));
+  }
+  issue_slab(0);
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();                          // halo tables in LDS (slab 0 stays in flight)
+
+  // ---- phase A: attention coefficients, kept as bf16 pairs until their head's slabs come up
+  uint32_t apk[NHL][(K + 2) / 2];
+#pragma unroll
+  for (int i = 0; i < NHL; ++i)
+#pragma unroll
+    for (int b = 0; b < (K + 2) / 2; ++b) apk[i][b] = 0u;
+  {
+    const uint32_t hid0 = lds_addr(hid), has0 = lds_addr(has);
+    int my = lds_read1i<0>(hid0 + (uint32_t)self_idx * 4u);
+    lds_reads_done();
+    float part[NHL][K + 1];
+    if (my < 0) {
+#pragma unroll
+      for (int i = 0; i < NHL; ++i)
+#pragma unroll
+        for (int b = 0; b <= K; ++b) part[i][b] = 0.0f;
+    } else {
+      using S = HaloSlot<K, HW_>;
+      int nb[K];
+      float hs[NHL][K + 1];
+      halo_ids<K, HW_>(hid0 + (uint32_t)(self_idx - S::MAXOFF) * 4u, nb, std::make_integer_sequence<int, K>{});
+#pragma unroll
+      for (int i = 0; i < NHL; ++i)
+        halo_alpha_src<H, K, HW_>(has0 + (uint32_t)((hl + i * 2) * HR + self_idx - S::MAXOFF) * 4u, hs[i], std::make_integer_sequence<int, K>{});
+      float dsrc[K + 1];
+      halo_depths<K, HW_>(lds_addr(hdp) + (uint32_t)(self_idx - S::MAXOFF) * 4u, dsrc, std::make_integer_sequence<int, K>{});
+      lds_reads_done();
+      EdgeTerms<K> et;
+      edge_terms_compact<K>(nb, eraw, dsrc, tdist.x, tdist.y, tdist.z, et);
+      attention_head_pair<K, false>(et, hs[0], hs[1], adv[0], adv[1], vpre[0], vpre[1], part[0], part[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i)
+#pragma unroll
+      for (int b = 0; b <= K; b += 2) apk[i][b / 2] = pack_bf16x2(part[i][b], b + 1 <= K ? part[i][b + 1] : 0.0f);
+  }
+
+  // ---- phase 1: aggregate every slab; h stays in registers as bf16 MFMA operands
+  const uint32_t slab0 = lds_addr(slab);
+  const uint32_t scsh0 = lds_addr(scsh) + hl * 16;
+  const int wbase = Win::base(wave);
+  const uint32_t dn0 = lds_addr(alx) + wave * (32 * Win::PITCH);
+  const uint32_t bq0 = dn0 + r * Win::PITCH + hl * 16;
+  uint32_t tr0, tr1;
+  {
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, cb = grp & 1;
+    const int row0 = wbase + 8 * hl + q;
+    const int c = 2 * cb + (p4 >> 1);
+    tr0 = slab0 + row0 * 64 + ((c ^ ((row0 >> 2) & 3)) << 4) + 8 * (p4 & 1);
+    tr1 = slab0 + (row0 + 4) * 64 + ((c ^ (((row0 + 4) >> 2) & 3)) << 4) + 8 * (p4 & 1);
+  }
+  auto densify = [&](int hd) {
+    if (hd == 0) {
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      constexpr int DB = 32 * Win::PITCH;
+#pragma unroll
+      for (int i = 0; i < (DB + 1023) / 1024; ++i)
+        if ((i + 1) * 1024 <= DB || lane * 16 + i * 1024 < DB)
+          asm volatile("ds_write_b128 %0, %1" ::"v"(dn0 + lane * 16 + i * 1024), "v"(z4) : "memory");
+    }
+    if (hl == (hd & 1)) {
+      const int wself = self_idx - wbase;
+      const uint32_t rowb = dn0 + r * Win::PITCH;
+#pragma unroll
+      for (int b = 0; b <= K; ++b) {
+        const int off = b < K ? Off::dr[b < K ? b : 0] * HW_ + Off::dc[b < K ? b : 0] : 0;
+        const uint32_t ad = rowb + (uint32_t)(wself - off) * 2u;
+        const uint32_t v = (hd >> 1) ? apk[1][b / 2] : apk[0][b / 2];
+        if (b & 1) asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(ad), "v"(v) : "memory");
+        else asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"(v) : "memory");
+      }
+    }
+  };
+  // W^T image (hi-only bf16, MFMA A-fragment lane order): k-step st, tile t at (st * 8 + t) KiB.  A pass moves tiles 2 cp, 2 cp + 1
+  // of all 16 k-steps: 32 pieces of 1 KiB, 8 per wave, to wpass + (st * 2 + tt) KiB.
+  auto issue_w = [&](int cp) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int q = j * 4 + wave;                        // piece: st = q >> 1, tt = q & 1
+      __builtin_amdgcn_global_load_lds(
+          reinterpret_cast<const void *>(reinterpret_cast<const char *>(a.Wt) + ((q >> 1) * 8 + 2 * cp + (q & 1)) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void *)(wpass + q * 1024), 16, 0, 0);
+    }
+  };
+  bf16x8 xh[NSLAB][2];
+  auto slab_step = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s % SPH == 0 && s > 0) densify(s / SPH);
+    wait_vm_lgkm<0>();                                   // slab s is all this wave has in flight
+    __builtin_amdgcn_s_barrier();                        // slab s visible to every wave
+    if constexpr (s == 0) {
+      scsh[tid] = scv; scsh[HC + tid] = shv;             // (phase A is over on every wave: nothing is in flight, visible stores are fine)
+      densify(0);
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+    }
+    f32x16 d;
+    if constexpr (Win::NKB == 8) {
+      agg_blocks<0, 4, true, false>(d, tr0, tr1, bq0, hl);
+      agg_blocks<4, 4, false, Win::TAIL_BEYOND_PITCH>(d, tr0, tr1, bq0, hl);
+    } else {
+      static_assert(Win::NKB == 5, "window blocks");
+      agg_blocks<0, 3, true, false>(d, tr0, tr1, bq0, hl);
+      agg_blocks<3, 2, false, false>(d, tr0, tr1, bq0, hl);
+    }
+    // (the reads of slab s are complete -- agg_blocks waits for them before its MFMAs -- so the image can be handed to slab s + 1
+    //  as soon as every wave is here; BatchNorm / ReLU / conversion then run under that DMA's flight)
+    __builtin_amdgcn_s_barrier();
+    if constexpr (s + 1 < NSLAB) {
+      issue_slab(s + 1);
+    } else {
+      // last slab: the image and the alpha matrices are dead on every wave -> phase 2's first W pass and the next layer's
+      // att_src | att_dst can be requested NOW (they land in [0, 32 KB) and behind the patches: clear of the scale / shift table the
+      // BatchNorm below still reads).  One att piece per wave (waves 2, 3 repeat 0, 1's) so that every wave's VM queue counts alike.
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(((wave & 1) == 0 ? a.att_src : a.att_dst) + lane * 4),
+                                       (__attribute__((address_space(3))) void *)(attl + (wave & 1) * NC), 16, 0, 0);
+      issue_w(0);
+    }
+    f32x4 g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = (f32x4){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
+    {
+      const uint32_t cp = scsh0 + s * 128;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        f32x4 sc0, sc1, sh0, sh1;
+        if (jp == 0) { sc0 = lds_read4<0>(cp); sc1 = lds_read4<32>(cp); sh0 = lds_read4<HC * 4>(cp); sh1 = lds_read4<HC * 4 + 32>(cp); }
+        else { sc0 = lds_read4<64>(cp); sc1 = lds_read4<96>(cp); sh0 = lds_read4<HC * 4 + 64>(cp); sh1 = lds_read4<HC * 4 + 96>(cp); }
+        lds_reads_done();
+        g[2 * jp] = g[2 * jp] * sc0 + sh0;
+        g[2 * jp + 1] = g[2 * jp + 1] * sc1 + sh1;
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          asm("v_max_f32 %0, 0, %0" : "+v"(g[j].x)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].y));
+          asm("v_max_f32 %0, 0, %0" : "+v"(g[j].z)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].w));
+        }
+      }
+    }
+    xh[s][0] = to_bf16x8(g[0], g[1]);
+    xh[s][1] = to_bf16x8(g[2], g[3]);
+  };
+  slab_step(std::integral_constant<int, 0>{}); slab_step(std::integral_constant<int, 1>{});
+  slab_step(std::integral_constant<int, 2>{}); slab_step(std::integral_constant<int, 3>{});
+  slab_step(std::integral_constant<int, 4>{}); slab_step(std::integral_constant<int, 5>{});
+  slab_step(std::integral_constant<int, 6>{}); slab_step(std::integral_constant<int, 7>{});
+
+  // ---- phase 2: the GEMM, one head (64 columns) of the next layer per pass (W(0) and the att vectors are already in flight; the
+  // first pass's barrier also orders every wave's last scale / shift read before the first patch write)
+  const uint32_t wfrag = lds_addr(wpass) + lane * 16;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 ps[4], pd[4];
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
+  const int id = cid[cell];
+  constexpr int NSTORE = 4;
+  char *prow[NSTORE];
+#pragma unroll
+  for (int k = 0; k < NSTORE; ++k) {
+    const int rid = cid[wave * 32 + (lane >> 3) + 8 * k];
+    prow[k] = (rid >= 0 ? reinterpret_cast<char *>(a.out) + (int64_t)rid * (NC * 2) : reinterpret_cast<char *>(a.dump)) + (lane & 7) * 16;
+  }
+  char *patch = patches + wave * (32 * 128);
+  const uint32_t asl = lds_addr(attl + 4 * hl);
+  auto col_pass = [&](auto cpc) {
+    constexpr int cp = decltype(cpc)::value;
+    // VM queue of this wave: [att piece][W(0) x 8] (cp = 0) / [W(cp) x 8][the 4 row stores of pass cp - 1] (cp > 0)
+    if constexpr (cp == 0) wait_vm_lgkm<0>(); else wait_vm_lgkm<NSTORE>();
+    __builtin_amdgcn_s_barrier();                        // W(cp) visible
+    f32x16 acc0, acc1;
+    {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc0 = z; acc1 = z;
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {                     // four k-steps (two slabs) per LDS wait
+      f32x4 w[8];
+      if (q4 == 0) { w[0] = lds_read4<0>(wfrag); w[1] = lds_read4<1024>(wfrag); w[2] = lds_read4<2048>(wfrag); w[3] = lds_read4<3072>(wfrag);
+                     w[4] = lds_read4<4096>(wfrag); w[5] = lds_read4<5120>(wfrag); w[6] = lds_read4<6144>(wfrag); w[7] = lds_read4<7168>(wfrag); }
+      if (q4 == 1) { w[0] = lds_read4<8192>(wfrag); w[1] = lds_read4<9216>(wfrag); w[2] = lds_read4<10240>(wfrag); w[3] = lds_read4<11264>(wfrag);
+                     w[4] = lds_read4<12288>(wfrag); w[5] = lds_read4<13312>(wfrag); w[6] = lds_read4<14336>(wfrag); w[7] = lds_read4<15360>(wfrag); }
+      if (q4 == 2) { w[0] = lds_read4<16384>(wfrag); w[1] = lds_read4<17408>(wfrag); w[2] = lds_read4<18432>(wfrag); w[3] = lds_read4<19456>(wfrag);
+                     w[4] = lds_read4<20480>(wfrag); w[5] = lds_read4<21504>(wfrag); w[6] = lds_read4<22528>(wfrag); w[7] = lds_read4<23552>(wfrag); }
+      if (q4 == 3) { w[0] = lds_read4<24576>(wfrag); w[1] = lds_read4<25600>(wfrag); w[2] = lds_read4<26624>(wfrag); w[3] = lds_read4<27648>(wfrag);
+                     w[4] = lds_read4<28672>(wfrag); w[5] = lds_read4<29696>(wfrag); w[6] = lds_read4<30720>(wfrag); w[7] = lds_read4<31744>(wfrag); }
+      lds_reads_done();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                      // k-step st = 4 q4 + i = slab st / 2, half st % 2
+        const int st = 4 * q4 + i;
+        acc0 = mfma_lp(__builtin_bit_cast(bf16x8, w[2 * i]), xh[st / 2][st % 2], acc0);
+        acc1 = mfma_lp(__builtin_bit_cast(bf16x8, w[2 * i + 1]), xh[st / 2][st % 2], acc1);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // every wave has read W(cp)
+    if constexpr (cp + 1 < 4) issue_w(cp + 1);
+    // epilogue of the pass: head cp of the next layer -- attention dots, bf16 conversion, two tiles side by side through the
+    // wave's patch, whole 128-byte row segments out (the one-phase kernel's epilogue, tile pair (2 cp, 2 cp + 1))
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      constexpr int NC4 = NC * 4;
+      const int t = 2 * cp + tt;
+      const f32x16 &acc = tt ? acc1 : acc0;
+      f32x4 s4[4], d4[4];
+      s4[0] = lds_read4<0>(asl + t * 128); s4[1] = lds_read4<32>(asl + t * 128);
+      s4[2] = lds_read4<64>(asl + t * 128); s4[3] = lds_read4<96>(asl + t * 128);
+      d4[0] = lds_read4<NC4>(asl + t * 128); d4[1] = lds_read4<NC4 + 32>(asl + t * 128);
+      d4[2] = lds_read4<NC4 + 64>(asl + t * 128); d4[3] = lds_read4<NC4 + 96>(asl + t * 128);
+      lds_reads_done();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+        ps[cp] += vlo * (f32x2){s4[g].x, s4[g].y}; ps[cp] += vhi * (f32x2){s4[g].z, s4[g].w};
+        pd[cp] += vlo * (f32x2){d4[g].x, d4[g].y}; pd[cp] += vhi * (f32x2){d4[g].z, d4[g].w};
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        char *pb = patch + r * 128 + ((hl ^ ((r >> 3) & 1)) << 3);
+        *reinterpret_cast<bf16x4 *>(pb + (((tt * 4 + g) ^ (r & 7)) << 4)) = o;
+      }
+      asm volatile("" : "+v"(ps[cp]), "+v"(pd[cp]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < NSTORE; ++k) {
+      const int row = (lane >> 3) + 8 * k;
+      uint4 q = *reinterpret_cast<const uint4 *>(patch + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+      if (k & 1) q = make_uint4(q.z, q.w, q.x, q.y);
+      *reinterpret_cast<uint4 *>(prow[k] + cp * 128) = q;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  col_pass(std::integral_constant<int, 0>{}); col_pass(std::integral_constant<int, 1>{});
+  col_pass(std::integral_constant<int, 2>{}); col_pass(std::integral_constant<int, 3>{});
+  {
+    float srow[4], drow_[4];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+      const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
+      srow[hd] = sl + __shfl_xor(sl, 32);
+      drow_[hd] = dl + __shfl_xor(dl, 32);
+    }
+    if (id >= 0 && hl == 0) {
+      float *ao = a.asd_out + (int64_t)id * 8;
+      *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], srow[2], srow[3]);
+      *reinterpret_cast<float4 *>(ao + 4) = make_float4(drow_[0], drow_[1], drow_[2], drow_[3]);
+    }
+  }
+}
+
+template <int K>
+static int launch_two_phase(bgnn_ctx *ctx, const FusedArgs &a) {
+  constexpr size_t lds_bytes = (size_t)TwoPhaseLds<K>::BYTES;
+  static std::atomic<uint64_t> configured{0};
+  auto kern = gat_layer_bf16_2p_kernel<K>;
+  if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
+    BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tb.n_blocks), dim3(256), lds_bytes, ctx->stream, a);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
 template <int K>
 static int launch_persist(bgnn_ctx *ctx, const FusedArgs &a, int uni_h, int uni_w) {
   constexpr size_t lds_bytes = (size_t)PersistLds<K>::FLOATS * 4;
@@ -1872,6 +2320,9 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
     a.eattr = g->d_eattr;
     return g->K == 8 ? launch_persist<8>(ctx, a, g->uni_h, g->uni_w) : launch_persist<4>(ctx, a, g->uni_h, g->uni_w);
   }
+  // bf16 storage, 256 -> 256: the two-phase form (three workgroups per CU; bit-identical to the one-phase instance)
+  if (split == 3 && HC == 256 && NC == 256 && C == 64 && ctx->opts.bf16_two_phase)
+    return g->K == 8 ? launch_two_phase<8>(ctx, a) : g->K == 4 ? launch_two_phase<4>(ctx, a) : launch_two_phase<16>(ctx, a);
 #define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
   BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
 #undef BGNN_FUSED_CASE

@@ -871,6 +871,42 @@ def test_config3_bf16_batch_properties(gpu_device):
         assert np.abs(a["confidence"] - b["confidence"]).max() < 2e-2 and a["confidence"].shape == b["confidence"].shape
 
 
+@pytest.mark.parametrize("conn", ["16-dilated", "8-connected", "4-connected"])
+def test_bf16_two_phase_instance_is_bit_identical_to_the_one_phase_instance(conn, gpu_device):
+    """matrix_path = bf16: the 256 -> 256 fused layer runs in its two-phase form by default (all slabs aggregated into bf16 registers,
+    then the GEMM in four column passes; three workgroups per CU).  Aggregation, BatchNorm / ReLU, conversion and the k order of every
+    accumulator are the one-phase instance's: the grids must agree BIT FOR BIT -- uniform tiles with holes and ragged edges, and a
+    ragged batch walked through the canvas."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    model = _model(synthetic.synthetic_state_dict(seed=1234))
+    gb = GraphBuilder(connectivity=conn)
+    eng = TileBatchEngine(model, gb, gpu_device)
+    ctx = rt.get_context(gpu_device)
+    assert ctx.get_option("bf16_two_phase") == 1
+    depth, mask, _ = synthetic.synthetic_tile_batch(5, 72, 88, 640, "V1")
+    depth = depth.copy(); depth[3, 10:20, 30:50] = np.nan
+    hw = np.tile(np.array([[72, 88]], np.int32), (5, 1)); res = np.full((5, 2), 0.5)
+    d_t = torch.from_numpy(depth).cuda().reshape(-1); m_t = torch.from_numpy((mask & np.isfinite(depth)).view(np.uint8)).cuda().reshape(-1)
+    ragged = [synthetic.synthetic_tile(h, w, 700 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (9, 31), (50, 50), (3, 3), (26, 8)])]
+    _set_matrix_path("bf16")
+    outs = {}
+    for two in (1, 0):
+        ctx.set_option("bf16_two_phase", two)
+        try:
+            u = eng.infer_device(hw, res, d_t, m_t, None).clone()
+            rg = eng.infer([t[0] for t in ragged], [t[1] for t in ragged], None, [(0.5, 1.0)] * len(ragged))
+        finally:
+            ctx.set_option("bf16_two_phase", 1)
+        outs[two] = (u, rg)
+    assert torch.isfinite(outs[1][0]).all() and float(outs[1][0][1].max()) > 0.0
+    assert torch.equal(outs[1][0], outs[0][0])
+    for a, b in zip(outs[1][1], outs[0][1]):
+        for k in ("classification", "confidence", "correction"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
 def test_bf16_storage_refuses_what_it_does_not_cover(gpu_device):
     """matrix_path = bf16 exists on the fused stencil path of the default model shape only: anything else fails loudly
     instead of silently running another precision."""
