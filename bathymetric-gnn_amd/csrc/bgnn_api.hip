@@ -656,6 +656,17 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     }
   }
 
+  // plain backbones (hidden 64): the layer weight in the fused layer kernel's column-permuted image (launch_fused_plain_layer)
+  std::vector<size_t> o_plainfp(L, 0);
+  if (!gat && hid == 64) {
+    for (int l = 0; l < L; ++l) o_plainfp[l] = reserve((size_t)(d->gnn_type == BGNN_GNN_SAGE ? 2 : 1) * hid * hid);
+    for (int l = 0; l < L; ++l) {                          // (reserve may reallocate pk: sources taken afterwards)
+      const int D = (d->gnn_type == BGNN_GNN_SAGE ? 2 : 1) * hid;
+      std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * hid);
+      pack_tilegroup_image(src.data(), D, hid, pk.data() + o_plainfp[l]);
+    }
+  }
+
   bgnn_model *m = new bgnn_model();
   m->ctx = ctx; m->desc = *d; m->blob_floats = pk.size();
   hipError_t e = hipMalloc((void **)&m->blob, pk.size() * sizeof(float));
@@ -680,6 +691,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     if (d->gnn_type == BGNN_GNN_GIN) { Ly.b1 = m->blob + lo[l].b1; Ly.Wt2 = m->blob + lo[l].Wt2; Ly.b2 = m->blob + lo[l].b2; }
     Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
     Ly.tr_Wt = lo[l].tr_Wt ? m->blob + lo[l].tr_Wt : nullptr;
+    Ly.Wfp = o_plainfp[l] ? m->blob + o_plainfp[l] : nullptr;
   }
   m->ones = m->blob + o_ones;
   for (int l = 0; l < L && gat; ++l) {
@@ -1157,9 +1169,25 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     float *dinv = asdX;
     if (d.gnn_type == BGNN_GNN_GCN) BGNN_TRY(launch_degree_inv_sqrt(ctx, g, dinv));
     const size_t nl = m->layers.size();
+    // Eval mode on stencil graphs: a layer is ONE launch of the fused layer kernel in its plain-backbone mode -- aggregate ->
+    // GEMM -> per-column post-op -- instead of reduce + GEMM launches with h round-tripping through HBM (GIN: its second Linear
+    // stays a GEMM launch).  Anything the fused form does not cover falls through to the plain kernels below.
+    const bool plain_fused = use_fused && g->kind == 0 && hid == 64;
     for (size_t l = 0; l < nl; ++l) {                 // invariant: X = h_l [rows][hid]
       const BgnnLayer &L = m->layers[l];
       const int relu = l + 1 < nl ? 1 : 0;
+      if (plain_fused) {
+        int rc = BGNN_ERR_UNSUPPORTED;
+        if (d.gnn_type == BGNN_GNN_GCN) rc = launch_fused_plain_layer(ctx, g, 1, hid, X, dinv, L.Wfp, m->ones, L.scale, L.shift, relu, Y);
+        else if (d.gnn_type == BGNN_GNN_SAGE) rc = launch_fused_plain_layer(ctx, g, 2, hid, X, nullptr, L.Wfp, m->ones, m->ones, L.b2, relu, Y);
+        else rc = launch_fused_plain_layer(ctx, g, 3, hid, X, nullptr, L.Wfp, m->ones, m->ones, L.b1, 1, Y);
+        if (rc == BGNN_OK) {
+          if (d.gnn_type == BGNN_GNN_GIN) BGNN_TRY(launch_gemm_f32(ctx, Y, hid, L.Wt2, L.b2, X, hid, dm, rows, hid, hid, relu));
+          else std::swap(X, Y);
+          continue;
+        }
+        if (rc != BGNN_ERR_UNSUPPORTED) return rc;
+      }
       if (d.gnn_type == BGNN_GNN_GCN) {               // lin, normalised aggregate, + bias, BatchNorm, ReLU
         BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt, nullptr, Y, hid, dm, rows, hid, hid, 0));
         if (tr) {

@@ -285,6 +285,9 @@ int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLay
 int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
                             const void *xw, const float *asd, void *xw_next, float *asd_next);
 bool fused_heads_available(const bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m);
+// one layer of a plain backbone as aggregate -> GEMM -> post-op (mode 1 GCN, 2 GraphSAGE, 3 GIN's first Linear); see gat_layer_fused.hip
+int launch_fused_plain_layer(bgnn_ctx *ctx, const bgnn_graph *g, int mode, int C, const float *x, const float *dinv, const float *Wfp,
+                             const float *ones, const float *post_scale, const float *post_shift, int post_relu, float *out);
 int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m, const BgnnLayer &L, int C, const float *V3,
                              const void *xw, const float *asd, float thr_auto, float thr_review, float norm_floor,
                              const bgnn_outputs *o, float *cls_grid, float *conf_grid, float *corr_grid);

@@ -77,6 +77,7 @@ struct FusedArgs {
   const float *zero_page; // >= 16 B of zeros (source of halo rows that have no node)
   float *dump;            // >= 1 KiB scratch row: stores of rows that have no node land here (keeps the epilogue branch-free)
   int relu, dbg;
+  int self_loops, relu2;  // AGG != 0 (plain backbones): the graph carries explicit self loops; ReLU of the post-GEMM epilogue
   unsigned long long *stamps;   // diagnostic build only: per-phase cycle sums
   // EPI_NEXT
   const float *att_src;   // [NC]
@@ -534,8 +535,19 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
   static constexpr int PER_CU = FLOATS * 4 * 3 <= 160 * 1024 && NT <= 3 && !WIDE_PHASE_A ? 3 : FLOATS * 4 * 2 <= 160 * 1024 ? 2 : 1;
 };
 
-template <int HC, int C, int K, int NT, int EPI, int SP = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3, 3 bf16 storage + MFMA
+// AGG (exact path, EPI_NEXT only): what phase A puts into the coefficient table, and what the epilogue does with the product --
+//   0  GATConv: softmax attention; epilogue = next layer's attention dots (the kernel this file is about)
+//   1  GCNConv: coefficient dinv[i] dinv[j] (self: dinv[i]^2), dinv = (in-degree + 1)^-1/2 read where GAT reads alpha_src
+//   2  SAGEConv (mean): TWO virtual heads over the SAME C source channels -- head 0 = 1 / count on every in-edge, head 1 = the node
+//      itself -- so the GEMM sees [mean_j x_j | x_i] against the stacked [lin_l ; lin_r] weight
+//   3  GINConv (eps = 0): 1 on every in-edge, 1 on the node itself (2 with an explicit self loop)
+// and for 1 .. 3 the layer is aggregate -> GEMM -> per-column scale / shift (+ ReLU) -> h_{l+1}: the post-op vectors ride where the
+// attention vectors ride (a.att_src = scale, a.att_dst = shift), the pre-GEMM scale / shift are the identity.  (GCN: A (X W) = (A X) W.)
+template <int HC, int C, int K, int NT, int EPI, int SP = 0, int AGG = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3, 3 bf16 storage + MFMA
 __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) void gat_layer_fused_kernel(FusedArgs a) {
+  static_assert(AGG == 0 || (SP == 0 && EPI == EPI_NEXT), "the plain backbones run on the exact path, layer form");
+  static_assert(AGG != 2 || HC == 2 * C, "GraphSAGE: two virtual heads");
+  constexpr int SRCW = AGG == 2 ? C : HC;                // channels of a SOURCE row (GraphSAGE: both virtual heads read the same C)
   // (narrow next stages leave registers and LDS for a third workgroup per CU)
   // 4 waves.  Wave w: cells 32w..32w+31 of the block (two tile rows).  Lane (r, hl): node r of the group, k-half hl.
   constexpr int NTH = 256;
@@ -669,7 +681,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   for (int i = 0; i < NHL; ++i) {
     const int hh = hl + i * 2;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) vpre[i][f] = hh < H ? a.V[hh * 3 + f] : 0.0f;
+    for (int f = 0; f < 3; ++f) vpre[i][f] = (AGG == 0 && hh < H) ? a.V[hh * 3 + f] : 0.0f;
   }
   // (heads: the small second-stage weight table -- 296 floats, packed on the host in its LDS layout -- is one LDS-DMA piece
   //  issued where its LDS region falls free, see stage_head_table below.  Read straight from global memory in the final epilogue
@@ -708,7 +720,17 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // of the bytes and registers of the [K][3] block this round used to load (k = 16: 64 + 4 + 16 instead of 192 bytes per node).
   float eraw[K], adv[NHL], hasv[H], hdep;
   float4 tdist;
-  {
+  if constexpr (AGG != 0) {                              // plain backbones: no edge terms; GCN reads dinv of the halo row
+    const uint64_t hrow = (uint32_t)(hid_v >= 0 ? hid_v : 0);
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) hasv[hh] = 0.0f;
+    if constexpr (AGG == 1) hasv[0] = a.asd[hrow];
+#pragma unroll
+    for (int i = 0; i < K; ++i) eraw[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) adv[i] = 0.0f;
+    hdep = 0.0f; tdist = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
     const uint64_t hrow = (uint32_t)(hid_v >= 0 ? hid_v : 0), mrow = (uint32_t)(my_pre >= 0 ? my_pre : 0);   // (zero-extended: one v_mad_u64_u32 each)
     hdep = a.node_depth[hrow];
     tdist = a.tile_dist[tile_m];
@@ -762,7 +784,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     for (int p = 0; p < NPIECE; ++p) {
       const int row = prow_r[p] * HW_ + prow_c[p];
       const int c = cc ^ swz(row);
-      dbase[p] = drow[p] >= 0 ? xbase + ((uint64_t)(uint32_t)drow[p] * (uint32_t)(HC * XB) + (uint32_t)(c * 16)) : zp;
+      dbase[p] = drow[p] >= 0 ? xbase + ((uint64_t)(uint32_t)drow[p] * (uint32_t)(SRCW * XB) + (uint32_t)(c * 16)) : zp;
     }
   }
   int npc = 0;
@@ -778,7 +800,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
     }
   };
   auto issue_slab = [&](int s) {
-    const int sb = s * ROWB;                           // wave-uniform
+    const int sb = (AGG == 2 ? s % SPH : s) * ROWB;    // wave-uniform (GraphSAGE: the second virtual head re-reads the same channels)
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) {
       if ((p + 1) * NTH <= HR * CPR || p * NTH + tid < HR * CPR) {        // (only the last piece is partial: compile-time true before)
@@ -792,7 +814,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   if (tid < HR) {
     hid[tid] = hid_v;
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) has[hh * HR + tid] = hid_v >= 0 ? hasv[hh] : -__builtin_inff();   // (-inf: an absent source drops out of the softmax)
+    for (int hh = 0; hh < H; ++hh) has[hh * HR + tid] = hid_v >= 0 ? hasv[hh] : (AGG == 0 ? -__builtin_inff() : 0.0f);   // (-inf: an absent source drops out of the softmax)
     hdp[tid] = hid_v >= 0 ? hdep : 0.0f;
   }
   if (Lds::HID_IN_ALPHA && hl == 0) cid[cell] = my_pre < 0 ? -1 : my_pre;
@@ -849,6 +871,26 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       int nb[K];
       float hs[NHL][K + 1];
       halo_ids<K, HW_>(hid0 + (uint32_t)(self_a - S::MAXOFF) * 4u, nb, std::make_integer_sequence<int, K>{});
+      if constexpr (AGG != 0) {
+        // plain backbones: the coefficient of in-edge b (b = K: the node itself), in the order the gather sums them -- the order of
+        // neighbor_reduce.hip (slots ascending, self last)
+        static_assert(AGG == 0 || NHL == 1, "one (virtual) head per lane");
+        if constexpr (AGG == 1) halo_alpha_src<1, K, HW_>(has0 + (uint32_t)(self_a - S::MAXOFF) * 4u, hs[0], std::make_integer_sequence<int, K>{});
+        lds_reads_done();
+        int cnt = a.self_loops ? 1 : 0;
+#pragma unroll
+        for (int b = 0; b < K; ++b) cnt += nb[b] >= 0 ? 1 : 0;
+        const float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+        for (int b = 0; b <= K; ++b) {
+          const bool self = b == K, on = self || nb[b < K ? b : 0] >= 0;
+          float c;
+          if constexpr (AGG == 1) c = self ? hs[0][K] * hs[0][K] : (on ? hs[0][b] * hs[0][K] : 0.0f);      // dinv[j] * dinv[i]
+          else if constexpr (AGG == 2) c = hl == 0 ? ((self ? a.self_loops != 0 : on) ? inv : 0.0f) : (self ? 1.0f : 0.0f);
+          else c = self ? (a.self_loops ? 2.0f : 1.0f) : (on ? 1.0f : 0.0f);
+          part[0][b] = c;
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NHL; ++i) {
         const int hh = hl + i * 2 < H ? hl + i * 2 : 0;
@@ -866,6 +908,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         for (int i = 0; i < NHL; ++i)
           if (hl + i * 2 < H) attention_head<K, false>(et, hs[i], adv[i], vpre[i], part[i]);
       }
+      }   // AGG == 0
     }
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
@@ -1181,10 +1224,16 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         lds_reads_done();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-          const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
-          ps[t / TPH] += vlo * (f32x2){s4[g].x, s4[g].y}; ps[t / TPH] += vhi * (f32x2){s4[g].z, s4[g].w};
-          pd[t / TPH] += vlo * (f32x2){d4[g].x, d4[g].y}; pd[t / TPH] += vhi * (f32x2){d4[g].z, d4[g].w};
+          float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+          if constexpr (AGG != 0) {
+            // plain backbones: the layer's post-op on the product -- per-column scale (s4) / shift (d4), ReLU -- instead of attention dots
+            v.x = v.x * s4[g].x + d4[g].x; v.y = v.y * s4[g].y + d4[g].y; v.z = v.z * s4[g].z + d4[g].z; v.w = v.w * s4[g].w + d4[g].w;
+            if (a.relu2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+          } else {
+            const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+            ps[t / TPH] += vlo * (f32x2){s4[g].x, s4[g].y}; ps[t / TPH] += vhi * (f32x2){s4[g].z, s4[g].w};
+            pd[t / TPH] += vlo * (f32x2){d4[g].x, d4[g].y}; pd[t / TPH] += vhi * (f32x2){d4[g].z, d4[g].w};
+          }
           if constexpr (SP == 3) {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 o;
@@ -1224,7 +1273,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
         srow[hd] = sl + __shfl_xor(sl, 32);
         drow_[hd] = dl + __shfl_xor(dl, 32);
       }
-      if (id >= 0 && hl == 0) {
+      if (AGG == 0 && id >= 0 && hl == 0) {
         float *ao = a.asd_out + (int64_t)id * 2 * H2;
         if constexpr (H2 == 4) {
           *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], srow[2], srow[3]);
@@ -2237,12 +2286,12 @@ static int launch_persist(bgnn_ctx *ctx, const FusedArgs &a, int uni_h, int uni_
   return BGNN_OK;
 }
 
-template <int HC, int C, int K, int NT, int EPI, int SP = 0>
+template <int HC, int C, int K, int NT, int EPI, int SP = 0, int AGG = 0>
 static int launch_inst(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr size_t lds_bytes = (size_t)FusedLds<HC, C, K, NT, EPI, SP>::FLOATS * 4;
   static_assert(lds_bytes <= 160 * 1024, "one workgroup fits the CU's LDS");
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
-  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, SP>;
+  auto kern = gat_layer_fused_kernel<HC, C, K, NT, EPI, SP, AGG>;
   const size_t lds_launch = std::max(lds_bytes, (size_t)ctx->opts.fused_lds_pad_kb * 1024);   // (pad: occupancy experiment)
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2332,6 +2381,28 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
     return g->K == 8 ? launch_inst<hc, 64, 8, nt, EPI_NEXT>(ctx, a) : launch_inst<hc, 64, 4, nt, EPI_NEXT>(ctx, a);
   BGNN_FUSED_CASE(128, 4) BGNN_FUSED_CASE(128, 2) BGNN_FUSED_CASE(64, 2)
 #undef BGNN_FUSED_CASE
+  return BGNN_ERR_UNSUPPORTED;
+}
+
+// One layer of a plain backbone (GCN / GraphSAGE / GIN) as aggregate -> GEMM -> post-op in ONE launch (kernel template AGG = mode):
+// x [rows][C] -> out [rows][C].  `Wfp` = the layer's W^T ([C][C]; GraphSAGE: the stacked [2 C][C]) in the column-permuted image;
+// post_scale / post_shift [C] and post_relu: the per-column epilogue; dinv [rows] (GCN only).  BGNN_ERR_UNSUPPORTED: take the plain kernels.
+int launch_fused_plain_layer(bgnn_ctx *ctx, const bgnn_graph *g, int mode, int C, const float *x, const float *dinv, const float *Wfp,
+                             const float *ones, const float *post_scale, const float *post_shift, int post_relu, float *out) {
+  if (!fused_supported(g, C) || !Wfp || mode < 1 || mode > 3) return BGNN_ERR_UNSUPPORTED;
+  FusedArgs a{};
+  BgnnLayer L{};
+  L.V = nullptr; L.scale = const_cast<float *>(ones); L.shift = ctx->zero_page;   // pre-GEMM epilogue: the identity
+  fill_common(a, g, L, nullptr, x, dinv, 0);
+  a.Wt = Wfp; a.att_src = post_scale; a.att_dst = post_shift; a.out = out; a.asd_out = nullptr;
+  a.H2 = 1; a.C2 = C; a.relu2 = post_relu; a.self_loops = g->include_self_loops;
+  ProfScope ps(ctx, BGNN_K_FUSED);
+#define BGNN_PLAIN_CASE(M, HCV)                                                                                   \
+  if (mode == M)                                                                                                  \
+    return g->K == 8 ? launch_inst<HCV, 64, 8, 2, EPI_NEXT, 0, M>(ctx, a) : g->K == 4 ? launch_inst<HCV, 64, 4, 2, EPI_NEXT, 0, M>(ctx, a) \
+                                                                                       : launch_inst<HCV, 64, 16, 2, EPI_NEXT, 0, M>(ctx, a);
+  BGNN_PLAIN_CASE(1, 64) BGNN_PLAIN_CASE(2, 128) BGNN_PLAIN_CASE(3, 64)
+#undef BGNN_PLAIN_CASE
   return BGNN_ERR_UNSUPPORTED;
 }
 

@@ -89,22 +89,21 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
 
 
 def plain_backbone_model(gnn_type, num_layers=4, hidden=64, in_ch=7, deg=8, classes=3):
-    """Compulsory HBM bytes per node and forward of the non-attention backbones (reference models/gnn.py:120-143; plain gather +
-    GEMM kernels, csrc/neighbor_reduce.hip + gemm_f32.hip): every kernel reads its inputs once and writes its outputs once, float32.
-    K = 64 GEMMs have 16 flop per byte -- below the 19.7 flop/B balance of the exact-f32 MFMA -- so both kernel classes are priced
-    by bytes.  ``agg``: the neighbour reductions (x row in, K stencil ids, out row; GCN + 4 B of deg^-1/2, GraphSAGE writes [mean | x]);
-    ``gemm``: every GEMM launch (extractor 2, backbone 1-2 per layer, the heads' first layers)."""
+    """Compulsory HBM bytes and executed flops per node and forward of the non-attention backbones (reference models/gnn.py:120-143).
+    Since round 4 a layer is ONE launch of the fused layer kernel in its plain-backbone mode (aggregate -> GEMM -> per-column post-op;
+    GIN's second Linear stays a GEMM launch): ``fused_bytes`` = h row in + h row out per layer (+ 4 B of deg^-1/2 for GCN),
+    ``fused_flops`` = the layer's GEMM (GraphSAGE: K = 128, the stacked [lin_l ; lin_r]); ``gemm_bytes`` = every plain GEMM launch
+    (extractor 2, heads' first layers 1, GIN + 1 per layer).  K = 64 GEMMs have 16 flop per byte -- below the 19.7 flop/B balance of the
+    exact-f32 MFMA -- so they are priced by bytes; the fused launches are priced both ways."""
     row = 4 * hidden
     gemm = (32 + row) + (row + row) + (row + 4 * 3 * (hidden // 2))          # extractor layers, heads' first layers
-    agg = 0
+    fused_bytes, fused_flops = 0, 0
     for _ in range(num_layers):
-        if gnn_type == "GCN":
-            gemm += row + row; agg += row + 4 * deg + 4 + row
-        elif gnn_type == "GraphSAGE":
-            agg += row + 4 * deg + 2 * row; gemm += 2 * row + row
-        else:                                                                   # GIN
-            agg += row + 4 * deg + row; gemm += 2 * (row + row)
-    return {"agg_bytes": agg, "gemm_bytes": gemm}
+        fused_bytes += row + row + (4 if gnn_type == "GCN" else 0)
+        fused_flops += 2 * hidden * hidden * (2 if gnn_type == "GraphSAGE" else 1)
+        if gnn_type == "GIN":
+            gemm += row + row
+    return {"fused_bytes": fused_bytes, "fused_flops": fused_flops, "gemm_bytes": gemm}
 
 
 def cpu_baseline(n_runs, tile, sd, seed0, connectivity="8-connected"):
@@ -566,10 +565,12 @@ class Bench:
         roofs = {}
         if wl.get("gnn_type", "GAT") != "GAT":
             pm = plain_backbone_model(wl["gnn_type"], num_layers=self.layers, deg=wl["deg"])
-            roofs["aggregate_hbm"] = roof("neighbor_reduce_kernel", "aggregate", "hbm", pm["agg_bytes"],
-                                          f"{wl['gnn_type']}: neighbour reductions (x row + stencil ids in, reduced row out), priced by compulsory bytes")
+            roofs["fused_hbm"] = roof("gat_layer_fused_kernel", "fused", "hbm", pm["fused_bytes"],
+                                      f"{wl['gnn_type']} layers, one fused launch each (aggregate -> GEMM -> post-op): h row in, h row out")
+            roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma", pm["fused_flops"], "same launches priced by the layer GEMM's exact-f32 flops")
             roofs["gemm_hbm"] = roof("gemm_f32_kernel", "gemm", "hbm", pm["gemm_bytes"],
-                                     "every GEMM launch (K = 64 / 128: below the f32 MFMA's flop/B balance), priced by compulsory bytes")
+                                     "the plain GEMM launches (extractor, heads' first layers, GIN's second Linear; K = 64: below the f32 MFMA's "
+                                     "flop/B balance), priced by compulsory bytes")
         elif prof["fused"]["launches"]:
             if bf16:
                 roofs["fused_mfma"] = roof("gat_layer_fused_kernel", "fused", "mfma_bf16", am["fused_flops"],
@@ -616,7 +617,10 @@ class Bench:
                 v["traffic_frac"] = v["traffic"] / (v["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
                 v["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
                                        f"kernels {t.get('_kernel_source_sha')} (= this library), collected separately, not by this run")
-        if "fused_mfma" in roofs:
+        if wl.get("gnn_type", "GAT") != "GAT" and roofs:
+            # the class that takes the most time; for the fused launches the roof they sit closest to
+            dominant = max(roofs.values(), key=lambda v: (v["avg_launch_ms"] * v["launches_per_step"], v["frac"]))
+        elif "fused_mfma" in roofs:
             dominant = roofs["fused_hbm"] if (split or bf16) else roofs["fused_mfma"]   # 16-bit MFMA paths: memory-side bound
         elif roofs:
             dominant = max(roofs.values(), key=lambda v: v["avg_launch_ms"] * v["launches_per_step"])
@@ -728,7 +732,7 @@ def main():
     if rank == 0:
         rep = bench.report(wl, m)
         line = {
-            "metric": ((f"classified tile-nodes/s (graph build + 4-layer {wl.get('gnn_type')} forward + scatter; plain gather + GEMM kernels)"
+            "metric": ((f"classified tile-nodes/s (graph build + 4-layer {wl.get('gnn_type')} forward + scatter; fused aggregate-GEMM layer launches)"
                         if wl.get("gnn_type", "GAT") != "GAT" else
                         "classified tile-nodes/s (fused graph build + 4-layer GAT forward + scatter)") if wl["kind"] != "survey" else
                        "classified tile-nodes/s (node evaluations of the survey's overlapping tiles: cut + graph build + GAT forward + stitch)"),
@@ -760,7 +764,7 @@ def main():
         plain = wl.get("gnn_type", "GAT") != "GAT"
         default_headline = wl["kind"] == "tiles" and not wl["unfused"] and not wl["bf16"] and not wl["split"] and not plain
         if plain:
-            line["path"], line["matrix_path"] = "plain gather + GEMM", "exact f32"
+            line["path"], line["matrix_path"] = "fused layers (plain-backbone mode)", "exact f32"
 
         def guarded(key, fn):
             """One side measurement: its failure is recorded under its key, the headline still prints."""

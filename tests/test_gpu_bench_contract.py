@@ -60,7 +60,7 @@ def test_default_command_shape_prints_one_small_line(gpu_device, tmp_path):
         assert k in j, k
     assert set(j["gnn_types"]) == {"GCN", "GraphSAGE", "GIN"}
     for v in j["gnn_types"].values():
-        assert v["value"] > 0 and 0 < v["frac"] <= 1.0 and v["kernel"] in ("neighbor_reduce_kernel", "gemm_f32_kernel")
+        assert v["value"] > 0 and 0 < v["frac"] <= 1.0 and v["kernel"] in ("gat_layer_fused_kernel", "gemm_f32_kernel")
     for k in ("config3", "config4", "config5"):
         assert "error" not in j[k], j[k]
         assert j[k]["value"] > 0 and j[k]["ms_per_step"] > 0 and j[k]["dtype"] in ("f32", "bf16")
