@@ -485,6 +485,32 @@ def test_other_backbones_match_oracle(kind, loops, gpu_device):
         assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4
 
 
+@pytest.mark.parametrize("kind,conn", [("GCN", "16-dilated"), ("GraphSAGE", "4-connected"), ("GIN", "16-dilated"), ("GCN", "4-connected")])
+def test_fused_plain_layers_on_the_other_stencils(kind, conn, gpu_device):
+    """The plain backbones' fused layer form (aggregate -> GEMM -> post-op) on the 4-connected and the 16-dilated stencil, ragged
+    tiles with holes, against the oracle (the 8-connected case and the launch counts: test_other_backbones_match_oracle)."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    d, mk, _ = synthetic.synthetic_tile(45, 70, 400, "V1")
+    og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5), connectivity=conn)
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=4, seed=41), og.x, og.edge_index, og.edge_attr)
+    m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=4, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).eval()
+    g = GraphBuilder(connectivity=conn).build_graph(d, mk, None, (0.5, 0.5))
+    ctx = rt.get_context(gpu_device)
+    ctx.profile(rt.K_NAMES)
+    try:
+        out = m.predict(g)
+        prof = ctx.profile_read()
+    finally:
+        ctx.profile([])
+    assert prof["fused"]["launches"] == 4
+    # (a 4-layer GCN's normalised averaging leaves these synthetic weights a single class: the numeric bars still bind)
+    _compare(out, gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr), require_mixed=False)
+
+
 @pytest.mark.parametrize("path,bound", [("bf16x3", 5e-5), ("fp16x3", 5e-6)])
 def test_split_matrix_paths(path, bound, gpu_device):
     """Opt-in matrix_path = bf16x3 / fp16x3 (context option; BGNN_SPLIT_BF16=1 / BGNN_SPLIT_F16=1 set the default of a new

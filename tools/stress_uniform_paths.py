@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Race hunt for the uniform-batch paths: random tile sizes / masks / batch sizes; every option pair that must not change a bit
-(fused_persistent, fused_front) is toggled and compared, every configuration is run twice (run-to-run equality), and the bf16 path
+(fused_persistent, fused_front, bf16_two_phase) is toggled and compared, every configuration is run twice (run-to-run equality), and the bf16 path
 is checked for finiteness and distance to the exact path."""
 import argparse, os, sys, time
 import numpy as np, torch
@@ -36,9 +36,12 @@ for rnd in range(args.rounds):
     ok = all(torch.equal(o, outs[0]) for o in outs[1:])
     ctx.set_option("matrix_path", "bf16")
     bf = eng.infer_device(hw, res, d, m, u).clone(); bf2 = eng.infer_device(hw, res, d, m, u).clone()
+    ctx.set_option("bf16_two_phase", 0)               # the one-phase 256 -> 256 instance: bit-identical to the two-phase form
+    bf1 = eng.infer_device(hw, res, d, m, u).clone()
+    ctx.set_option("bf16_two_phase", 1)
     ctx.set_option("matrix_path", "exact_f32")
     err = float((bf[1] - outs[0][1]).abs().max())
-    ok = ok and torch.equal(bf, bf2) and err < 5e-2 and bool(torch.isfinite(bf).all())
+    ok = ok and torch.equal(bf, bf2) and torch.equal(bf, bf1) and err < 5e-2 and bool(torch.isfinite(bf).all())
     nodes += int(sum(int(x.sum()) for x in mask))
     if not ok:
         bad += 1
