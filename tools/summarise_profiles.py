@@ -78,7 +78,8 @@ def main():
                                ("bench_split_f16", "bench_split_f16"), ("bench_vr_50k", "bench_vr_budget50k"),
                                ("bench_vr_50k_1ctx", "bench_vr_budget50k_1ctx"), ("bench_vr_50k_2ctx", "bench_vr_budget50k_2ctx"),
                                ("bench_survey_20000", "bench_survey_20000"),
-                               ("bench_vr_1M", "bench_vr_budget1M"), ("bench_c3", "bench_c3_k16_bf16"), ("bench_bf16_k8", "bench_bf16_k8")):
+                               ("bench_vr_1M", "bench_vr_budget1M"), ("bench_c3", "bench_c3_k16_bf16"), ("bench_bf16_k8", "bench_bf16_k8"),
+                               ("bench_GCN", "bench_gcn"), ("bench_GraphSAGE", "bench_graphsage"), ("bench_GIN", "bench_gin")):
         p = os.path.join(a.src, src_name + ".json")
         if os.path.exists(p):
             # the stdout line is compact since round 4; the full record (rooflines of every kernel class, side measurements in
@@ -109,6 +110,8 @@ def main():
             cls = re.sub(r"<.*$", "", k)
             if cls == "features_tiled_kernel":
                 cls = "features_kernel"          # the LDS-tiled form of the same kernel class (bench key "features")
+            if cls == "gat_layer_bf16_2p_kernel":
+                cls = "gat_layer_fused_kernel"   # the two-phase form of the bf16 256 -> 256 instance (bench key "fused")
             cls_acc[cls][0] += (2.0 * fb + wb) * n
             cls_acc[cls][1] += n
         for cls, (tot, n) in cls_acc.items():
