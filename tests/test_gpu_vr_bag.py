@@ -286,6 +286,21 @@ def test_staged_batches_device_mask_fresh_results_and_mixed_nodata(gpu_device):
     third = proc.flush_batch()
     first, second = proc.collect_batch(), proc.collect_batch()
     assert same(single[:4], first) and same(single[4:8], second) and same(single[8:], third)
+    # a grid larger than the slab's initial capacity (131 072 cells) joins a batch that already holds grids: the slab grows, what was
+    # staged before survives; a float64 / non-contiguous depth array is converted on the way in
+    big_d, big_m, big_u = synthetic.synthetic_tile(400, 420, 9, "V1", True)
+    big_d = np.where(big_m, big_d, np.float32(1.0e6)).astype(np.float32)
+    want_big = proc.process_grid(big_d, big_u, (0.5, 0.5))
+    proc.add_to_batch(grids[0][0], grids[0][1], grids[0][2])
+    proc.add_to_batch(np.asfortranarray(big_d.astype(np.float64)), big_u, (0.5, 0.5))
+    proc.add_to_batch(grids[2][0], grids[2][1], grids[2][2])
+    got = proc.flush_batch()
+    assert same([single[0], want_big, single[2]], got) and got[1][0].shape == (400, 420)
+    # mixing grids with and without an uncertainty layer in one batch is refused when queued
+    proc.add_to_batch(grids[0][0], grids[0][1], grids[0][2])
+    with pytest.raises(ValueError, match="uncertainty"):
+        proc.add_to_batch(grids[1][0], None, grids[1][2])
+    proc.flush_batch()
     # an all-invalid grid never enters a batch
     z = proc.add_to_batch(np.full((4, 5), 1.0e6, np.float32), None, (1.0, 1.0))
     assert z is not None and all(float(np.abs(a).max()) == 0.0 and a.shape == (4, 5) for a in z) and not proc.batch_pending
