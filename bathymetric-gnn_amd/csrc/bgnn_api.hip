@@ -199,7 +199,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.ragged_atlas = getenv("BGNN_NO_ATLAS") ? 0 : 1;
     o.fused_front = getenv("BGNN_NO_FUSED_FRONT") ? 0 : 1;
     o.fused_persistent = getenv("BGNN_PERSISTENT") ? 1 : 0;
-    o.bf16_two_phase = getenv("BGNN_NO_TWO_PHASE") ? 0 : 1;
+    o.bf16_two_phase = getenv("BGNN_NO_TWO_PHASE") ? 0 : env_int("BGNN_TWO_PHASE", 1);
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;

@@ -80,7 +80,8 @@ struct BgnnOpts {
   int fused_persistent = 0;  // 1 (opt-in experiment): big uniform batches run the 256 -> 256 exact-f32 fused layer in its persistent
                              // one-workgroup-per-CU form (bit-identical; measured 11.4 ms per launch against 10.15: DESIGN.md)
   int bf16_two_phase = 1;    // matrix_path = bf16: the 256 -> 256 fused layer in its two-phase form (aggregate all slabs to bf16 registers, then
-                             // the GEMM in four column passes: three workgroups per CU; bit-identical to the one-phase instance, 0 selects that)
+                             // the GEMM in four column passes: three workgroups per CU; bit-identical to the one-phase instance, 0 selects that;
+                             // 2: the 256 -> 64 instance in the same form too -- experiment, neutral)
   int fused_front = 1;       // 1: extractor layer 1 runs inside the lin_0 GEMM where that GEMM's W-resident form is used (0: own launch)
   int features_tiled = 1;    // 1: LDS-tiled feature kernel with mirrored-edge slope reuse (K = 8 / 16); 0: thread-per-cell form (bit-identical)
   int ragged_atlas = 1;      // ragged batches: fused layers walk a shelf-packed canvas of the grids (0: per-grid 8x16 blocks)

@@ -1834,11 +1834,11 @@ __global__ __launch_bounds__(256, 1) void gat_layer_persist_kernel(FusedArgs a, 
 //            accumulator registers -> attention dots + bf16 store of those 64 columns, under the next pass's W DMA.
 // ~160 VGPRs and 51 KB of LDS: THREE workgroups per CU.  Per accumulator the MFMAs run in the same k order as in the one-phase
 // kernel, the aggregation / BatchNorm / conversion code is the same: bit-identical results (tests/test_gpu_forward.py).
-template <int K>
+template <int K, int NPASS = 4>
 struct TwoPhaseLds {
   using Geo = FusedGeom<K>;
   using Win = AggWindow<K>;
-  static constexpr int HR = Geo::HR, H = 4, HC = 256, NC = 256;
+  static constexpr int HR = Geo::HR, H = 4, HC = 256, NC = 64 * NPASS;       // NPASS = heads (64 columns each) of the next layer
   static constexpr int SLAB_B = HR * 64;                 // bf16 slab image [HR][32 ch]
   static constexpr int PAD_B = 512;                      // zeros: the k = 16 window's last MFMA reads 8 rows past the image (AggWindow)
   static constexpr int ALPHA_B = 4 * 32 * Win::PITCH;    // four wave-private dense alpha matrices
@@ -1856,11 +1856,11 @@ struct TwoPhaseLds {
   static_assert(3 * BYTES <= 160 * 1024, "three workgroups per CU");
 };
 
-template <int K>
+template <int K, int NPASS = 4>       // NPASS: column passes = heads of the next layer (4: 256 -> 256; 1: 256 -> 64, the last GAT layer's lin)
 __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) {
-  constexpr int NTH = 256, HC = 256, C = 64, H = 4, NC = 256, NSLAB = 8, SPH = 2, NHL = 2;
+  constexpr int NTH = 256, HC = 256, C = 64, H = 4, NC = 64 * NPASS, NT = 2 * NPASS, NSLAB = 8, SPH = 2, NHL = 2;
   using Geo = FusedGeom<K>;
-  using Lds = TwoPhaseLds<K>;
+  using Lds = TwoPhaseLds<K, NPASS>;
   using Win = AggWindow<K>;
   using Off = StencilOffsets<K>;
   constexpr int HR = Geo::HR, HW_ = Geo::HW, RAD = Geo::R;
@@ -2078,14 +2078,14 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
       }
     }
   };
-  // W^T image (hi-only bf16, MFMA A-fragment lane order): k-step st, tile t at (st * 8 + t) KiB.  A pass moves tiles 2 cp, 2 cp + 1
+  // W^T image (hi-only bf16, MFMA A-fragment lane order): k-step st, tile t at (st * NT + t) KiB.  A pass moves tiles 2 cp, 2 cp + 1
   // of all 16 k-steps: 32 pieces of 1 KiB, 8 per wave, to wpass + (st * 2 + tt) KiB.
   auto issue_w = [&](int cp) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int q = j * 4 + wave;                        // piece: st = q >> 1, tt = q & 1
       __builtin_amdgcn_global_load_lds(
-          reinterpret_cast<const void *>(reinterpret_cast<const char *>(a.Wt) + ((q >> 1) * 8 + 2 * cp + (q & 1)) * 1024 + lane * 16),
+          reinterpret_cast<const void *>(reinterpret_cast<const char *>(a.Wt) + ((q >> 1) * NT + 2 * cp + (q & 1)) * 1024 + lane * 16),
           (__attribute__((address_space(3))) void *)(wpass + q * 1024), 16, 0, 0);
     }
   };
@@ -2119,8 +2119,9 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
       // last slab: the image and the alpha matrices are dead on every wave -> phase 2's first W pass and the next layer's
       // att_src | att_dst can be requested NOW (they land in [0, 32 KB) and behind the patches: clear of the scale / shift table the
       // BatchNorm below still reads).  One att piece per wave (waves 2, 3 repeat 0, 1's) so that every wave's VM queue counts alike.
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(((wave & 1) == 0 ? a.att_src : a.att_dst) + lane * 4),
-                                       (__attribute__((address_space(3))) void *)(attl + (wave & 1) * NC), 16, 0, 0);
+      if (lane * 4 < NC)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(((wave & 1) == 0 ? a.att_src : a.att_dst) + lane * 4),
+                                         (__attribute__((address_space(3))) void *)(attl + (wave & 1) * NC), 16, 0, 0);
       issue_w(0);
     }
     f32x4 g[4];
@@ -2157,9 +2158,9 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
   // first pass's barrier also orders every wave's last scale / shift read before the first patch write)
   const uint32_t wfrag = lds_addr(wpass) + lane * 16;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 ps[4], pd[4];
+  f32x2 ps[NPASS], pd[NPASS];
 #pragma unroll
-  for (int hd = 0; hd < 4; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
+  for (int hd = 0; hd < NPASS; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
   const int id = cid[cell];
   constexpr int NSTORE = 4;
   char *prow[NSTORE];
@@ -2200,7 +2201,7 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
       }
     }
     __builtin_amdgcn_s_barrier();                        // every wave has read W(cp)
-    if constexpr (cp + 1 < 4) issue_w(cp + 1);
+    if constexpr (cp + 1 < NPASS) issue_w(cp + 1);
     // epilogue of the pass: head cp of the next layer -- attention dots, bf16 conversion, two tiles side by side through the
     // wave's patch, whole 128-byte row segments out (the one-phase kernel's epilogue, tile pair (2 cp, 2 cp + 1))
 #pragma unroll
@@ -2238,29 +2239,36 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  col_pass(std::integral_constant<int, 0>{}); col_pass(std::integral_constant<int, 1>{});
-  col_pass(std::integral_constant<int, 2>{}); col_pass(std::integral_constant<int, 3>{});
+  col_pass(std::integral_constant<int, 0>{});
+  if constexpr (NPASS == 4) {
+    col_pass(std::integral_constant<int, 1>{}); col_pass(std::integral_constant<int, 2>{}); col_pass(std::integral_constant<int, 3>{});
+  }
+  static_assert(NPASS == 1 || NPASS == 4, "256 -> 64 or 256 -> 256");
   {
-    float srow[4], drow_[4];
+    float srow[NPASS], drow_[NPASS];
 #pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
+    for (int hd = 0; hd < NPASS; ++hd) {
       const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
       srow[hd] = sl + __shfl_xor(sl, 32);
       drow_[hd] = dl + __shfl_xor(dl, 32);
     }
     if (id >= 0 && hl == 0) {
-      float *ao = a.asd_out + (int64_t)id * 8;
-      *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], srow[2], srow[3]);
-      *reinterpret_cast<float4 *>(ao + 4) = make_float4(drow_[0], drow_[1], drow_[2], drow_[3]);
+      float *ao = a.asd_out + (int64_t)id * 2 * NPASS;
+      if constexpr (NPASS == 4) {
+        *reinterpret_cast<float4 *>(ao) = make_float4(srow[0], srow[1], srow[2], srow[3]);
+        *reinterpret_cast<float4 *>(ao + 4) = make_float4(drow_[0], drow_[1], drow_[2], drow_[3]);
+      } else {
+        *reinterpret_cast<float2 *>(ao) = make_float2(srow[0], drow_[0]);
+      }
     }
   }
 }
 
-template <int K>
+template <int K, int NPASS>
 static int launch_two_phase(bgnn_ctx *ctx, const FusedArgs &a) {
-  constexpr size_t lds_bytes = (size_t)TwoPhaseLds<K>::BYTES;
+  constexpr size_t lds_bytes = (size_t)TwoPhaseLds<K, NPASS>::BYTES;
   static std::atomic<uint64_t> configured{0};
-  auto kern = gat_layer_bf16_2p_kernel<K>;
+  auto kern = gat_layer_bf16_2p_kernel<K, NPASS>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
@@ -2371,7 +2379,9 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   }
   // bf16 storage, 256 -> 256: the two-phase form (three workgroups per CU; bit-identical to the one-phase instance)
   if (split == 3 && HC == 256 && NC == 256 && C == 64 && ctx->opts.bf16_two_phase)
-    return g->K == 8 ? launch_two_phase<8>(ctx, a) : g->K == 4 ? launch_two_phase<4>(ctx, a) : launch_two_phase<16>(ctx, a);
+    return g->K == 8 ? launch_two_phase<8, 4>(ctx, a) : g->K == 4 ? launch_two_phase<4, 4>(ctx, a) : launch_two_phase<16, 4>(ctx, a);
+  if (split == 3 && HC == 256 && NC == 64 && C == 64 && ctx->opts.bf16_two_phase >= 2)      // (experiment: the 256 -> 64 instance too)
+    return g->K == 8 ? launch_two_phase<8, 1>(ctx, a) : g->K == 4 ? launch_two_phase<4, 1>(ctx, a) : launch_two_phase<16, 1>(ctx, a);
 #define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
   BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
 #undef BGNN_FUSED_CASE

@@ -932,7 +932,7 @@ def test_bf16_two_phase_instance_is_bit_identical_to_the_one_phase_instance(conn
     ragged = [synthetic.synthetic_tile(h, w, 700 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (9, 31), (50, 50), (3, 3), (26, 8)])]
     _set_matrix_path("bf16")
     outs = {}
-    for two in (1, 0):
+    for two in (1, 0, 2):                                # (2: the 256 -> 64 instance in the two-phase form as well)
         ctx.set_option("bf16_two_phase", two)
         try:
             u = eng.infer_device(hw, res, d_t, m_t, None).clone()
@@ -941,10 +941,11 @@ def test_bf16_two_phase_instance_is_bit_identical_to_the_one_phase_instance(conn
             ctx.set_option("bf16_two_phase", 1)
         outs[two] = (u, rg)
     assert torch.isfinite(outs[1][0]).all() and float(outs[1][0][1].max()) > 0.0
-    assert torch.equal(outs[1][0], outs[0][0])
-    for a, b in zip(outs[1][1], outs[0][1]):
-        for k in ("classification", "confidence", "correction"):
-            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    for other in (0, 2):
+        assert torch.equal(outs[1][0], outs[other][0])
+        for a, b in zip(outs[1][1], outs[other][1]):
+            for k in ("classification", "confidence", "correction"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (other, k)
 
 
 def test_bf16_storage_refuses_what_it_does_not_cover(gpu_device):
