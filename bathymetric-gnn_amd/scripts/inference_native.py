@@ -32,8 +32,7 @@ class _BatchSlot:
     def __init__(self, dev, cells: int = 1 << 17):
         self.dev = dev
         self.cap = 0
-        self.copy = torch.cuda.Stream(dev)               # H2D of the records, D2H of the results: beside the engine's stream
-        self.up, self.down = torch.cuda.Event(), torch.cuda.Event()
+        self.down = torch.cuda.Event()                   # recorded behind the batch's D2H on the engine's stream
         self.mask_h = None                               # pinned uint8 [cap]: only for batches that mix nodata values
         self._grow(cells)
         self.reset()
@@ -46,10 +45,11 @@ class _BatchSlot:
             if self.mask_h is not None:
                 m = torch.empty(cap, dtype=torch.uint8, pin_memory=True); m[:self.n] = self.mask_h[:self.n]; self.mask_h = m
         self.rec_h, self.rec_np = rec_h, rec_h.numpy()
-        self.out_h = torch.empty((3, cap), dtype=torch.float32, pin_memory=True)
+        # (flat: a batch of n cells uses the first 3 n floats as a CONTIGUOUS [3, n] block, so that the results come back in one copy)
+        self.out_h = torch.empty(3 * cap, dtype=torch.float32, pin_memory=True)
         mk = lambda dt, shape: torch.empty(shape, dtype=dt, device=self.dev)
         self.rec_t, self.depth_t, self.unc_t = mk(torch.float32, (cap, 2)), mk(torch.float32, cap), mk(torch.float32, cap)
-        self.mask_t, self.out_t = mk(torch.uint8, cap), mk(torch.float32, (3, cap))
+        self.mask_t, self.out_t = mk(torch.uint8, cap), mk(torch.float32, 3 * cap)
         self.cap = cap
 
     def reset(self):
@@ -220,9 +220,9 @@ class NativeVRProcessor:
         return self._engines[i]
 
     def _launch(self, eng: TileBatchEngine) -> _BatchSlot:
-        """Everything of the queued batch that runs on the GPU, asynchronously: H2D of the record slab (copy stream), unpack +
-        valid mask (``bgnn_vr_unpack``), the fused classification (``bgnn_infer_tiles``), D2H of the three result planes into the
-        slot's pinned buffer (copy stream).  The caller's torch stream is not involved: nothing it does later waits for this."""
+        """Everything of the queued batch that runs on the GPU, asynchronously: H2D of the record slab, unpack + valid mask
+        (``bgnn_vr_unpack``), the fused classification (``bgnn_infer_tiles``), D2H of the three result planes into the slot's
+        pinned buffer.  The caller's torch stream is not involved: nothing it does later waits for this."""
         import ctypes as C
         from .. import runtime as rt
         slot, self._fill, self._batch_node_count = self._fill, None, 0
@@ -230,33 +230,30 @@ class NativeVRProcessor:
         slot.engine = eng
         slot.hw_np = np.array(slot.hw, np.int32).reshape(-1, 2)
         slot.res_np = np.array(slot.res, np.float64).reshape(-1, 2)
-        with torch.cuda.stream(slot.copy):
-            slot.copy.wait_stream(ctx.stream)            # (the device buffers' previous batch is long collected; cheap and explicit)
+        # Everything goes onto the ENGINE's stream, in order -- H2D of the record slab, unpack + mask, the fused classification, D2H of
+        # the results: one stream switch per batch.  (Batches alternate between two engines; a copy stream per slot bought nothing
+        # measurable -- the upload is ~0.5 MB -- and cost two more stream waits and an event per batch on the host.)
+        with torch.cuda.stream(ctx.stream):
             slot.rec_t[:n].copy_(slot.rec_h[:n], non_blocking=True)
             if slot.host_masks:
                 slot.mask_t[:n].copy_(slot.mask_h[:n], non_blocking=True)
-            slot.up.record(slot.copy)
-        ctx.stream.wait_event(slot.up)
-        unc_t = slot.unc_t[:n] if slot.has_unc else None
-        # (host masks -- a batch that mixes nodata values: the kernel's own mask goes to a scratch plane and is not used)
-        mask_out = slot.mask_t[:n]
-        if slot.host_masks:
-            if getattr(slot, "scratch_t", None) is None or slot.scratch_t.numel() < n:
-                slot.scratch_t = torch.empty(slot.cap, dtype=torch.uint8, device=slot.dev)
-            mask_out = slot.scratch_t[:n]
-        rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(slot.rec_t), n, C.c_float(slot.nodata), 0, None, C.c_double(0.0),
-                                        rt.ptr(slot.depth_t), rt.ptr(unc_t), rt.ptr(mask_out), None, None))
-        # (begin=False: the inputs were made on the engine's own stream -- nothing of the caller's torch stream to wait for)
-        eng.infer_device(slot.hw_np, slot.res_np, slot.depth_t[:n], slot.mask_t[:n], unc_t,
-                         out=(slot.out_t[0, :n], slot.out_t[1, :n], slot.out_t[2, :n]), defer_end=True, begin=False)
-        with torch.cuda.stream(slot.copy):
-            slot.copy.wait_stream(ctx.stream)
-            # (three CONTIGUOUS row copies = three plain hipMemcpyAsync.  One strided [3, n] copy_ goes through a temporary and a
-            #  CPU-side at::parallel_for: it is synchronous, and its OpenMP team -- 128 threads on the GPU box, spinning after the
+            unc_t = slot.unc_t[:n] if slot.has_unc else None
+            # (host masks -- a batch that mixes nodata values: the kernel's own mask goes to a scratch plane and is not used)
+            mask_out = slot.mask_t[:n]
+            if slot.host_masks:
+                if getattr(slot, "scratch_t", None) is None or slot.scratch_t.numel() < n:
+                    slot.scratch_t = torch.empty(slot.cap, dtype=torch.uint8, device=slot.dev)
+                mask_out = slot.scratch_t[:n]
+            rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(slot.rec_t), n, C.c_float(slot.nodata), 0, None, C.c_double(0.0),
+                                            rt.ptr(slot.depth_t), rt.ptr(unc_t), rt.ptr(mask_out), None, None))
+            # (begin=False: the inputs were made on the engine's own stream -- nothing of the caller's torch stream to wait for)
+            out_t = slot.out_t[:3 * n].view(3, n)
+            eng.infer_device(slot.hw_np, slot.res_np, slot.depth_t[:n], slot.mask_t[:n], unc_t, out=out_t, defer_end=True, begin=False)
+            # (ONE contiguous copy = one plain hipMemcpyAsync.  A strided [3, n] view of a [3, cap] buffer would go through a temporary
+            #  and a CPU-side at::parallel_for: synchronous, and its OpenMP team -- 128 threads on the GPU box, spinning after the
             #  region -- eats the container's CPU quota: the whole process then stalled ~90 ms at a time, anywhere)
-            for c in range(3):
-                slot.out_h[c, :n].copy_(slot.out_t[c, :n], non_blocking=True)
-            slot.down.record(slot.copy)
+            slot.out_h[:3 * n].copy_(slot.out_t[:3 * n], non_blocking=True)
+            slot.down.record(ctx.stream)
         return slot
 
     def _finish(self, slot: _BatchSlot, copy: bool = True):
@@ -264,7 +261,7 @@ class NativeVRProcessor:
         the results are a FRESH array (one copy per batch); ``copy=False``: a view of the slot's pinned result buffer, valid until
         the next ``submit_batch`` / ``flush_batch`` (the next D2H into that buffer cannot be queued earlier)."""
         slot.down.synchronize()
-        flat = slot.out_h.numpy()[:, :slot.n]
+        flat = slot.out_h.numpy()[:3 * slot.n].reshape(3, slot.n)
         if copy:
             flat = np.array(flat)
         hw = slot.hw
