@@ -200,6 +200,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.fused_front = getenv("BGNN_NO_FUSED_FRONT") ? 0 : 1;
     o.fused_persistent = getenv("BGNN_PERSISTENT") ? 1 : 0;
     o.bf16_two_phase = getenv("BGNN_NO_TWO_PHASE") ? 0 : env_int("BGNN_TWO_PHASE", 1);
+    o.stats_narrow = env_int("BGNN_STATS_NARROW", -1);
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
     o.diag_stamps = getenv("BGNN_FUSED_STAMPS") ? 1 : 0;
@@ -214,7 +215,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
 static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
-      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent}, {"bf16_two_phase", &o.bf16_two_phase},
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent}, {"bf16_two_phase", &o.bf16_two_phase}, {"stats_narrow", &o.stats_narrow},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
@@ -792,13 +793,15 @@ static int validate_opts(const bgnn_graph_opts *o) {
   return BGNN_OK;
 }
 
-static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out, int64_t *n_nodes_copy);
+static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out, int64_t *n_nodes_copy,
+                            float *const *clear_grids = nullptr);
 
 int bgnn_graph_build(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out) {
   return graph_build_impl(ctx, tiles, opts, out, nullptr);
 }
 
-static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out, int64_t *n_nodes_copy) {
+static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_graph_opts *opts, bgnn_graph **out, int64_t *n_nodes_copy,
+                            float *const *clear_grids) {
   BGNN_REQUIRE(ctx && tiles && opts && out, "bgnn_graph_build: NULL argument");
   BGNN_REQUIRE(tiles->n_tiles >= 1, "bgnn_graph_build: n_tiles=%d", tiles->n_tiles);
   BGNN_REQUIRE(tiles->hw && tiles->resolution && tiles->depth && tiles->mask, "bgnn_graph_build: NULL tile array");
@@ -806,6 +809,7 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
   bgnn_graph *g = new bgnn_graph();
   g->ctx = ctx; g->kind = 0; g->n_tiles = tiles->n_tiles; g->d_n_nodes_copy = n_nodes_copy;
+  if (clear_grids) for (int i = 0; i < 3; ++i) g->clear_grids[i] = clear_grids[i];
   g->K = opts->connectivity; g->ED = opts->n_edge_features; g->include_self_loops = opts->include_self_loops ? 1 : 0;
   g->has_unc = tiles->uncertainty ? 1 : 0;
   // feature count (see launch_graph_build for the column rule)
@@ -1363,7 +1367,9 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
                      int64_t *n_nodes_out) {
   BGNN_REQUIRE(ctx && m && tiles && opts, "bgnn_infer_tiles: NULL argument");
   bgnn_graph *g = nullptr;
-  BGNN_TRY(graph_build_impl(ctx, tiles, opts, &g, n_nodes_out));   // (the compaction scan writes the node count there itself)
+  float *const grids[3] = {classification, confidence, correction};
+  // (the compaction scan writes the node count there itself; a ragged batch's canvas fill zero-fills the result grids on its way)
+  BGNN_TRY(graph_build_impl(ctx, tiles, opts, &g, n_nodes_out, grids));
   const int64_t rows = g->row_capacity;
   GridOut go;
   go.cls = classification; go.conf = confidence; go.corr = correction; go.norm_floor = norm_floor;
@@ -1377,7 +1383,7 @@ int bgnn_infer_tiles(bgnn_ctx *ctx, bgnn_model *m, const bgnn_tiles *tiles, cons
     o.confidence = (float *)(o.predicted_class + rows);
     o.correction = m->desc.predict_correction ? o.confidence + rows : nullptr;
     const bool try_fused = fused_heads_available(ctx, g, m);
-    if (try_fused && g->d_atlas) {          // the canvas walk writes valid cells only: clear the grids (fill 0.0) first
+    if (try_fused && g->d_atlas && !g->grids_cleared) {   // the canvas walk writes valid cells only: clear the grids (fill 0.0) first
       const size_t nb = (size_t)g->total_cells * sizeof(float);
       if (classification && confidence == classification + g->total_cells && correction == confidence + g->total_cells) {
         BGNN_HIP_CHECK(hipMemsetAsync(classification, 0, 3 * nb, ctx->stream));      // one [3, cells] block: one fill

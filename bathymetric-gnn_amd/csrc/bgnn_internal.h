@@ -82,6 +82,8 @@ struct BgnnOpts {
   int bf16_two_phase = 1;    // matrix_path = bf16: the 256 -> 256 fused layer in its two-phase form (aggregate all slabs to bf16 registers, then
                              // the GEMM in four column passes: three workgroups per CU; bit-identical to the one-phase instance, 0 selects that;
                              // 2: the 256 -> 64 instance in the same form too -- experiment, neutral)
+  int stats_narrow = -1;     // box statistics with 16 instead of 64 running sums per workgroup (four times the workgroups, a quarter of the
+                             // work between two barriers): -1 picks it when the wide launch would leave most CUs idle; bit-identical
   int fused_front = 1;       // 1: extractor layer 1 runs inside the lin_0 GEMM where that GEMM's W-resident form is used (0: own launch)
   int features_tiled = 1;    // 1: LDS-tiled feature kernel with mirrored-edge slope reuse (K = 8 / 16); 0: thread-per-cell form (bit-identical)
   int ragged_atlas = 1;      // ragged batches: fused layers walk a shelf-packed canvas of the grids (0: per-grid 8x16 blocks)
@@ -215,7 +217,9 @@ struct bgnn_graph {
   float *d_slope = nullptr;           // [rows][K]
   float *d_node_depth = nullptr;      // [rows]
   float4 *d_tile_dist = nullptr;      // [n_tiles]
-  int32_t *d_atlas_tile_of = nullptr; // canvas: grid index of every canvas cell (with d_atlas)
+  int32_t *d_atlas_tile_of = nullptr; // canvas: grid index of every canvas cell that holds a node (with d_atlas; other cells: undefined)
+  float *clear_grids[3] = {nullptr, nullptr, nullptr};   // bgnn_infer_tiles: result grids the canvas fill zero-fills on its way
+  bool grids_cleared = false;
   mutable float *d_eattr = nullptr;   // grid: [rows][K][ED] ; generic: [E][ED]
   int32_t *d_rowptr = nullptr;        // generic only [N+1]
   int32_t *d_edge_perm = nullptr;     // generic only

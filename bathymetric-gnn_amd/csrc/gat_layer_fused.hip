@@ -653,7 +653,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   const int raw_m = node_at(cell_m);
   // whose edge lengths: the block's tile, or (canvas walk) the grid this cell belongs to -- a canvas array read beside the ids
   int tile_m = pos.tile;
-  if (a.tile_of_cell) tile_m = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.tile_of_cell) + (cell_m << 2));
+  if (a.tile_of_cell) {                                 // (only cells that hold a node have an entry: the table is not cleared)
+    const int t_ = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.tile_of_cell) + (cell_m << 2));
+    tile_m = raw_m >= 0 ? t_ : 0;
+  }
   // DMA piece p moves chunk (p * NTH + tid) % CPR of halo row (p * NTH + tid) / CPR: the row advances by NTH / CPR per piece
   static_assert(NTH % CPR == 0, "pieces advance by whole halo rows");
   constexpr int RSTEP = NTH / CPR, RSTEP_R = RSTEP / HW_, RSTEP_C = RSTEP % HW_;
@@ -1908,7 +1911,10 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
   const uint32_t cell_m = cell_index(gr_m, gc_m);
   const int raw_m = node_at(cell_m);
   int tile_m = pos.tile;
-  if (a.tile_of_cell) tile_m = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.tile_of_cell) + (cell_m << 2));
+  if (a.tile_of_cell) {                                 // (only cells that hold a node have an entry: the table is not cleared)
+    const int t_ = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.tile_of_cell) + (cell_m << 2));
+    tile_m = raw_m >= 0 ? t_ : 0;
+  }
   static_assert(NTH % CPR == 0, "pieces advance by whole halo rows");
   constexpr int RSTEP = NTH / CPR, RSTEP_R = RSTEP / HW_, RSTEP_C = RSTEP % HW_;
   int drow[NPIECE], prow_r[NPIECE], prow_c[NPIECE];

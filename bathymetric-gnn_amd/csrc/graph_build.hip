@@ -185,11 +185,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_nodes_kernel(MaskValu
 // block counts the valid cells of all chunks before its own by itself (<= 126 KiB of mask bytes, 16 per load) -- redundant work
 // that is far cheaper than two more dependent launches on an otherwise idle chip.  The last block writes the total.
 constexpr int SCAN_SMALL_BLOCKS = 64;
-__global__ __launch_bounds__(SCAN_THREADS) void scan_small_nodes_kernel(MaskValue val, int64_t n, int32_t *node_id,
-                                                                        int32_t *cell_of_node, int64_t *total, int64_t *total_copy) {
+__device__ __forceinline__ void scan_small_nodes_body(MaskValue val, int64_t n, int32_t *node_id, int32_t *cell_of_node,
+                                                      int64_t *total, int64_t *total_copy, int chunk, int n_chunks) {
   __shared__ int red[SCAN_THREADS / 64];
   __shared__ int off_s;
-  const int64_t before = (int64_t)blockIdx.x * SCAN_CHUNK;            // cells in earlier chunks (a multiple of 16)
+  const int64_t before = (int64_t)chunk * SCAN_CHUNK;                 // cells in earlier chunks (a multiple of 16)
   int c = 0;
   const uint4 *m16 = reinterpret_cast<const uint4 *>(val.mask);
   for (int64_t i = threadIdx.x; i < before / 16; i += SCAN_THREADS) {
@@ -223,10 +223,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_small_nodes_kernel(MaskValu
       }
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) {   // last thread of the last chunk
+  if (chunk == n_chunks - 1 && threadIdx.x == SCAN_THREADS - 1) {         // last thread of the last chunk
     *total = (int64_t)p;
     if (total_copy) *total_copy = (int64_t)p;
   }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_small_nodes_kernel(MaskValue val, int64_t n, int32_t *node_id,
+                                                                        int32_t *cell_of_node, int64_t *total, int64_t *total_copy) {
+  scan_small_nodes_body(val, n, node_id, cell_of_node, total, total_copy, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,32 +253,48 @@ __device__ __forceinline__ void masked_vals(const float *depth, const uint8_t *m
 // these kernels are latency machines: what matters is what sits ON the chain.  Here that is one float64 addition per step
 // and sum: inputs are fetched one chunk ahead by independent, coalesced loads; the step is branch-free (the window's first
 // output is produced by the prologue, every later step is "s += X(l+2) - X(l-3)" with zeros beyond the axis); the / 5.0 of
-// uniform_filter1d and the finalisation's divisions / square root are taken off the chain (independent per element).
-// A single 256 x 256 tile went from 190 + 140 us to ~10 + ~20 us.
+// uniform_filter1d and the finalisation's divisions / square root are taken off the chain (independent per element), and each
+// of the three sums of a row / column has a thread of its own.  What the kernel trace of one 256 x 256 tile showed on the way
+// (rocprofv3, round 4): a prefetched value must not be touched before the barrier (a select on it put the whole load latency
+// back on every chunk); float64 divisions by 5.0 and by the count were most of the instructions between two barriers (now 3 + 3
+// fused operations and one shared reciprocal, bit-identical); 16-wide workgroups put 16 CUs instead of 4 on a single tile.
+// stats_v + stats_h of one tile: 24 + 24 us in the trace before, ~8 + ~5 us for a 50 000-node ragged batch after.
 constexpr int STATV_CH = 16;
 
-// vertical pass: 64 columns per 256-thread workgroup.  Outputs are produced in chunks of 16 rows (l = 1 + chunk + j); the rows
-// that ENTER those windows (l + 2) are loaded one chunk ahead by all four waves (row-major, coalesced) into a double-buffered
-// LDS tile; wave 0 (thread = column) runs the three running sums from LDS and parks the RAW sums (the reader divides by 5.0)
-// in an LDS tile that all four waves then write out.  Nothing but the additions is on the serial chain, and the chain's wave
-// issues no global memory operation inside the loop.
-__global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
-                                                      const uint8_t *mask, double *vs, double *vc, double *vq) {
-  __shared__ float in_d[2][STATV_CH * 64];
-  __shared__ uint8_t in_m[2][STATV_CH * 64];
-  __shared__ double outt[3][STATV_CH * 64];
-  const BgnnTileMeta t = tiles[blockIdx.y];
-  const int c0 = blockIdx.x * 64;
+// x / 5.0, correctly rounded, in three float64 operations instead of the ~11 of a general division (Markstein: with
+// y = RN(1/5) and q = RN(x y), RN(q + (x - 5 q) y) is the correctly rounded quotient).  A non-finite x (only possible under a
+// caller's own mask) gives a non-finite q, which IS the quotient (the correction would turn inf into inf - inf).
+__device__ __forceinline__ double div5(double x) {
+  const double q = x * 0.2;
+  const double r = __builtin_fma(-5.0, q, x);
+  const double c = __builtin_fma(r, 0.2, q);
+  return __builtin_fabs(q) < __builtin_inf() ? c : q;
+}
+
+// vertical pass: COLS columns per 256-thread workgroup (64; 16 when the launch would otherwise leave most CUs idle).  Outputs
+// are produced in chunks of 16 rows (l = 1 + chunk + j); the rows that ENTER those windows (l + 2) are loaded one chunk ahead by
+// all four waves (row-major, coalesced) into a double-buffered LDS tile; the first COLS threads (thread = column) run the three
+// running sums from LDS and park the RAW sums (the reader divides by 5.0) in an LDS tile that all four waves then write out.
+// Nothing but the additions is on the serial chain, and the chain's wave issues no global memory operation inside the loop.
+template <int COLS>
+__device__ __forceinline__ void stats_v_body(const BgnnTileMeta *tiles, const float *depth, const uint8_t *mask, double *vs,
+                                             double *vc, double *vq, int bx, int by) {
+  constexpr int RPW = 256 / COLS, NK = STATV_CH / RPW;  // rows one pass of the workgroup covers; passes per chunk
+  __shared__ float in_d[2][STATV_CH * COLS];
+  __shared__ uint8_t in_m[2][STATV_CH * COLS];
+  __shared__ double outt[3][STATV_CH * COLS];
+  const BgnnTileMeta t = tiles[by];
+  const int c0 = bx * COLS;
   if (c0 >= t.w) return;                               // (uniform)
   const int h = t.h, w = t.w, tid = threadIdx.x;
-  const int lc = tid & 63, lr = tid >> 6;              // loader / writer role: column lc, rows lr + 4k (k < 4) of a chunk
+  const int lc = tid % COLS, lr = tid / COLS;          // loader / writer role: column lc, rows lr + RPW k (k < NK) of a chunk
   const bool col_ok = c0 + lc < w;
   const int64_t base = (int64_t)t.cell_off + c0 + (col_ok ? lc : 0);
-  float pd[STATV_CH / 4]; uint32_t pm[STATV_CH / 4];   // chunk fetched ahead
+  float pd[NK]; uint32_t pm[NK];                       // chunk fetched ahead
   auto fetch = [&](int r0) {                           // rows r0 .. r0 + 15 (rows >= h read row h - 1 and are cleared)
 #pragma unroll
-    for (int k = 0; k < STATV_CH / 4; ++k) {
-      const int r = r0 + lr + 4 * k;
+    for (int k = 0; k < NK; ++k) {
+      const int r = r0 + lr + RPW * k;
       const int64_t o = base + (int64_t)(r < h ? r : h - 1) * w;
       pd[k] = depth[o];
       pm[k] = mask[o];
@@ -281,154 +302,246 @@ __global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles,
     asm volatile("" ::: "memory");                     // every load is issued before anything below
   };
   fetch(3);
-  // wave 0, thread = column: initial window, rows 0..2 in ascending order (rows < 0 contribute nothing) = output 0
-  const bool chain = tid < 64;
-  double hv[5], hc[5], hq[5];                          // hv[k] = X(last entered row - k); X = (value, count, square), 0 if masked
+  // chain role, thread = (sum, column): the first 3 COLS threads each run ONE of the three running sums (value, count, square) of
+  // one column -- one float64 addition per step and thread on the serial chain (three sums in one thread were three times the
+  // instructions between the two barriers).  Initial window: rows 0..2 in ascending order (rows < 0 contribute nothing) = output 0
+  const bool chain = tid < 3 * COLS;
+  const int which = lr;                                // (chain threads: 0 value, 1 count, 2 square)
+  double hx[5];                                        // hx[k] = X(last entered row - k), 0 if masked
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { hv[k] = 0.0; hc[k] = 0.0; hq[k] = 0.0; }
-  double s = 0.0, n = 0.0, q = 0.0;
+  for (int k = 0; k < 5; ++k) hx[k] = 0.0;
+  double s = 0.0;
   if (chain) {
 #pragma unroll
     for (int r = 0; r <= 2; ++r) {
       double a = 0.0, b = 0.0, d = 0.0;
       if (r < h) masked_vals(depth, mask, base + (int64_t)r * w, a, b, d);
-      s += a; n += b; q += d;
-      hv[2 - r] = a; hc[2 - r] = b; hq[2 - r] = d;
+      const double x = which == 0 ? a : which == 1 ? b : d;
+      s += x;
+      hx[2 - r] = x;
     }
-    if (col_ok) { vs[base] = s; vc[base] = n; vq[base] = q; }
+    if (col_ok) (which == 0 ? vs : which == 1 ? vc : vq)[base] = s;
   }
+  // a chunk's sums are stored one iteration late, just before the next prefetch is issued (see stats_h_kernel)
+  double o0[NK], o1[NK], o2[NK]; int64_t oo[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) oo[k] = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (oo[k] >= 0) { vs[oo[k]] = o0[k]; vc[oo[k]] = o1[k]; vq[oo[k]] = o2[k]; }
+  };
   int buf = 0;
   for (int l0 = 1; l0 < h; l0 += STATV_CH, buf ^= 1) {
 #pragma unroll
-    for (int k = 0; k < STATV_CH / 4; ++k) {
-      const int j = lr + 4 * k;
-      in_d[buf][j * 64 + lc] = pd[k];
-      in_m[buf][j * 64 + lc] = (l0 + 2 + j < h && pm[k]) ? (uint8_t)1 : (uint8_t)0;   // entering row l0 + j + 2
+    for (int k = 0; k < NK; ++k) {
+      const int j = lr + RPW * k;
+      in_d[buf][j * COLS + lc] = pd[k];
+      in_m[buf][j * COLS + lc] = (l0 + 2 + j < h && pm[k]) ? (uint8_t)1 : (uint8_t)0;   // entering row l0 + j + 2
     }
+    flush();                                           // the previous chunk's sums
     if (l0 + STATV_CH < h) fetch(l0 + STATV_CH + 2);   // next chunk's loads fly under this chunk's chain
     __syncthreads();
     if (chain) {
+      float xd[STATV_CH]; uint8_t xm[STATV_CH];
+#pragma unroll
+      for (int j = 0; j < STATV_CH; ++j) { xm[j] = in_m[buf][j * COLS + lc]; xd[j] = in_d[buf][j * COLS + lc]; }
+      double o[STATV_CH];
 #pragma unroll
       for (int j = 0; j < STATV_CH; ++j) {
-        const bool on = in_m[buf][j * 64 + tid] != 0;
-        const double d = (double)in_d[buf][j * 64 + tid];
-        const double a1 = on ? d : 0.0, b1 = on ? 1.0 : 0.0, d1 = on ? d * d : 0.0;
-        s += (a1 - hv[4]); n += (b1 - hc[4]); q += (d1 - hq[4]);
+        const double d = (double)xd[j];
+        const double x = xm[j] != 0 ? (which == 0 ? d : which == 1 ? 1.0 : d * d) : 0.0;
+        s += (x - hx[4]);
 #pragma unroll
-        for (int k = 4; k > 0; --k) { hv[k] = hv[k - 1]; hc[k] = hc[k - 1]; hq[k] = hq[k - 1]; }
-        hv[0] = a1; hc[0] = b1; hq[0] = d1;
-        outt[0][j * 64 + tid] = s; outt[1][j * 64 + tid] = n; outt[2][j * 64 + tid] = q;
+        for (int k = 4; k > 0; --k) hx[k] = hx[k - 1];
+        hx[0] = x;
+        o[j] = s;
       }
+#pragma unroll
+      for (int j = 0; j < STATV_CH; ++j) outt[which][j * COLS + lc] = o[j];
     }
     __syncthreads();
-    if (col_ok) {
 #pragma unroll
-      for (int k = 0; k < STATV_CH / 4; ++k) {           // RAW running sums: the / 5.0 of uniform_filter1d is taken by the reader
-        const int j = lr + 4 * k, l = l0 + j;
-        if (l < h) {
-          const int64_t o = base + (int64_t)l * w;
-          vs[o] = outt[0][j * 64 + lc]; vc[o] = outt[1][j * 64 + lc]; vq[o] = outt[2][j * 64 + lc];
-        }
+    for (int k = 0; k < NK; ++k) {                       // RAW running sums: the / 5.0 of uniform_filter1d is taken by the reader
+      const int j = lr + RPW * k, l = l0 + j;
+      oo[k] = -1;
+      if (col_ok && l < h) {
+        oo[k] = base + (int64_t)l * w;
+        o0[k] = outt[0][j * COLS + lc]; o1[k] = outt[1][j * COLS + lc]; o2[k] = outt[2][j * COLS + lc];
       }
     }
   }
+  flush();
+}
+
+template <int COLS>
+__global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
+                                                      const uint8_t *mask, double *vs, double *vc, double *vq) {
+  stats_v_body<COLS>(tiles, depth, mask, vs, vc, vq, blockIdx.x, blockIdx.y);
+}
+
+// Small batches: the compaction scan and the vertical pass read the same inputs and do not depend on each other, so they share
+// ONE launch -- row 0 of the grid scans (chunk = blockIdx.x), the rows above it are the vertical pass of tile blockIdx.y - 1, and
+// for a ragged batch one more row fills the canvas with -1.  Every launch taken off the latency path is its own few microseconds
+// (the scan alone: 8 us for one 256 x 256 tile) plus an inter-kernel gap.
+template <int COLS>
+__global__ __launch_bounds__(256) void stats_v_scan_kernel(const BgnnTileMeta *tiles, const float *depth, const uint8_t *mask,
+                                                           double *vs, double *vc, double *vq, int64_t cells, int n_chunks,
+                                                           int32_t *node_id, int32_t *cell_of_node, int64_t *total,
+                                                           int64_t *total_copy, int4 *canvas, int64_t canvas_q) {
+  static_assert(SCAN_THREADS == 256, "one workgroup shape for all roles");
+  if (blockIdx.y == 0) {
+    if ((int)blockIdx.x < n_chunks)
+      scan_small_nodes_body(MaskValue{mask}, cells, node_id, cell_of_node, total, total_copy, blockIdx.x, n_chunks);
+    return;
+  }
+  if (blockIdx.y == gridDim.y - 1 && canvas) {           // ragged batches, last row: the canvas' node ids start as -1 (16 B a store)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < canvas_q; i += (int64_t)gridDim.x * 256)
+      canvas[i] = make_int4(-1, -1, -1, -1);
+    return;
+  }
+  stats_v_body<COLS>(tiles, depth, mask, vs, vc, vq, blockIdx.x, blockIdx.y - 1);
 }
 
 // finalisation of one cell: (sums / 5.0) * 25.0 -> mean, std in float64, then float32 (graph_construction.py:408-432).  Taken by the
 // horizontal pass as it writes a chunk out (it used to be a launch of its own over three float64 arrays written and read back:
 // 48 B per cell and one launch -- of a dozen per ragged batch -- less)
-__device__ __forceinline__ void stats_finalise(double hs, double hn, double hq2, float *local_mean, float *local_std, int64_t i) {
+__device__ __forceinline__ void stats_finalise(double hs, double hn, double hq2, float &out_mean, float &out_std) {
   // uniform_filter(...) * 25.0   (:408-425)
-  const double sum_vals = (hs / 5.0) * 25.0;
-  const double count = (hn / 5.0) * 25.0;
-  const double sum_sq = (hq2 / 5.0) * 25.0;
+  const double sum_vals = div5(hs) * 25.0;
+  const double count = div5(hn) * 25.0;
+  const double sum_sq = div5(hq2) * 25.0;
   const double safe = count > 1.0 ? count : 1.0;       // np.maximum(count, 1.0)
-  const double mean = sum_vals / safe;
-  const double mean_sq = sum_sq / safe;
+  // two quotients by one divisor in [1, 25]: the refined reciprocal of the float64 division's own expansion (v_rcp_f64 and two
+  // Newton steps) is formed once, each quotient is then q = a y corrected by (a - safe q) y -- the same operations, and the same
+  // bits, as two divisions, minus their range scaling and special-case fix-up, which a divisor in this range never needs
+  // (a non-finite dividend gives a non-finite q, which is the quotient)
+  double y = __builtin_amdgcn_rcp(safe);
+  double e = __builtin_fma(-safe, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-safe, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q1 = sum_vals * y, q2 = sum_sq * y;
+  const double c1 = __builtin_fma(__builtin_fma(-safe, q1, sum_vals), y, q1);
+  const double c2 = __builtin_fma(__builtin_fma(-safe, q2, sum_sq), y, q2);
+  const double mean = __builtin_fabs(q1) < __builtin_inf() ? c1 : q1;
+  const double mean_sq = __builtin_fabs(q2) < __builtin_inf() ? c2 : q2;
   double var = mean_sq - mean * mean;
   var = var > 0.0 ? var : 0.0;                          // np.maximum(variance, 0.0) (NaN -> NaN in numpy; inputs finite)
-  local_mean[i] = (float)mean;
-  local_std[i] = (float)sqrt(var);
+  out_mean = (float)mean;
+  out_std = (float)sqrt(var);
 }
 
 constexpr int STAT_CH = 16;
 
-// horizontal pass: 64 rows per 256-thread workgroup.  Outputs are produced in chunks of 16 columns (l = 1 + chunk + j); the
-// inputs that ENTER those windows (columns l + 2) are loaded row-major one chunk ahead by all four waves (16 lanes x 8 B per
-// row), divided by 5.0 there and handed to the row's thread (wave 0) through a double-buffered LDS tile; the raw horizontal
-// sums go back the same way, so both directions are coalesced and nothing but the additions is left on the serial chain.
+// horizontal pass: ROWS rows per 256-thread workgroup (64; 16 when the launch would otherwise leave most CUs idle).  Outputs are
+// produced in chunks of 16 columns (l = 1 + chunk + j); the inputs that ENTER those windows (columns l + 2) are loaded row-major
+// one chunk ahead by all four waves (16 lanes x 8 B per row), divided by 5.0 there and handed to the row's thread through a
+// double-buffered LDS tile; the raw horizontal sums go back the same way, so both directions are coalesced and nothing but the
+// additions is left on the serial chain.
+template <int ROWS>
 __global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
                                                       const double *vq, float *local_mean, float *local_std) {
   constexpr int P = STAT_CH + 1;                       // pitch in doubles: (34 r) mod 64 banks are distinct over 32 lanes
-  __shared__ double tile[2][3][64 * P];
+  constexpr int NK = ROWS / 16;                        // rows per loader thread
+  __shared__ double tile[2][3][ROWS * P];
   const BgnnTileMeta t = tiles[blockIdx.y];
-  const int r0 = blockIdx.x * 64;
+  const int r0 = blockIdx.x * ROWS;
   if (r0 >= t.h) return;                               // (uniform)
   const int w = t.w, h = t.h, tid = threadIdx.x;
-  const int nrow = h - r0 < 64 ? h - r0 : 64;
+  const int nrow = h - r0 < ROWS ? h - r0 : ROWS;
   const int64_t base0 = (int64_t)t.cell_off + (int64_t)r0 * w;
-  const int lr = tid >> 4, lc = tid & 15;              // loader role: rows lr + 16k (k < 4), column lc of the chunk
-  double pv[4], pc[4], pq[4];                          // chunk fetched ahead
-  auto fetch = [&](int c0) {                           // columns c0 .. c0 + 15 of rows r0 .. r0 + 63 (zero outside the tile)
+  const int lr = tid >> 4, lc = tid & 15;              // loader role: rows lr + 16k (k < NK), column lc of the chunk
+  double pv[NK], pc[NK], pq[NK];                       // chunk fetched ahead
+  auto fetch = [&](int c0) {                           // columns c0 .. c0 + 15 of rows r0 .. r0 + ROWS - 1 (clamped addresses)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int rr = lr + 16 * k, cc = c0 + lc;
       const bool ok = rr < nrow && cc < w;
       const int64_t o = base0 + (int64_t)(ok ? rr : 0) * w + (ok ? cc : 0);
-      const double a = vs[o], b = vc[o], d = vq[o];
-      pv[k] = ok ? a : 0.0; pc[k] = ok ? b : 0.0; pq[k] = ok ? d : 0.0;
+      pv[k] = vs[o]; pc[k] = vc[o]; pq[k] = vq[o];      // raw: the consumer clears what lies outside (any use here would wait for the load)
     }
+    asm volatile("" ::: "memory");                     // every load is issued before anything below
   };
   fetch(3);
-  // wave 0, thread = row: initial window (columns 0..2 ascending; columns < 0 contribute nothing) = output 0
-  const bool chain = tid < 64;
-  const int64_t base = base0 + (int64_t)(tid < nrow ? tid : 0) * w;
-  double hv[5], hc[5], hq[5];                          // hv[k] = X(last entered column - k)
+  // chain role, thread = (sum, row): the first 3 ROWS threads each run ONE of the three running sums of one row (see stats_v_kernel).
+  // Initial window: columns 0..2 ascending (columns < 0 contribute nothing) = output 0, handed to the row's finaliser through LDS
+  const bool chain = tid < 3 * ROWS;
+  const int which = chain ? tid / ROWS : 0, crow = tid % ROWS;
+  double hx[5];                                        // hx[k] = X(last entered column - k)
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { hv[k] = 0.0; hc[k] = 0.0; hq[k] = 0.0; }
-  double s = 0.0, n = 0.0, q = 0.0;
+  for (int k = 0; k < 5; ++k) hx[k] = 0.0;
+  double s = 0.0;
   if (chain) {
+    const double *src = which == 0 ? vs : which == 1 ? vc : vq;
+    const int64_t base = base0 + (int64_t)(crow < nrow ? crow : 0) * w;
 #pragma unroll
     for (int c = 0; c <= 2; ++c) {
-      double a = 0.0, b = 0.0, d = 0.0;
-      if (c < w) { a = vs[base + c] / 5.0; b = vc[base + c] / 5.0; d = vq[base + c] / 5.0; }
-      s += a; n += b; q += d;
-      hv[2 - c] = a; hc[2 - c] = b; hq[2 - c] = d;
+      const double a = c < w ? div5(src[base + c]) : 0.0;
+      s += a;
+      hx[2 - c] = a;
     }
-    if (tid < nrow) stats_finalise(s, n, q, local_mean, local_std, base);
+    tile[1][which][crow * P] = s;                      // (buffer 1 is next written by the loop's second fill, two barriers on)
   }
+  __syncthreads();
+  if (tid < nrow) {
+    float m0, s0;
+    stats_finalise(tile[1][0][tid * P], tile[1][1][tid * P], tile[1][2][tid * P], m0, s0);
+    const int64_t o = base0 + (int64_t)tid * w;
+    local_mean[o] = m0; local_std[o] = s0;
+  }
+  // A chunk's results are stored one iteration late, just before the next prefetch is issued: by the time the loop waits for that
+  // prefetch (vmcnt counts loads and stores in order) the stores ahead of it have had a whole chain to drain -- stored at once,
+  // their write latency was on every chunk's critical path
+  float om[NK], od[NK]; int64_t oo[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) oo[k] = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (oo[k] >= 0) { local_mean[oo[k]] = om[k]; local_std[oo[k]] = od[k]; }
+  };
   int buf = 0;
   for (int l0 = 1; l0 < w; l0 += STAT_CH, buf ^= 1) {
-    double (*tl)[64 * P] = tile[buf];
+    double (*tl)[ROWS * P] = tile[buf];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int o = (lr + 16 * k) * P + lc;
-      tl[0][o] = pv[k] / 5.0; tl[1][o] = pc[k] / 5.0; tl[2][o] = pq[k] / 5.0;
+      const bool ok = lr + 16 * k < nrow && l0 + 2 + lc < w;   // entering column l0 + lc + 2
+      tl[0][o] = ok ? div5(pv[k]) : 0.0; tl[1][o] = ok ? div5(pc[k]) : 0.0; tl[2][o] = ok ? div5(pq[k]) : 0.0;
     }
+    flush();                                           // the previous chunk's results
     if (l0 + STAT_CH < w) fetch(l0 + STAT_CH + 2);     // next chunk's loads fly under this chunk's chain
     __syncthreads();
     if (chain) {
+      double x[STAT_CH];
+#pragma unroll
+      for (int j = 0; j < STAT_CH; ++j) x[j] = tl[which][crow * P + j];
 #pragma unroll
       for (int j = 0; j < STAT_CH; ++j) {              // column l0 + j + 2 enters (zero beyond the row), five entries back leaves
-        const double a1 = tl[0][tid * P + j], b1 = tl[1][tid * P + j], d1 = tl[2][tid * P + j];
-        s += (a1 - hv[4]); n += (b1 - hc[4]); q += (d1 - hq[4]);
+        const double a1 = x[j];
+        s += (a1 - hx[4]);
 #pragma unroll
-        for (int k = 4; k > 0; --k) { hv[k] = hv[k - 1]; hc[k] = hc[k - 1]; hq[k] = hq[k - 1]; }
-        hv[0] = a1; hc[0] = b1; hq[0] = d1;
-        // the thread's own row of the tile is reused for its outputs (nobody else reads it before the barrier)
-        tl[0][tid * P + j] = s; tl[1][tid * P + j] = n; tl[2][tid * P + j] = q;
+        for (int k = 4; k > 0; --k) hx[k] = hx[k - 1];
+        hx[0] = a1;
+        x[j] = s;
       }
+      // the sums go back into the thread's own row of the tile (nobody else reads it before the barrier)
+#pragma unroll
+      for (int j = 0; j < STAT_CH; ++j) tl[which][crow * P + j] = x[j];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                      // write the chunk out row-major: 16 lanes x 8 B per row
+    for (int k = 0; k < NK; ++k) {                     // finalise the chunk row-major (16 lanes x 4 B per row); stored by flush()
       const int rr = lr + 16 * k, cc = l0 + lc;
+      oo[k] = -1;
       if (rr < nrow && cc < w) {
-        const int64_t o = base0 + (int64_t)rr * w + cc;
-        stats_finalise(tl[0][rr * P + lc], tl[1][rr * P + lc], tl[2][rr * P + lc], local_mean, local_std, o);
+        oo[k] = base0 + (int64_t)rr * w + cc;
+        stats_finalise(tl[0][rr * P + lc], tl[1][rr * P + lc], tl[2][rr * P + lc], om[k], od[k]);
       }
     }
   }
+  flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -985,12 +1098,17 @@ static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_
 }
 
 // canvas cell of every grid cell: atlas[(row0 + r) * AW + col0 + c] = node id (gutters / free space stay -1)
-// (atlas_tile: the grid a canvas cell belongs to -- the fused kernels look the grid's edge lengths up by it; cleared to 0 beforehand,
-//  so that every canvas cell holds a valid grid index)
+// (atlas_tile: the grid a canvas cell belongs to -- the fused kernels look the grid's edge lengths up by it, for cells that hold a
+//  node only, so the table needs no clearing.  clear0..2: result grids the canvas walk will write valid cells of -- zero-filled here,
+//  cell by cell, instead of by a fill launch of their own)
 __global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *pos, int atlas_w,
-                                                         const int32_t *node_id, int64_t cells, int32_t *atlas, int32_t *atlas_tile) {
+                                                         const int32_t *node_id, int64_t cells, int32_t *atlas, int32_t *atlas_tile,
+                                                         float *clear0, float *clear1, float *clear2) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= cells) return;
+  if (clear0) clear0[i] = 0.0f;
+  if (clear1) clear1[i] = 0.0f;
+  if (clear2) clear2[i] = 0.0f;
   const int id = node_id[i];
   if (id < 0) return;
   const int t = find_tile(tiles, n_tiles, i);
@@ -1086,28 +1204,12 @@ int ensure_edge_attrs(const bgnn_graph *g) {
 int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, const bgnn_graph_opts *opts) {
   const Stencil st = make_stencil(opts->connectivity);
   const int64_t cells = g->total_cells;
-  // 1. compaction scan
-  {
-    ProfScope ps(ctx, BGNN_K_SCAN);
-    MaskValue mv{tiles->mask};
-    int n_blocks = (int)((cells + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    if (n_blocks <= SCAN_SMALL_BLOCKS && ((uintptr_t)tiles->mask & 15) == 0) {
-      hipLaunchKernelGGL(scan_small_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
-                         g->d_node_id, g->d_cell_of_node, g->d_counts, g->d_n_nodes_copy);
-    } else {
-      int32_t *block_off;
-      BGNN_TRY(run_scan_counts(ctx, mv, cells, &block_off, g->d_counts, g->d_n_nodes_copy));
-      hipLaunchKernelGGL(scan_apply_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
-                         block_off, g->d_node_id, g->d_cell_of_node);
-    }
-  }
-  if (g->d_atlas) {
-    BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas, 0xff, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
-    if (g->d_atlas_tile_of) BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas_tile_of, 0, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(atlas_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles, g->n_tiles,
-                       g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas, g->d_atlas_tile_of);
-  }
-  // 2. box statistics
+  int max_h = 0, max_w = 0;
+  for (auto &t : g->h_tiles) { if (t.h > max_h) max_h = t.h; if (t.w > max_w) max_w = t.w; }
+  // box statistics: 64 running sums per workgroup fill the chip from ~500 workgroups up; below that (a single tile: four workgroups
+  // a pass) the 16-wide instances put four times the CUs to work and leave a quarter of the loads, divisions and stores between barriers
+  const int64_t wide_wgs = (int64_t)((max_h + 63) / 64) * g->n_tiles;
+  const bool narrow = ctx->opts.stats_narrow < 0 ? wide_wgs < 384 : ctx->opts.stats_narrow != 0;
   double *vs, *vc, *vq;
   float *lmean, *lstd;
   {
@@ -1117,14 +1219,55 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     BGNN_TRY(ctx_workspace(ctx, 1, (size_t)cells * sizeof(float) * 2, &p));
     lmean = (float *)p; lstd = lmean + cells;
   }
-  int max_h = 0, max_w = 0;
-  for (auto &t : g->h_tiles) { if (t.h > max_h) max_h = t.h; if (t.w > max_w) max_w = t.w; }
+  // 1. compaction scan (small batches: in the launch of the statistics' vertical pass)
+  const int n_blocks = (int)((cells + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  const bool small_scan = n_blocks <= SCAN_SMALL_BLOCKS && ((uintptr_t)tiles->mask & 15) == 0;
+  const bool scan_with_stats = small_scan && narrow;
+  bool canvas_cleared = false;
+  if (!scan_with_stats) {
+    ProfScope ps(ctx, BGNN_K_SCAN);
+    MaskValue mv{tiles->mask};
+    if (small_scan) {
+      hipLaunchKernelGGL(scan_small_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
+                         g->d_node_id, g->d_cell_of_node, g->d_counts, g->d_n_nodes_copy);
+    } else {
+      int32_t *block_off;
+      BGNN_TRY(run_scan_counts(ctx, mv, cells, &block_off, g->d_counts, g->d_n_nodes_copy));
+      hipLaunchKernelGGL(scan_apply_nodes_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, mv, cells,
+                         block_off, g->d_node_id, g->d_cell_of_node);
+    }
+  } else {
+    ProfScope ps(ctx, BGNN_K_STATS);
+    const int gx = (max_w + 15) / 16 > n_blocks ? (max_w + 15) / 16 : n_blocks;
+    const int64_t canvas_cells = g->d_atlas ? (int64_t)g->atlas_h * g->atlas_w : 0;
+    canvas_cleared = g->d_atlas && canvas_cells % 4 == 0 && ((uintptr_t)g->d_atlas & 15) == 0;
+    hipLaunchKernelGGL(stats_v_scan_kernel<16>, dim3(gx, g->n_tiles + 1 + (canvas_cleared ? 1 : 0)), dim3(256), 0, ctx->stream,
+                       g->d_tiles, tiles->depth, tiles->mask, vs, vc, vq, cells, n_blocks, g->d_node_id, g->d_cell_of_node,
+                       g->d_counts, g->d_n_nodes_copy, canvas_cleared ? (int4 *)g->d_atlas : (int4 *)nullptr, canvas_cells / 4);
+  }
+  if (g->d_atlas) {
+    if (!canvas_cleared)
+      BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas, 0xff, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(atlas_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles, g->n_tiles,
+                       g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas, g->d_atlas_tile_of, g->clear_grids[0],
+                       g->clear_grids[1], g->clear_grids[2]);
+    g->grids_cleared = true;
+  }
+  // 2. box statistics
   {
     ProfScope ps(ctx, BGNN_K_STATS);
-    hipLaunchKernelGGL(stats_v_kernel, dim3((max_w + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
-                       tiles->depth, tiles->mask, vs, vc, vq);
-    hipLaunchKernelGGL(stats_h_kernel, dim3((max_h + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
-                       vs, vc, vq, lmean, lstd);
+    if (narrow) {
+      if (!scan_with_stats)
+        hipLaunchKernelGGL(stats_v_kernel<16>, dim3((max_w + 15) / 16, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+                           tiles->depth, tiles->mask, vs, vc, vq);
+      hipLaunchKernelGGL(stats_h_kernel<16>, dim3((max_h + 15) / 16, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+                         vs, vc, vq, lmean, lstd);
+    } else {
+      hipLaunchKernelGGL(stats_v_kernel<64>, dim3((max_w + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+                         tiles->depth, tiles->mask, vs, vc, vq);
+      hipLaunchKernelGGL(stats_h_kernel<64>, dim3((max_h + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+                         vs, vc, vq, lmean, lstd);
+    }
   }
   // 3. features + neighbour table + edge attributes
   {

@@ -270,3 +270,43 @@ def test_tiled_feature_kernel_is_bit_identical_to_the_cell_kernel(conn, gpu_devi
     ea = outs[2][0][1]
     zero = ea[:, 1] == 0
     assert int(zero.sum()) > 0 and bool((ea[zero, 2].view(torch.int32) == 0).all())
+
+
+def test_box_statistics_forms_agree_bit_for_bit_and_with_the_oracle(gpu_device):
+    """The 5 x 5 box statistics divide by 5.0 with a three-operation exact quotient and share one refined reciprocal between the
+    two quotients by the count; the 16-wide instances (option stats_narrow = 1, picked for small launches) regroup the same
+    running sums.  All of that must leave local_mean / local_std bit-identical: narrow == wide on every input (non-finite depths
+    inside the mask included -- they take the general division), and both == the float64 oracle (scipy's uniform_filter order)
+    on finite inputs spanning twelve decades of depth."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    ctx = rt.get_context(gpu_device)
+    rng = np.random.default_rng(11)
+    feats = ["depth", "local_mean", "local_std"]
+    gb = GraphBuilder(node_features=feats, device=gpu_device)
+    cases = []
+    for (h, w), scale in [((256, 256), 1.0), ((50, 47), 1e-4), ((19, 130), 3.0e4), ((3, 3), 1.0), ((70, 5), 977.0), ((131, 66), 1e-7)]:
+        d, m, _ = synthetic.synthetic_tile(h, w, int(rng.integers(1 << 30)), "V1" if min(h, w) >= 16 else "V0")
+        d = (d.astype(np.float64) * scale).astype(np.float32)
+        d.flat[rng.integers(0, h * w, size=max(1, h * w // 40))] *= np.float32(1.0e3)     # outliers: cancelling variances
+        cases.append((d, m.copy(), True))
+    d, m, _ = synthetic.synthetic_tile(90, 200, 3, "V1")
+    d = d.copy(); m = m.copy()
+    ii = rng.integers(0, d.size, size=(3, 60))
+    d.flat[ii[0]] = np.inf; d.flat[ii[1]] = -np.inf; d.flat[ii[2]] = np.nan
+    m.flat[ii.ravel()] = True
+    cases.append((d, m, False))                                                           # identity of the two forms only
+    outs = {}
+    for narrow in (0, 1):
+        with ctx.options(stats_narrow=narrow):
+            per = [gb.build_graph(d, m, None, (0.5, 0.5)).x.clone() for d, m, _ in cases]
+            per.append(gb.build_graphs([c[0] for c in cases], [c[1] for c in cases], None, [(0.5, 0.5)] * len(cases)).x.clone())
+            outs[narrow] = per
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for (d, m, finite), x in zip(cases, outs[1]):
+        if not finite:
+            continue
+        o = graph_cpu.build_graph(d, m, None, (0.5, 0.5), node_feature_names=feats)
+        _check_x(x.cpu().numpy(), o.x, feats)
+        assert ulp_diff_f32(x.cpu().numpy()[:, 1], o.x[:, 1]).max(initial=0) == 0       # local_mean: 0 ulp
