@@ -258,7 +258,8 @@ __device__ __forceinline__ void masked_vals(const float *depth, const uint8_t *m
 // (rocprofv3, round 4): a prefetched value must not be touched before the barrier (a select on it put the whole load latency
 // back on every chunk); float64 divisions by 5.0 and by the count were most of the instructions between two barriers (now 3 + 3
 // fused operations and one shared reciprocal, bit-identical); 16-wide workgroups put 16 CUs instead of 4 on a single tile.
-// stats_v + stats_h of one tile: 24 + 24 us in the trace before, ~8 + ~5 us for a 50 000-node ragged batch after.
+// stats_v + stats_h of one 256 x 256 tile in the trace: 24 + 24 us before, 15 (with the scan in the same launch) + 12 us after;
+// ~8 + ~5 us for a 50 000-node ragged batch.
 constexpr int STATV_CH = 16;
 
 // x / 5.0, correctly rounded, in three float64 operations instead of the ~11 of a general division (Markstein: with
@@ -271,47 +272,80 @@ __device__ __forceinline__ double div5(double x) {
   return __builtin_fabs(q) < __builtin_inf() ? c : q;
 }
 
-// vertical pass: COLS columns per 256-thread workgroup (64; 16 when the launch would otherwise leave most CUs idle).  Outputs
-// are produced in chunks of 16 rows (l = 1 + chunk + j); the rows that ENTER those windows (l + 2) are loaded one chunk ahead by
-// all four waves (row-major, coalesced) into a double-buffered LDS tile; the first COLS threads (thread = column) run the three
-// running sums from LDS and park the RAW sums (the reader divides by 5.0) in an LDS tile that all four waves then write out.
-// Nothing but the additions is on the serial chain, and the chain's wave issues no global memory operation inside the loop.
+// Both passes are software pipelines of two roles with ONE barrier per chunk of 16 outputs:
+//   workers (threads 0..255, four waves): fetch chunk i + 2 from global memory, hand chunk i + 1 to the chain through LDS, and take
+//     chunk i - 1's sums back out (the horizontal pass finalises them: divisions, square root) -- stored one chunk later still,
+//     so that no wait ever sees a young store (vmcnt counts loads and stores in order);
+//   chain (the waves after them, thread = (sum, row or column)): run chunk i's additions, one float64 sum per thread.
+// The chain wave's critical path is 16 dependent additions and their LDS traffic; everything else happens beside it.
+constexpr int stats_threads(int lanes) { return 256 + (3 * lanes + 63) / 64 * 64; }
+
+// vertical pass: COLS columns per workgroup (64; 16 when the launch would otherwise leave most CUs idle).  Outputs are produced in
+// chunks of 16 rows (l = 1 + 16 i + j); the rows that ENTER those windows (l + 2) are loaded row-major (coalesced) by the workers;
+// the chain parks the RAW sums (the reader divides by 5.0) in an LDS tile that the workers write out.
 template <int COLS>
 __device__ __forceinline__ void stats_v_body(const BgnnTileMeta *tiles, const float *depth, const uint8_t *mask, double *vs,
                                              double *vc, double *vq, int bx, int by) {
-  constexpr int RPW = 256 / COLS, NK = STATV_CH / RPW;  // rows one pass of the workgroup covers; passes per chunk
+  constexpr int RPW = 256 / COLS, NK = STATV_CH / RPW;  // rows one pass of the workers covers; passes per chunk
   __shared__ float in_d[2][STATV_CH * COLS];
   __shared__ uint8_t in_m[2][STATV_CH * COLS];
-  __shared__ double outt[3][STATV_CH * COLS];
+  __shared__ double outt[2][3][STATV_CH * COLS];
   const BgnnTileMeta t = tiles[by];
   const int c0 = bx * COLS;
   if (c0 >= t.w) return;                               // (uniform)
   const int h = t.h, w = t.w, tid = threadIdx.x;
-  const int lc = tid % COLS, lr = tid / COLS;          // loader / writer role: column lc, rows lr + RPW k (k < NK) of a chunk
+  const bool worker = tid < 256;
+  const int lc = tid % COLS, lr = tid / COLS;          // workers: column lc, rows lr + RPW k (k < NK) of a chunk
+  const int which = lr - RPW;                          // chain threads: 0 value, 1 count, 2 square (column lc)
+  const bool chain = !worker && which < 3;
   const bool col_ok = c0 + lc < w;
   const int64_t base = (int64_t)t.cell_off + c0 + (col_ok ? lc : 0);
+  const int nch = (h - 1 + STATV_CH - 1) / STATV_CH;   // chunk i: outputs l = 1 + 16 i + j
   float pd[NK]; uint32_t pm[NK];                       // chunk fetched ahead
-  auto fetch = [&](int r0) {                           // rows r0 .. r0 + 15 (rows >= h read row h - 1 and are cleared)
+  auto fetch = [&](int i) {                            // the rows entering chunk i (rows >= h read row h - 1 and are cleared)
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      const int r = r0 + lr + RPW * k;
+      const int r = 3 + STATV_CH * i + lr + RPW * k;
       const int64_t o = base + (int64_t)(r < h ? r : h - 1) * w;
       pd[k] = depth[o];
       pm[k] = mask[o];
     }
-    asm volatile("" ::: "memory");                     // every load is issued before anything below
+    asm volatile("" ::: "memory");                     // every load is issued before anything below (and none is touched before its fill)
   };
-  fetch(3);
-  // chain role, thread = (sum, column): the first 3 COLS threads each run ONE of the three running sums (value, count, square) of
-  // one column -- one float64 addition per step and thread on the serial chain (three sums in one thread were three times the
-  // instructions between the two barriers).  Initial window: rows 0..2 in ascending order (rows < 0 contribute nothing) = output 0
-  const bool chain = tid < 3 * COLS;
-  const int which = lr;                                // (chain threads: 0 value, 1 count, 2 square)
-  double hx[5];                                        // hx[k] = X(last entered row - k), 0 if masked
+  auto fill = [&](int i) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int j = lr + RPW * k;
+      in_d[i & 1][j * COLS + lc] = pd[k];
+      in_m[i & 1][j * COLS + lc] = (3 + STATV_CH * i + j < h && pm[k]) ? (uint8_t)1 : (uint8_t)0;
+    }
+  };
+  double o0[NK], o1[NK], o2[NK]; int64_t oo[NK];       // sums taken back out, stored by the next flush()
+#pragma unroll
+  for (int k = 0; k < NK; ++k) oo[k] = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (oo[k] >= 0) { vs[oo[k]] = o0[k]; vc[oo[k]] = o1[k]; vq[oo[k]] = o2[k]; oo[k] = -1; }
+  };
+  auto collect = [&](int i) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int j = lr + RPW * k, l = 1 + STATV_CH * i + j;
+      if (col_ok && l < h) {
+        oo[k] = base + (int64_t)l * w;
+        o0[k] = outt[i & 1][0][j * COLS + lc]; o1[k] = outt[i & 1][1][j * COLS + lc]; o2[k] = outt[i & 1][2][j * COLS + lc];
+      }
+    }
+  };
+  double hx[5];                                        // chain: hx[k] = X(last entered row - k), 0 if masked
 #pragma unroll
   for (int k = 0; k < 5; ++k) hx[k] = 0.0;
   double s = 0.0;
-  if (chain) {
+  if (worker) {
+    if (nch > 0) { fetch(0); fill(0); }
+    if (nch > 1) fetch(1);
+  } else if (chain) {                                  // initial window: rows 0..2 in ascending order (rows < 0 contribute nothing) = output 0
 #pragma unroll
     for (int r = 0; r <= 2; ++r) {
       double a = 0.0, b = 0.0, d = 0.0;
@@ -322,33 +356,20 @@ __device__ __forceinline__ void stats_v_body(const BgnnTileMeta *tiles, const fl
     }
     if (col_ok) (which == 0 ? vs : which == 1 ? vc : vq)[base] = s;
   }
-  // a chunk's sums are stored one iteration late, just before the next prefetch is issued (see stats_h_kernel)
-  double o0[NK], o1[NK], o2[NK]; int64_t oo[NK];
-#pragma unroll
-  for (int k = 0; k < NK; ++k) oo[k] = -1;
-  auto flush = [&]() {
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-      if (oo[k] >= 0) { vs[oo[k]] = o0[k]; vc[oo[k]] = o1[k]; vq[oo[k]] = o2[k]; }
-  };
-  int buf = 0;
-  for (int l0 = 1; l0 < h; l0 += STATV_CH, buf ^= 1) {
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int j = lr + RPW * k;
-      in_d[buf][j * COLS + lc] = pd[k];
-      in_m[buf][j * COLS + lc] = (l0 + 2 + j < h && pm[k]) ? (uint8_t)1 : (uint8_t)0;   // entering row l0 + j + 2
-    }
-    flush();                                           // the previous chunk's sums
-    if (l0 + STATV_CH < h) fetch(l0 + STATV_CH + 2);   // next chunk's loads fly under this chunk's chain
-    __syncthreads();
-    if (chain) {
+  __syncthreads();
+  for (int i = 0; i <= nch; ++i) {
+    if (worker) {
+      if (i + 1 < nch) fill(i + 1);
+      flush();                                         // chunk i - 2
+      if (i + 2 < nch) fetch(i + 2);
+      if (i >= 1) collect(i - 1);
+    } else if (chain && i < nch) {
       float xd[STATV_CH]; uint8_t xm[STATV_CH];
 #pragma unroll
-      for (int j = 0; j < STATV_CH; ++j) { xm[j] = in_m[buf][j * COLS + lc]; xd[j] = in_d[buf][j * COLS + lc]; }
+      for (int j = 0; j < STATV_CH; ++j) { xm[j] = in_m[i & 1][j * COLS + lc]; xd[j] = in_d[i & 1][j * COLS + lc]; }
       double o[STATV_CH];
 #pragma unroll
-      for (int j = 0; j < STATV_CH; ++j) {
+      for (int j = 0; j < STATV_CH; ++j) {               // row l + 2 enters (zero beyond the column), five entries back leaves
         const double d = (double)xd[j];
         const double x = xm[j] != 0 ? (which == 0 ? d : which == 1 ? 1.0 : d * d) : 0.0;
         s += (x - hx[4]);
@@ -358,25 +379,16 @@ __device__ __forceinline__ void stats_v_body(const BgnnTileMeta *tiles, const fl
         o[j] = s;
       }
 #pragma unroll
-      for (int j = 0; j < STATV_CH; ++j) outt[which][j * COLS + lc] = o[j];
+      for (int j = 0; j < STATV_CH; ++j) outt[i & 1][which][j * COLS + lc] = o[j];
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {                       // RAW running sums: the / 5.0 of uniform_filter1d is taken by the reader
-      const int j = lr + RPW * k, l = l0 + j;
-      oo[k] = -1;
-      if (col_ok && l < h) {
-        oo[k] = base + (int64_t)l * w;
-        o0[k] = outt[0][j * COLS + lc]; o1[k] = outt[1][j * COLS + lc]; o2[k] = outt[2][j * COLS + lc];
-      }
-    }
   }
-  flush();
+  if (worker) flush();
 }
 
 template <int COLS>
-__global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
-                                                      const uint8_t *mask, double *vs, double *vc, double *vq) {
+__global__ __launch_bounds__(stats_threads(COLS)) void stats_v_kernel(const BgnnTileMeta *tiles, const float *depth,
+                                                                      const uint8_t *mask, double *vs, double *vc, double *vq) {
   stats_v_body<COLS>(tiles, depth, mask, vs, vc, vq, blockIdx.x, blockIdx.y);
 }
 
@@ -385,11 +397,14 @@ __global__ __launch_bounds__(256) void stats_v_kernel(const BgnnTileMeta *tiles,
 // for a ragged batch one more row fills the canvas with -1.  Every launch taken off the latency path is its own few microseconds
 // (the scan alone: 8 us for one 256 x 256 tile) plus an inter-kernel gap.
 template <int COLS>
-__global__ __launch_bounds__(256) void stats_v_scan_kernel(const BgnnTileMeta *tiles, const float *depth, const uint8_t *mask,
+__global__ __launch_bounds__(stats_threads(COLS)) void stats_v_scan_kernel(const BgnnTileMeta *tiles, const float *depth, const uint8_t *mask,
                                                            double *vs, double *vc, double *vq, int64_t cells, int n_chunks,
                                                            int32_t *node_id, int32_t *cell_of_node, int64_t *total,
                                                            int64_t *total_copy, int4 *canvas, int64_t canvas_q) {
-  static_assert(SCAN_THREADS == 256, "one workgroup shape for all roles");
+  static_assert(SCAN_THREADS == 256, "the scan and the canvas fill are work of the first four waves");
+  if (blockIdx.y == 0 || (blockIdx.y == gridDim.y - 1 && canvas)) {
+    if (threadIdx.x >= 256) return;                      // (whole waves: a finished wave does not hold a barrier up)
+  }
   if (blockIdx.y == 0) {
     if ((int)blockIdx.x < n_chunks)
       scan_small_nodes_body(MaskValue{mask}, cells, node_id, cell_of_node, total, total_copy, blockIdx.x, n_chunks);
@@ -434,45 +449,77 @@ __device__ __forceinline__ void stats_finalise(double hs, double hn, double hq2,
 
 constexpr int STAT_CH = 16;
 
-// horizontal pass: ROWS rows per 256-thread workgroup (64; 16 when the launch would otherwise leave most CUs idle).  Outputs are
-// produced in chunks of 16 columns (l = 1 + chunk + j); the inputs that ENTER those windows (columns l + 2) are loaded row-major
-// one chunk ahead by all four waves (16 lanes x 8 B per row), divided by 5.0 there and handed to the row's thread through a
-// double-buffered LDS tile; the raw horizontal sums go back the same way, so both directions are coalesced and nothing but the
+// horizontal pass: ROWS rows per workgroup (64; 16 when the launch would otherwise leave most CUs idle).  Outputs are produced in
+// chunks of 16 columns (l = 1 + 16 i + j); the inputs that ENTER those windows (columns l + 2) are loaded row-major by the workers
+// (16 lanes x 8 B per row), divided by 5.0 there and handed to the chain through a triple-buffered LDS tile (chunk i + 1 being
+// filled, chunk i being summed in place, chunk i - 1 being finalised), so both directions are coalesced and nothing but the
 // additions is left on the serial chain.
 template <int ROWS>
-__global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
-                                                      const double *vq, float *local_mean, float *local_std) {
+__global__ __launch_bounds__(stats_threads(ROWS)) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
+                                                                      const double *vq, float *local_mean, float *local_std) {
   constexpr int P = STAT_CH + 1;                       // pitch in doubles: (34 r) mod 64 banks are distinct over 32 lanes
-  constexpr int NK = ROWS / 16;                        // rows per loader thread
-  __shared__ double tile[2][3][ROWS * P];
+  constexpr int NK = ROWS / 16;                        // rows per worker thread
+  __shared__ double tile[3][3][ROWS * P];
+  __shared__ double first[3][ROWS];
   const BgnnTileMeta t = tiles[blockIdx.y];
   const int r0 = blockIdx.x * ROWS;
   if (r0 >= t.h) return;                               // (uniform)
   const int w = t.w, h = t.h, tid = threadIdx.x;
   const int nrow = h - r0 < ROWS ? h - r0 : ROWS;
   const int64_t base0 = (int64_t)t.cell_off + (int64_t)r0 * w;
-  const int lr = tid >> 4, lc = tid & 15;              // loader role: rows lr + 16k (k < NK), column lc of the chunk
+  const bool worker = tid < 256;
+  const int lr = tid >> 4, lc = tid & 15;              // workers: rows lr + 16k (k < NK), column lc of the chunk
+  const int ct = tid - 256;                            // chain threads: sum ct / ROWS of row ct % ROWS
+  const bool chain = !worker && ct < 3 * ROWS;
+  const int which = chain ? ct / ROWS : 0, crow = chain ? ct % ROWS : 0;
+  const int nch = (w - 1 + STAT_CH - 1) / STAT_CH;     // chunk i: outputs l = 1 + 16 i + j
   double pv[NK], pc[NK], pq[NK];                       // chunk fetched ahead
-  auto fetch = [&](int c0) {                           // columns c0 .. c0 + 15 of rows r0 .. r0 + ROWS - 1 (clamped addresses)
+  auto fetch = [&](int i) {                            // the columns entering chunk i, rows r0 .. r0 + ROWS - 1 (clamped addresses)
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      const int rr = lr + 16 * k, cc = c0 + lc;
+      const int rr = lr + 16 * k, cc = 3 + STAT_CH * i + lc;
       const bool ok = rr < nrow && cc < w;
       const int64_t o = base0 + (int64_t)(ok ? rr : 0) * w + (ok ? cc : 0);
-      pv[k] = vs[o]; pc[k] = vc[o]; pq[k] = vq[o];      // raw: the consumer clears what lies outside (any use here would wait for the load)
+      pv[k] = vs[o]; pc[k] = vc[o]; pq[k] = vq[o];      // raw: fill() clears what lies outside (any use here would wait for the load)
     }
     asm volatile("" ::: "memory");                     // every load is issued before anything below
   };
-  fetch(3);
-  // chain role, thread = (sum, row): the first 3 ROWS threads each run ONE of the three running sums of one row (see stats_v_kernel).
-  // Initial window: columns 0..2 ascending (columns < 0 contribute nothing) = output 0, handed to the row's finaliser through LDS
-  const bool chain = tid < 3 * ROWS;
-  const int which = chain ? tid / ROWS : 0, crow = tid % ROWS;
-  double hx[5];                                        // hx[k] = X(last entered column - k)
+  auto fill = [&](int i) {
+    double (*tl)[ROWS * P] = tile[i % 3];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int o = (lr + 16 * k) * P + lc;
+      const bool ok = lr + 16 * k < nrow && 3 + STAT_CH * i + lc < w;
+      tl[0][o] = ok ? div5(pv[k]) : 0.0; tl[1][o] = ok ? div5(pc[k]) : 0.0; tl[2][o] = ok ? div5(pq[k]) : 0.0;
+    }
+  };
+  float om[NK], od[NK]; int64_t oo[NK];                // results finalised, stored by the next flush()
+#pragma unroll
+  for (int k = 0; k < NK; ++k) oo[k] = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (oo[k] >= 0) { local_mean[oo[k]] = om[k]; local_std[oo[k]] = od[k]; oo[k] = -1; }
+  };
+  auto finalise = [&](int i) {                         // row-major: 16 lanes x 4 B per row
+    double (*tl)[ROWS * P] = tile[i % 3];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int rr = lr + 16 * k, cc = 1 + STAT_CH * i + lc;
+      if (rr < nrow && cc < w) {
+        oo[k] = base0 + (int64_t)rr * w + cc;
+        stats_finalise(tl[0][rr * P + lc], tl[1][rr * P + lc], tl[2][rr * P + lc], om[k], od[k]);
+      }
+    }
+  };
+  double hx[5];                                        // chain: hx[k] = X(last entered column - k)
 #pragma unroll
   for (int k = 0; k < 5; ++k) hx[k] = 0.0;
   double s = 0.0;
-  if (chain) {
+  if (worker) {
+    if (nch > 0) { fetch(0); fill(0); }
+    if (nch > 1) fetch(1);
+  } else if (chain) {                                  // initial window: columns 0..2 ascending (columns < 0 contribute nothing) = output 0
     const double *src = which == 0 ? vs : which == 1 ? vc : vq;
     const int64_t base = base0 + (int64_t)(crow < nrow ? crow : 0) * w;
 #pragma unroll
@@ -481,44 +528,28 @@ __global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles,
       s += a;
       hx[2 - c] = a;
     }
-    tile[1][which][crow * P] = s;                      // (buffer 1 is next written by the loop's second fill, two barriers on)
+    first[which][crow] = s;
   }
   __syncthreads();
-  if (tid < nrow) {
+  if (tid < nrow) {                                    // output 0 of every row
     float m0, s0;
-    stats_finalise(tile[1][0][tid * P], tile[1][1][tid * P], tile[1][2][tid * P], m0, s0);
+    stats_finalise(first[0][tid], first[1][tid], first[2][tid], m0, s0);
     const int64_t o = base0 + (int64_t)tid * w;
     local_mean[o] = m0; local_std[o] = s0;
   }
-  // A chunk's results are stored one iteration late, just before the next prefetch is issued: by the time the loop waits for that
-  // prefetch (vmcnt counts loads and stores in order) the stores ahead of it have had a whole chain to drain -- stored at once,
-  // their write latency was on every chunk's critical path
-  float om[NK], od[NK]; int64_t oo[NK];
-#pragma unroll
-  for (int k = 0; k < NK; ++k) oo[k] = -1;
-  auto flush = [&]() {
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-      if (oo[k] >= 0) { local_mean[oo[k]] = om[k]; local_std[oo[k]] = od[k]; }
-  };
-  int buf = 0;
-  for (int l0 = 1; l0 < w; l0 += STAT_CH, buf ^= 1) {
-    double (*tl)[ROWS * P] = tile[buf];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int o = (lr + 16 * k) * P + lc;
-      const bool ok = lr + 16 * k < nrow && l0 + 2 + lc < w;   // entering column l0 + lc + 2
-      tl[0][o] = ok ? div5(pv[k]) : 0.0; tl[1][o] = ok ? div5(pc[k]) : 0.0; tl[2][o] = ok ? div5(pq[k]) : 0.0;
-    }
-    flush();                                           // the previous chunk's results
-    if (l0 + STAT_CH < w) fetch(l0 + STAT_CH + 2);     // next chunk's loads fly under this chunk's chain
-    __syncthreads();
-    if (chain) {
+  for (int i = 0; i <= nch; ++i) {
+    if (worker) {
+      if (i + 1 < nch) fill(i + 1);
+      flush();                                         // chunk i - 2
+      if (i + 2 < nch) fetch(i + 2);
+      if (i >= 1) finalise(i - 1);
+    } else if (chain && i < nch) {
+      double (*tl)[ROWS * P] = tile[i % 3];
       double x[STAT_CH];
 #pragma unroll
       for (int j = 0; j < STAT_CH; ++j) x[j] = tl[which][crow * P + j];
 #pragma unroll
-      for (int j = 0; j < STAT_CH; ++j) {              // column l0 + j + 2 enters (zero beyond the row), five entries back leaves
+      for (int j = 0; j < STAT_CH; ++j) {              // column l + 2 enters (zero beyond the row), five entries back leaves
         const double a1 = x[j];
         s += (a1 - hx[4]);
 #pragma unroll
@@ -526,22 +557,12 @@ __global__ __launch_bounds__(256) void stats_h_kernel(const BgnnTileMeta *tiles,
         hx[0] = a1;
         x[j] = s;
       }
-      // the sums go back into the thread's own row of the tile (nobody else reads it before the barrier)
 #pragma unroll
-      for (int j = 0; j < STAT_CH; ++j) tl[which][crow * P + j] = x[j];
+      for (int j = 0; j < STAT_CH; ++j) tl[which][crow * P + j] = x[j];   // in place: the finaliser reads it after the barrier
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {                     // finalise the chunk row-major (16 lanes x 4 B per row); stored by flush()
-      const int rr = lr + 16 * k, cc = l0 + lc;
-      oo[k] = -1;
-      if (rr < nrow && cc < w) {
-        oo[k] = base0 + (int64_t)rr * w + cc;
-        stats_finalise(tl[0][rr * P + lc], tl[1][rr * P + lc], tl[2][rr * P + lc], om[k], od[k]);
-      }
-    }
   }
-  flush();
+  if (worker) flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1241,7 +1262,7 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     const int gx = (max_w + 15) / 16 > n_blocks ? (max_w + 15) / 16 : n_blocks;
     const int64_t canvas_cells = g->d_atlas ? (int64_t)g->atlas_h * g->atlas_w : 0;
     canvas_cleared = g->d_atlas && canvas_cells % 4 == 0 && ((uintptr_t)g->d_atlas & 15) == 0;
-    hipLaunchKernelGGL(stats_v_scan_kernel<16>, dim3(gx, g->n_tiles + 1 + (canvas_cleared ? 1 : 0)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(stats_v_scan_kernel<16>, dim3(gx, g->n_tiles + 1 + (canvas_cleared ? 1 : 0)), dim3(stats_threads(16)), 0, ctx->stream,
                        g->d_tiles, tiles->depth, tiles->mask, vs, vc, vq, cells, n_blocks, g->d_node_id, g->d_cell_of_node,
                        g->d_counts, g->d_n_nodes_copy, canvas_cleared ? (int4 *)g->d_atlas : (int4 *)nullptr, canvas_cells / 4);
   }
@@ -1258,14 +1279,14 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
     ProfScope ps(ctx, BGNN_K_STATS);
     if (narrow) {
       if (!scan_with_stats)
-        hipLaunchKernelGGL(stats_v_kernel<16>, dim3((max_w + 15) / 16, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+        hipLaunchKernelGGL(stats_v_kernel<16>, dim3((max_w + 15) / 16, g->n_tiles), dim3(stats_threads(16)), 0, ctx->stream, g->d_tiles,
                            tiles->depth, tiles->mask, vs, vc, vq);
-      hipLaunchKernelGGL(stats_h_kernel<16>, dim3((max_h + 15) / 16, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+      hipLaunchKernelGGL(stats_h_kernel<16>, dim3((max_h + 15) / 16, g->n_tiles), dim3(stats_threads(16)), 0, ctx->stream, g->d_tiles,
                          vs, vc, vq, lmean, lstd);
     } else {
-      hipLaunchKernelGGL(stats_v_kernel<64>, dim3((max_w + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+      hipLaunchKernelGGL(stats_v_kernel<64>, dim3((max_w + 63) / 64, g->n_tiles), dim3(stats_threads(64)), 0, ctx->stream, g->d_tiles,
                          tiles->depth, tiles->mask, vs, vc, vq);
-      hipLaunchKernelGGL(stats_h_kernel<64>, dim3((max_h + 63) / 64, g->n_tiles), dim3(256), 0, ctx->stream, g->d_tiles,
+      hipLaunchKernelGGL(stats_h_kernel<64>, dim3((max_h + 63) / 64, g->n_tiles), dim3(stats_threads(64)), 0, ctx->stream, g->d_tiles,
                          vs, vc, vq, lmean, lstd);
     }
   }
