@@ -310,3 +310,33 @@ def test_box_statistics_forms_agree_bit_for_bit_and_with_the_oracle(gpu_device):
         o = graph_cpu.build_graph(d, m, None, (0.5, 0.5), node_feature_names=feats)
         _check_x(x.cpu().numpy(), o.x, feats)
         assert ulp_diff_f32(x.cpu().numpy()[:, 1], o.x[:, 1]).max(initial=0) == 0       # local_mean: 0 ulp
+
+
+def test_box_statistics_shape_sweep(gpu_device):
+    """Chunk boundaries of the running-sum kernels: heights / widths of 2..5 cells (windows that never fill; a side of 1 is refused
+    like np.gradient refuses it in the reference), 16 k - 1 .. 16 k + 3
+    (outputs 1 + 16 i + j: the last chunk holds 15, 16, 1, 2 outputs), 64 and 65 (a second 64-wide workgroup with one row).  Every
+    shape alone and all of them as one ragged batch, both workgroup widths, local_mean 0 ulp / local_std <= 1 ulp against the oracle."""
+    from bathymetric_gnn_amd import runtime as rt
+    from bathymetric_gnn_amd.data import GraphBuilder
+    ctx = rt.get_context(gpu_device)
+    rng = np.random.default_rng(23)
+    feats = ["depth", "local_mean", "local_std"]
+    gb = GraphBuilder(node_features=feats, device=gpu_device)
+    sizes = [2, 3, 4, 5, 15, 16, 17, 18, 19, 31, 32, 33, 34, 35, 47, 48, 49, 50, 51, 64, 65]
+    shapes = [(int(rng.choice(sizes)), int(rng.choice(sizes))) for _ in range(40)] + [(2, 2), (2, 65), (65, 2), (2, 33), (33, 2), (17, 17), (65, 65)]
+    cases = []
+    for h, w in shapes:
+        d = (rng.normal(-30.0, 8.0, size=(h, w)) * rng.choice([1.0, 1e-3, 250.0])).astype(np.float32)
+        m = rng.random((h, w)) < rng.choice([1.0, 0.9, 0.5])
+        if not m.any():
+            m[0, 0] = True
+        cases.append((d, m))
+    oracle = [graph_cpu.build_graph(d, m, None, (0.5, 0.5), node_feature_names=feats).x for d, m in cases]
+    for narrow in (0, 1):
+        with ctx.options(stats_narrow=narrow):
+            for (d, m), o in zip(cases, oracle):
+                _check_x(gb.build_graph(d, m, None, (0.5, 0.5)).x.cpu().numpy(), o, feats)
+            xb = gb.build_graphs([c[0] for c in cases], [c[1] for c in cases], None, [(0.5, 0.5)] * len(cases)).x.cpu().numpy()
+            _check_x(xb, np.concatenate(oracle, axis=0), feats)
+            assert ulp_diff_f32(xb[:, 1], np.concatenate(oracle, axis=0)[:, 1]).max(initial=0) == 0
