@@ -455,14 +455,14 @@ constexpr int STAT_CH = 16;
 // filled, chunk i being summed in place, chunk i - 1 being finalised), so both directions are coalesced and nothing but the
 // additions is left on the serial chain.
 template <int ROWS>
-__global__ __launch_bounds__(stats_threads(ROWS)) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
-                                                                      const double *vq, float *local_mean, float *local_std) {
+__device__ __forceinline__ void stats_h_body(const BgnnTileMeta *tiles, const double *vs, const double *vc, const double *vq,
+                                             float *local_mean, float *local_std, int bx, int by) {
   constexpr int P = STAT_CH + 1;                       // pitch in doubles: (34 r) mod 64 banks are distinct over 32 lanes
   constexpr int NK = ROWS / 16;                        // rows per worker thread
   __shared__ double tile[3][3][ROWS * P];
   __shared__ double first[3][ROWS];
-  const BgnnTileMeta t = tiles[blockIdx.y];
-  const int r0 = blockIdx.x * ROWS;
+  const BgnnTileMeta t = tiles[by];
+  const int r0 = bx * ROWS;
   if (r0 >= t.h) return;                               // (uniform)
   const int w = t.w, h = t.h, tid = threadIdx.x;
   const int nrow = h - r0 < ROWS ? h - r0 : ROWS;
@@ -563,6 +563,12 @@ __global__ __launch_bounds__(stats_threads(ROWS)) void stats_h_kernel(const Bgnn
     __syncthreads();
   }
   if (worker) flush();
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(stats_threads(ROWS)) void stats_h_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
+                                                                      const double *vq, float *local_mean, float *local_std) {
+  stats_h_body<ROWS>(tiles, vs, vc, vq, local_mean, local_std, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1122,10 +1128,15 @@ static int run_scan_counts(bgnn_ctx *ctx, V val, int64_t n, int32_t **block_off_
 // (atlas_tile: the grid a canvas cell belongs to -- the fused kernels look the grid's edge lengths up by it, for cells that hold a
 //  node only, so the table needs no clearing.  clear0..2: result grids the canvas walk will write valid cells of -- zero-filled here,
 //  cell by cell, instead of by a fill launch of their own)
-__global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *tiles, int n_tiles, const int32_t *pos, int atlas_w,
-                                                         const int32_t *node_id, int64_t cells, int32_t *atlas, int32_t *atlas_tile,
-                                                         float *clear0, float *clear1, float *clear2) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+struct CanvasFill {
+  const BgnnTileMeta *tiles; int n_tiles; const int32_t *pos; int atlas_w; const int32_t *node_id; int64_t cells;
+  int32_t *atlas, *atlas_tile; float *clear0, *clear1, *clear2;
+};
+__device__ __forceinline__ void atlas_fill_body(const CanvasFill &f, int64_t block) {
+  const BgnnTileMeta *tiles = f.tiles; const int n_tiles = f.n_tiles; const int32_t *pos = f.pos; const int atlas_w = f.atlas_w;
+  const int32_t *node_id = f.node_id; const int64_t cells = f.cells; int32_t *atlas = f.atlas, *atlas_tile = f.atlas_tile;
+  float *clear0 = f.clear0, *clear1 = f.clear1, *clear2 = f.clear2;
+  const int64_t i = block * 256 + threadIdx.x;
   if (i >= cells) return;
   if (clear0) clear0[i] = 0.0f;
   if (clear1) clear1[i] = 0.0f;
@@ -1138,6 +1149,22 @@ __global__ __launch_bounds__(256) void atlas_fill_kernel(const BgnnTileMeta *til
   const int64_t at = (int64_t)(pos[2 * t] + r) * atlas_w + pos[2 * t + 1] + c;
   atlas[at] = id;
   if (atlas_tile) atlas_tile[at] = t;
+}
+__global__ __launch_bounds__(256) void atlas_fill_kernel(CanvasFill f) { atlas_fill_body(f, blockIdx.x); }
+
+// Small ragged batches: the canvas fill (needs the scan) and the statistics' horizontal pass (needs the vertical pass) both follow the
+// scan + vertical-pass launch and do not depend on each other: one launch, rows [0, n_tiles) of the grid are the horizontal pass,
+// the rows above them the canvas fill's blocks.
+template <int ROWS>
+__global__ __launch_bounds__(stats_threads(ROWS)) void stats_h_canvas_kernel(const BgnnTileMeta *tiles, const double *vs, const double *vc,
+                                                                             const double *vq, float *local_mean, float *local_std,
+                                                                             CanvasFill f) {
+  if ((int)blockIdx.y >= f.n_tiles) {
+    if (threadIdx.x >= 256) return;
+    atlas_fill_body(f, (int64_t)(blockIdx.y - f.n_tiles) * gridDim.x + blockIdx.x);
+    return;
+  }
+  stats_h_body<ROWS>(tiles, vs, vc, vq, local_mean, local_std, blockIdx.x, blockIdx.y);
 }
 
 // full edge-attribute table of a compact graph, on demand: attrs[node][b] = (length of slot b, nan_to_num(depth[node] - depth[source]),
@@ -1266,12 +1293,14 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
                        g->d_tiles, tiles->depth, tiles->mask, vs, vc, vq, cells, n_blocks, g->d_node_id, g->d_cell_of_node,
                        g->d_counts, g->d_n_nodes_copy, canvas_cleared ? (int4 *)g->d_atlas : (int4 *)nullptr, canvas_cells / 4);
   }
+  CanvasFill cf{g->d_tiles, g->n_tiles, g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas, g->d_atlas_tile_of,
+                g->clear_grids[0], g->clear_grids[1], g->clear_grids[2]};
+  const bool fill_with_stats = g->d_atlas && narrow;       // canvas fill in the launch of the horizontal pass
   if (g->d_atlas) {
     if (!canvas_cleared)
       BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas, 0xff, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(atlas_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, g->d_tiles, g->n_tiles,
-                       g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas, g->d_atlas_tile_of, g->clear_grids[0],
-                       g->clear_grids[1], g->clear_grids[2]);
+    if (!fill_with_stats)
+      hipLaunchKernelGGL(atlas_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, cf);
     g->grids_cleared = true;
   }
   // 2. box statistics
@@ -1281,8 +1310,15 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
       if (!scan_with_stats)
         hipLaunchKernelGGL(stats_v_kernel<16>, dim3((max_w + 15) / 16, g->n_tiles), dim3(stats_threads(16)), 0, ctx->stream, g->d_tiles,
                            tiles->depth, tiles->mask, vs, vc, vq);
-      hipLaunchKernelGGL(stats_h_kernel<16>, dim3((max_h + 15) / 16, g->n_tiles), dim3(stats_threads(16)), 0, ctx->stream, g->d_tiles,
-                         vs, vc, vq, lmean, lstd);
+      const int gx = (max_h + 15) / 16;
+      if (fill_with_stats) {
+        const int fill_rows = (int)(((cells + 255) / 256 + gx - 1) / gx);
+        hipLaunchKernelGGL(stats_h_canvas_kernel<16>, dim3(gx, g->n_tiles + fill_rows), dim3(stats_threads(16)), 0, ctx->stream,
+                           g->d_tiles, vs, vc, vq, lmean, lstd, cf);
+      } else {
+        hipLaunchKernelGGL(stats_h_kernel<16>, dim3(gx, g->n_tiles), dim3(stats_threads(16)), 0, ctx->stream, g->d_tiles,
+                           vs, vc, vq, lmean, lstd);
+      }
     } else {
       hipLaunchKernelGGL(stats_v_kernel<64>, dim3((max_w + 63) / 64, g->n_tiles), dim3(stats_threads(64)), 0, ctx->stream, g->d_tiles,
                          tiles->depth, tiles->mask, vs, vc, vq);
