@@ -93,3 +93,18 @@ def test_multi_rank_code_path_rehearsal_two_ranks_share_the_gpu(gpu_device):
     # node evaluations of all ranks = the single rank's (every tile is classified exactly once)
     assert two["config"]["nodes_per_step_per_gpu"] < one["config"]["nodes_per_step_per_gpu"]
     assert abs(two["value"] * two["ms_per_step"] - one["value"] * one["ms_per_step"]) < 1e-6 * one["value"] * one["ms_per_step"]
+
+
+def test_tile_workload_two_rank_rehearsal_counts_both_ranks(gpu_device):
+    """The headline workload through the same multi-rank plumbing (rank spawn, barrier, MAX of the elapsed times, SUM of the node counts
+    over the ranks) as a `--share-gpu` rehearsal: every rank keeps its full batch (weak scaling), `value` is the nodes of BOTH ranks over
+    the slowest rank's time -- so value x ms_per_step is twice the per-rank node count.  Labelled a rehearsal; no scaling claim."""
+    base = ["--tiles", "8", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    one = _line(base)
+    two = _line(base + ["--gpus", "2", "--share-gpu"])
+    assert one["n_gpus"] == 1 and "rehearsal" not in one
+    assert two["n_gpus"] == 2 and two["rehearsal"] is True and two["scaling"] == "weak"
+    per_rank = one["config"]["nodes_per_step_per_gpu"]
+    assert two["config"]["nodes_per_step_per_gpu"] == per_rank and "x2" in two["config"]["parallelism"]
+    assert abs(one["value"] * one["ms_per_step"] * 1e-3 - per_rank) < 1e-6 * per_rank
+    assert abs(two["value"] * two["ms_per_step"] * 1e-3 - 2 * per_rank) < 1e-6 * per_rank
