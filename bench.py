@@ -274,6 +274,7 @@ def spawn_ranks(n, argv, env=None, python=None, poll_s=0.2):
         e = dict(env, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))   # (torchrun sets 1: the ranks share the host's cores)
         procs.append(subprocess.Popen([python or sys.executable] + list(argv), env=e))
     rc = 0
     live = list(procs)
