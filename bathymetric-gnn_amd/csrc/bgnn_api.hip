@@ -804,6 +804,8 @@ static int graph_build_impl(bgnn_ctx *ctx, const bgnn_tiles *tiles, const bgnn_g
                             float *const *clear_grids) {
   BGNN_REQUIRE(ctx && tiles && opts && out, "bgnn_graph_build: NULL argument");
   BGNN_REQUIRE(tiles->n_tiles >= 1, "bgnn_graph_build: n_tiles=%d", tiles->n_tiles);
+  // (the per-grid kernels index grids by gridDim.y: 65 535 at most -- say so instead of failing the launch)
+  BGNN_REQUIRE(tiles->n_tiles <= 60000, "bgnn_graph_build: %d grids in one batch, at most 60000 (split the batch)", tiles->n_tiles);
   BGNN_REQUIRE(tiles->hw && tiles->resolution && tiles->depth && tiles->mask, "bgnn_graph_build: NULL tile array");
   BGNN_TRY(validate_opts(opts));
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));

@@ -1295,7 +1295,10 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
   }
   CanvasFill cf{g->d_tiles, g->n_tiles, g->d_atlas_pos, g->atlas_w, g->d_node_id, cells, g->d_atlas, g->d_atlas_tile_of,
                 g->clear_grids[0], g->clear_grids[1], g->clear_grids[2]};
-  const bool fill_with_stats = g->d_atlas && narrow;       // canvas fill in the launch of the horizontal pass
+  // canvas fill in the launch of the horizontal pass (its blocks are extra grid rows: gridDim.y stays far below the 65 535 limit
+  // for refinement grids; a pathological batch of very wide, flat grids keeps the fill launch of its own)
+  const int64_t fill_rows64 = ((cells + 255) / 256 + (max_h + 15) / 16 - 1) / ((max_h + 15) / 16);
+  const bool fill_with_stats = g->d_atlas && narrow && g->n_tiles + fill_rows64 <= 60000;
   if (g->d_atlas) {
     if (!canvas_cleared)
       BGNN_HIP_CHECK(hipMemsetAsync(g->d_atlas, 0xff, (size_t)g->atlas_h * g->atlas_w * sizeof(int32_t), ctx->stream));
@@ -1312,7 +1315,7 @@ int launch_graph_build(bgnn_ctx *ctx, bgnn_graph *g, const bgnn_tiles *tiles, co
                            tiles->depth, tiles->mask, vs, vc, vq);
       const int gx = (max_h + 15) / 16;
       if (fill_with_stats) {
-        const int fill_rows = (int)(((cells + 255) / 256 + gx - 1) / gx);
+        const int fill_rows = (int)fill_rows64;
         hipLaunchKernelGGL(stats_h_canvas_kernel<16>, dim3(gx, g->n_tiles + fill_rows), dim3(stats_threads(16)), 0, ctx->stream,
                            g->d_tiles, vs, vc, vq, lmean, lstd, cf);
       } else {

@@ -91,6 +91,7 @@ class _BatchSlot:
 class NativeVRProcessor:
     CLASS_NOISE = 2
     BATCH_NODE_BUDGET = 50000        # nodes to accumulate before a flush (reference :128)
+    MAX_GRIDS_PER_BATCH = 32768      # the library takes at most 60 000 grids per batch (a BAG of 3 x 3 grids reaches that before any cell budget)
 
     def __init__(self, model: BathymetricGNN, graph_builder: GraphBuilder, device=None,
                  auto_correct_threshold: float = 0.85):
@@ -189,7 +190,8 @@ class NativeVRProcessor:
 
     @property
     def batch_ready(self) -> bool:
-        return self._batch_node_count >= self.BATCH_NODE_BUDGET
+        return (self._batch_node_count >= self.BATCH_NODE_BUDGET or
+                (self._fill is not None and len(self._fill.hw) >= self.MAX_GRIDS_PER_BATCH))     # (a raised budget and tiny grids)
 
     @property
     def batch_pending(self) -> bool:
@@ -357,7 +359,7 @@ class NativeVRProcessor:
         g0 = 0
         while g0 < n_grids:
             g1 = int(np.searchsorted(off, off[g0] + cell_budget, side="right")) - 1
-            g1 = min(max(g1, g0 + 1), n_grids)
+            g1 = min(max(g1, g0 + 1), n_grids, g0 + self.MAX_GRIDS_PER_BATCH)
             lo, hi = int(off[g0]), int(off[g1])
             n = hi - lo
             rec_t = torch.from_numpy(rec_all[lo:hi]).to(dev)

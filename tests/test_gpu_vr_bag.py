@@ -333,3 +333,31 @@ def test_pipelined_loop_with_a_foreign_writer_takes_the_per_grid_path(gpu_device
     assert np.array_equal(w_bulk.refinements.view(np.uint32), w_plain.w.refinements.view(np.uint32))
     assert w_bulk._corrections_applied == w_plain.w._corrections_applied
     assert st_bulk == st_plain
+
+
+def test_grid_count_cap_closes_a_batch_and_the_library_names_its_limit(gpu_device):
+    """The per-grid kernels index grids by gridDim.y: the library refuses more than 60 000 grids in one batch with a message that
+    says so (not a failed launch), and the processor closes a batch at MAX_GRIDS_PER_BATCH grids whatever the node budget."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor
+    sd = synthetic.synthetic_state_dict(in_channels=8, seed=5)
+    model = BathymetricGNN(in_channels=8, edge_dim=3, dropout=0.0)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model.to(gpu_device).eval()
+    proc = NativeVRProcessor(model, GraphBuilder(device=gpu_device), gpu_device)
+    proc.BATCH_NODE_BUDGET = 10 ** 9
+    proc.MAX_GRIDS_PER_BATCH = 50
+    rng = np.random.default_rng(0)
+    for i in range(50):
+        assert not proc.batch_ready
+        d = rng.normal(-20.0, 1.0, (3, 3)).astype(np.float32)
+        assert proc.add_to_batch(d, np.full((3, 3), 0.1, np.float32), (0.5, 0.5)) is None
+    assert proc.batch_ready
+    assert len(proc.flush_batch()) == 50
+    n = 60001
+    gb = GraphBuilder(device=gpu_device)
+    d = np.zeros((n * 4,), np.float32)
+    with pytest.raises((rt.BgnnError, ValueError), match="at most 60000"):
+        gb.build_graphs([d[4 * i:4 * i + 4].reshape(2, 2) for i in range(n)], [np.ones((2, 2), bool)] * n, None, [(0.5, 0.5)] * n)
