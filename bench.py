@@ -171,7 +171,7 @@ def compact_line(line, budget=LINE_BUDGET):
     """The stdout line within `budget` bytes: optional keys are dropped (least important first) until it fits; the contract
     keys, roofline and cpu_baseline are never dropped."""
     out = dict(line)
-    for k in ("matrix_path", "path", "gnn_types", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
+    for k in ("opt_in_split", "matrix_path", "path", "gnn_types", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
         if len(json.dumps(out)) <= budget:
             break
         out.pop(k, None)
@@ -863,6 +863,9 @@ def main():
                                    "steps": n_sp, "max_abs_logit_diff_vs_exact_f32": float((lg_split - lg_exact).abs().max().item()),
                                    "note": f"matrix_path={env}: layer GEMMs as hi/lo operand splits on {instr}, float32 accumulate; "
                                            "opt-in, not the headline"}
+                    # (brief, in the line: what the opt-in operand-split paths give and how far their logits are from the headline path's)
+                    line.setdefault("opt_in_split", {"note": "not the headline; max |dlogit| vs the exact-f32 path"})[env] = {
+                        "value": detail[key]["value"], "max_dlogit": detail[key]["max_abs_logit_diff_vs_exact_f32"]}
             guarded("split_paths", _splits)
             # ---- the other single-GPU BASELINE configs, same protocol (rank 0, N = 1), each with its own roofline ----------
             k_x, w_x = max(4, min(args.steps, 10)), 2

@@ -138,6 +138,9 @@ def _representative_line():
             "gnn_types": {k: {"value": 412345678.1234567, "frac": 0.3312345678901234, "kernel": "neighbor_reduce_kernel"} for k in ("GCN", "GraphSAGE", "GIN")},
             "config4": dict(brief, one_context=157123456.12345678, two_contexts=203123456.12345678,
                             processor_api={"synchronous": 15123456.123456789, "pipelined": 16123456.123456789}),
+            "opt_in_split": {"note": "not the headline; max |dlogit| vs the exact-f32 path",
+                             "bf16x3": {"value": 478901592.1696222, "max_dlogit": 5.364418029785156e-06},
+                             "fp16x3": {"value": 473647466.0648265, "max_dlogit": 5.662441253662109e-07}},
             "detail": "gpurun_out/bench_detail.json"}
 
 
