@@ -127,6 +127,11 @@ __device__ __forceinline__ void lds_reads_done() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+template <int N>
+__device__ __forceinline__ void lds_reads_wait() {       // all but the N youngest LDS operations have returned (they return in order)
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 template <int OFF>
 __device__ __forceinline__ void lds_write1(uint32_t addr, float v) {     // (an LDS write hipcc does not see either: same reason)
   asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
@@ -554,6 +559,10 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   constexpr int H = HC / C;
   constexpr int NC = NT * 32;
   constexpr int NSLAB = HC / 32, SPH = C / 32;
+  // the exact path's gather with the next source's LDS reads in flight under the current source's accumulation: where the second
+  // register set fits the instance's occupancy (256 -> 256: 252 of 256 VGPRs at two waves per SIMD; 256 -> 64: 150 of 168 at three;
+  // the heads instances, k = 16 and the plain backbones would lose a resident workgroup to it)
+  constexpr bool GATHER_PIPE = SP == 0 && K <= 8 && EPI == EPI_NEXT && AGG == 0;
   using Geo = FusedGeom<K>;
   using Lds = FusedLds<HC, C, K, NT, EPI, SP>;
   constexpr int HR = Geo::HR, HW_ = Geo::HW, RAD = Geo::R;
@@ -1075,9 +1084,30 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
 #pragma unroll
           for (int j = 0; j < 4; ++j) g[j] = (f32x4){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
         } else {
-          // 128-byte rows of f32: slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5)).  (Not
-          // software-pipelined: measured, it buys nothing on the f32 paths -- the stamps put the gather at 4.6 % of a
-          // workgroup's lifetime -- and the second read buffer takes the kernel to 256 registers.)
+          // 128-byte rows of f32: slot of channel chunk hl of that row; chunk 2j + hl sits at (slot ^ (j << 5)).
+          if constexpr (GATHER_PIPE) {
+            // source b + 1's five reads are in flight while source b is accumulated (two register sets; LDS operations return in
+            // order, so "all but the five youngest" is source b).  The nine LDS round trips of a slab -- ~300-500 cycles each with the
+            // other workgroup's W-fragment reads on the same LDS -- were serial: 2.35 ms of the 24.8 ms fused step by the phase
+            // ablation.  Same additions in the same order: bit-identical.  Fused step 24.63 -> 24.25 ms (A/B on one box).
+            f32x4 xb[2][4];
+            float al[2];
+            auto issue = [&](int b, int q) {
+              const int nidx = nb_index(b);
+              const int hcol = tc + RAD - (b < K ? Off::dc[b < K ? b : 0] : 0);
+              const uint32_t rb = slabs + nidx * 128 + (((((hcol >> 1) & 7)) ^ (SP ? 2 * hl : hl)) << 4);
+              al[q] = lds_read1<0>(ap + 4 * b);
+              xb[q][0] = lds_read4<0>(rb); xb[q][1] = lds_read4<0>(rb ^ CX1); xb[q][2] = lds_read4<0>(rb ^ CX2); xb[q][3] = lds_read4<0>(rb ^ CX3);
+            };
+            issue(0, 0);
+#pragma unroll
+            for (int b = 0; b <= K; ++b) {
+              const int q = b & 1;
+              if (b + 1 <= K) { issue(b + 1, q ^ 1); lds_reads_wait<5>(); } else lds_reads_done();
+#pragma unroll
+              for (int j = 0; j < 4; ++j) g[j] += al[q] * xb[q][j];
+            }
+          } else {
 #pragma unroll
           for (int b = 0; b <= K; ++b) {
             const int nidx = nb_index(b);
@@ -1089,6 +1119,7 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
             lds_reads_done();
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] += alpha * x[j];
+          }
           }
         }
       }
