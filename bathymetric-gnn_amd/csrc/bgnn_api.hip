@@ -207,6 +207,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.gemm_waves = env_int("BGNN_GEMM_WAVES", 8);
     o.gemm_diag = env_int("BGNN_GEMM_DBG", 0);
     o.gemm_no_wres = getenv("BGNN_NO_WRES") ? 1 : 0;
+    o.gemm_pair_major = getenv("BGNN_NO_PAIR_MAJOR") ? 0 : 1;
   }
   *out = c;
   return BGNN_OK;
@@ -218,7 +219,7 @@ static int *option_slot(bgnn_ctx *ctx, const char *name) {
       {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent}, {"bf16_two_phase", &o.bf16_two_phase}, {"stats_narrow", &o.stats_narrow},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
-      {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}};
+      {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}, {"gemm_pair_major", &o.gemm_pair_major}};
   for (auto &t : tab) if (strcmp(t.n, name) == 0) return t.p;
   return nullptr;
 }
@@ -441,8 +442,9 @@ static void pack_alpha_tile(const float *Wt, const float *bias, const float *att
 
 // column-permuted f32 image for the fused exact-f32 kernel: column 32 t + r of a row goes to (t / TG) * 32 TG + r * TG + t % TG,
 // TG = 4 / 2 / 1 tiles per LDS read (gat_layer_fused.hip: WTileGroup)
-static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst) {
-  const int NT = NC / 32, TG = NT % 4 == 0 ? 4 : NT % 2 == 0 ? 2 : 1;
+// (tg > 0 forces the group width: the lin_0 GEMM's pair-major form reads TWO tiles per ds_read_b64, gemm_f32.hip PM)
+static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst, int tg = 0) {
+  const int NT = NC / 32, TG = tg > 0 ? tg : NT % 4 == 0 ? 4 : NT % 2 == 0 ? 2 : 1;
   for (int k = 0; k < D; ++k)
     for (int t = 0; t < NT; ++t)
       for (int r = 0; r < 32; ++r)
@@ -622,7 +624,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   // bf16 and float16 hi / lo images of the fused kernels' next-stage weights (layers 1.., the heads' first layers) and
   // of the folded layer-0 weight
   std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0), o_wbf(L, 0), o_wfp(L, 0);
-  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0, o_hW0bf = 0, o_l0fbf = 0, o_hW0fp = 0;
+  size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0, o_hW0bf = 0, o_l0fbf = 0, o_hW0fp = 0, o_l0fpm = 0;
   bool f16_ok = true;                  // every weight fits float16: else BGNN_SPLIT_F16 falls back to the bf16 split
   if (gat) {
     for (int l = 1; l < L; ++l) {
@@ -632,6 +634,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     }
     o_hW0fp = reserve((size_t)hid * HT);
     o_hW0sp = reserve((size_t)hid * HT); o_hW0sp16 = reserve((size_t)hid * HT); o_hW0bf = reserve((size_t)hid * HT / 2);
+    if (HC0 % 64 == 0) o_l0fpm = reserve((size_t)hid * HC0);
     o_l0fsp = reserve((size_t)hid * HC0); o_l0fsp16 = reserve((size_t)hid * HC0); o_l0fbf = reserve((size_t)hid * HC0 / 2 + (size_t)hid / 16 * 256 + 8);   // + the alpha tile and its constants
     for (int l = 1; l < L; ++l) {          // (reserve may reallocate pk: take the source pointers afterwards)
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
@@ -650,6 +653,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
     if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
     pack_bf16_image_accop(src0.data(), hid, HC0, pk.data() + o_l0fbf);
+    if (o_l0fpm) pack_tilegroup_image(src0.data(), hid, HC0, pk.data() + o_l0fpm, 2);
     if (HC0 / hid <= 4) {
       const std::vector<float> b0(pk.begin() + o_l0f_b, pk.begin() + o_l0f_b + HC0);
       const std::vector<float> as0(pk.begin() + lo[0].as, pk.begin() + lo[0].as + HC0), ad0(pk.begin() + lo[0].ad, pk.begin() + lo[0].ad + HC0);
@@ -679,6 +683,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->l0f_Wsp = gat ? m->blob + o_l0fsp : nullptr;
   m->l0f_Wsp16 = gat && f16_ok ? m->blob + o_l0fsp16 : nullptr;
   m->l0f_Wbf = gat ? m->blob + o_l0fbf : nullptr;
+  m->l0f_Wpm = gat && o_l0fpm ? m->blob + o_l0fpm : nullptr;
   m->hd_W0bf = gat ? m->blob + o_hW0bf : nullptr;
   m->hd_W0fp = gat ? m->blob + o_hW0fp : nullptr;
   m->layers.resize(L);
@@ -1236,7 +1241,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       if (!front) BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       BGNN_TRY(launch_gemm_f32(ctx, front ? g->d_x8 : Y, front ? 8 : hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid,
                                L0.heads * hid, 0, L0.att_src, L0.att_dst, asdX, L0.heads, hid, wsplit, smode,
-                               front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr));
+                               front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr, front && smode == 0 ? m->l0f_Wpm : nullptr));
     } else {
       BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));

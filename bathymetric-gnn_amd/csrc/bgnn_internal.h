@@ -91,6 +91,8 @@ struct BgnnOpts {
   int diag_mask = 0;         // BGNN_DIAG builds only: phase ablation bits of the fused kernel
   int diag_stamps = 0;       // BGNN_DIAG builds only: per-phase s_memtime sums
   int gemm_waves = 8, gemm_diag = 0, gemm_no_wres = 0;
+  int gemm_pair_major = 1;   // exact-f32 lin_0 GEMM with the extractor in front: tile-pair-major MFMA order, the epilogue of pair p (bias, attention
+                             // dots, transposed row stores) issued between the MFMAs of pair p + 1 (0: tile-major, epilogue after; bit-identical)
 };
 
 // Diagnostics (phase ablations, cycle stamps) are compiled in only with -DBGNN_DIAG=1 (python __graft_entry__.py --diag
@@ -164,6 +166,7 @@ struct bgnn_model {
   float *l0f_Wt, *l0f_b;      // [hid][HC0], [HC0]: second extractor layer folded into lin of layer 0 (no activation between)
   float *l0f_Wsp = nullptr, *l0f_Wsp16 = nullptr;   // l0f_Wt as bf16 / float16 hi / lo split images
   float *l0f_Wbf = nullptr, *hd_W0bf = nullptr;     // l0f_Wt / hd_W0t as bf16 (hi only) images
+  float *l0f_Wpm = nullptr;                         // l0f_Wt with the columns of tile pairs interleaved (gemm_f32.hip, PM form)
   float *hd_W0fp = nullptr;                         // hd_W0t column-permuted for the fused exact-f32 kernel
   std::vector<BgnnLayer> layers;
   float *ones = nullptr;      // [256] of 1.0f: the identity scale of an unfolded epilogue
@@ -279,7 +282,7 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
                     int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu,
                     const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
                     int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0,
-                    const float *front_W0t = nullptr, const float *front_b0 = nullptr);
+                    const float *front_W0t = nullptr, const float *front_b0 = nullptr, const float *Wt_pm = nullptr);
 bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                          const float *asd, float *out, int relu);

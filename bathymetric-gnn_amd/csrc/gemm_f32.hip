@@ -247,9 +247,18 @@ __device__ __forceinline__ f32x16 mfma_lp(const f16x8 &a, const f16x8 &b, const 
 // and one launch, less).  The result tile holds, on lane (r, h), channels 8s + 4h + i of row r: exactly this kernel's X fragment
 // order on the exact path; on the bf16 path it is the accumulator-as-operand order, for which the W image is packed
 // (bgnn_api.hip pack_bf16_image_accop).
-template <int NT, bool ATT, int SP = 0, bool FRONT = false>
+// PM (exact path, attention form with the fused front, NT >= 4): tile-PAIR-major MFMA order over a weight image whose columns
+// interleave the two tiles of a pair (bgnn_api.hip pack_tilegroup_image, TG = 2: one ds_read_b64 = the fragments of both tiles of a
+// k row), with the epilogue of pair p -- bias, attention dots, transposed patch, row stores -- issued in eight slots BETWEEN the
+// eight MFMA groups of pair p + 1.  In the tile-major form a wave's life is 256 MFMAs, then ~600 epilogue instructions; the two
+// waves of a SIMD share the matrix pipe fairly, so they stay in phase -- both in their MFMAs, then both in their epilogues with
+// the pipe idle (MfmaUtil 65 %).  Interleaved, a wave's instruction stream is uniform: its LDS round trips and store issue pass
+// under its own MFMAs and the row stores leave at an even pace.  Every accumulator sees the same products in the same k order and
+// the dots are summed in the same order: bit-identical to the tile-major form (option gemm_pair_major = 0).
+template <int NT, bool ATT, int SP = 0, bool FRONT = false, bool PM = false>
 __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   static_assert(!FRONT || SP == 0 || SP == 3, "the fused front exists on the exact and the bf16 storage paths");
+  static_assert(!PM || (SP == 0 && ATT && FRONT && NT % 2 == 0 && NT >= 4), "pair-major form: exact path, attention epilogue, fused front");
   constexpr int NC = NT * 32, K = 64;
   constexpr int WFLOATS = SP == 3 ? K * NC / 2 : K * NC;   // bytes of the weight image / 4
   extern __shared__ __attribute__((aligned(128))) float wres_lds[];
@@ -363,6 +372,125 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
         ax[s] = v;
       }
     }
+    float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
+    if constexpr (PM) {
+      constexpr int NP = NT / 2;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // the next block's feature row: xq is free again (the front consumed it), and every row store of this block follows
+      if (row0 + stride < M && !(BGNN_DIAG && (a.dbg & 4))) load_x(row0 + stride);
+      // row-segment stores: rows row0 + (lane >> 4) + 4 k -- a wave-uniform 64-bit base per k (scalar registers) plus ONE 32-bit
+      // lane offset that never changes, instead of eight 64-bit pointers in vector registers.  Rows past M are masked, not sent to
+      // the dump row: only the grid's very last block is partial, and it has no next block whose feature row would count on them.
+      const int64_t urow0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(row0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)row0);
+      const uint32_t ldyb = (uint32_t)a.ldy * 4u;
+      const uint32_t voff = (uint32_t)(lane >> 4) * ldyb + (uint32_t)(lane & 15) * 16u;
+      const int rows_left = (int)(M - urow0 < 32 ? M - urow0 : 32);     // wave-uniform
+      f32x16 acc[NT];
+      // pair-permuted image: column 32 t + r of row k at k NC + 64 (t / 2) + 2 r + (t & 1); lane (r, h) reads rows 8 s + 4 h + i
+      const float *wlane = wl + 4 * h * NC + 2 * r;
+      auto wfrag = [&](int s, int i, int p) -> f32x2 { return *reinterpret_cast<const f32x2 *>(wlane + (s * 8 + i) * NC + p * 64); };
+      // epilogue of one pair in micro-stages (t: tile, hf: half of its 16 accumulator registers, kh: half of the 8 row-segment stores)
+      f32x4 eb[2], es[2], ed[2], pv[4];
+      f32x2 ps2 = {0.f, 0.f}, pd2 = {0.f, 0.f};
+      // (the base is made opaque once per block: left visible, the loop-invariant address of every one of the 96 reads is hoisted
+      //  out of the row loop into a vector register of its own -- 30 spills; inside the loop they fold into the reads' offset fields)
+      typedef const __attribute__((address_space(3))) float lds_cf;
+      typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
+      lds_cf *ebase = (lds_cf *)(attl + 4 * h);         // att_src | att_dst [2 NC] | b0 [64] | bias [NC]
+      asm volatile("" : "+v"(ebase));
+      auto stage_R = [&](int t, int hf) {               // bias and attention vectors of the half tile: six LDS reads in flight
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int c0 = t * 32 + 8 * (2 * hf + gg);
+          eb[gg] = *reinterpret_cast<lds_cf4 *>(ebase + 2 * NC + 64 + c0);
+          es[gg] = *reinterpret_cast<lds_cf4 *>(ebase + c0);
+          ed[gg] = *reinterpret_cast<lds_cf4 *>(ebase + NC + c0);
+        }
+      };
+      auto stage_C = [&](int t, int hf) {               // + bias, the dots' partial sums (same order as the tile-major form), patch
+        if (hf == 0) { ps2 = (f32x2){0.f, 0.f}; pd2 = (f32x2){0.f, 0.f}; }
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * hf + gg;
+          f32x4 v = {acc[t][4 * g] + eb[gg].x, acc[t][4 * g + 1] + eb[gg].y, acc[t][4 * g + 2] + eb[gg].z, acc[t][4 * g + 3] + eb[gg].w};
+          const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+          ps2 += vlo * (f32x2){es[gg].x, es[gg].y}; ps2 += vhi * (f32x2){es[gg].z, es[gg].w};
+          pd2 += vlo * (f32x2){ed[gg].x, ed[gg].y}; pd2 += vhi * (f32x2){ed[gg].z, ed[gg].w};
+          *reinterpret_cast<f32x4 *>(patch + r * PP + (t & 1) * 32 + 8 * g + 4 * h) = v;
+        }
+        if (hf == 1) {
+          float ps = ps2.x + ps2.y, pd = pd2.x + pd2.y;
+          asm volatile("" : "+v"(ps), "+v"(pd));
+          // C == 64: a pair of tiles is a head.  Summed as the tile-major form sums them: (0 + tile 2q) + tile 2q + 1
+          if ((t & 1) == 0) { pts[t / 2] = 0.0f + ps; ptd[t / 2] = 0.0f + pd; }
+          else { pts[t / 2] += ps; ptd[t / 2] += pd; }
+        }
+      };
+      auto stage_PR = [&](int kh) {                     // four 256-byte row segments of the pair's patch
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pv[j] = *reinterpret_cast<const f32x4 *>(patch + ((lane >> 4) + 4 * (4 * kh + j)) * PP + (lane & 15) * 4);
+      };
+      auto stage_ST = [&](int q, int kh) {
+        if (!(BGNN_DIAG && (a.dbg & 1))) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = 4 * kh + j;
+            char *rowb = reinterpret_cast<char *>(a.Y) + (urow0 + 4 * k) * (int64_t)ldyb + q * 64 * 4;   // uniform
+            if ((lane >> 4) + 4 * k < rows_left) *reinterpret_cast<f32x4 *>(rowb + voff) = pv[j];
+          }
+        }
+      };
+      auto epilogue_slot = [&](int q, int slot) {       // pair q's epilogue, slot 0 .. 7
+        const int tA = 2 * q, tB = 2 * q + 1;
+        if (slot == 0) { stage_R(tA, 0); }
+        if (slot == 1) { stage_C(tA, 0); stage_R(tA, 1); }
+        if (slot == 2) { stage_C(tA, 1); stage_R(tB, 0); }
+        if (slot == 3) { stage_C(tB, 0); stage_R(tB, 1); }
+        if (slot == 4) { stage_C(tB, 1); }
+        if (slot == 5) { stage_PR(0); }
+        if (slot == 6) { stage_ST(q, 0); stage_PR(1); }
+        if (slot == 7) { stage_ST(q, 1); }
+      };
+      f32x2 wc[4], wn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wc[i] = wfrag(0, i, 0);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int s = 0; s < K / 8; ++s) {
+          if (!(p == NP - 1 && s == K / 8 - 1)) {       // the next group's fragments fly under this group's MFMAs
+            const int ns = s == K / 8 - 1 ? 0 : s + 1, np = s == K / 8 - 1 ? p + 1 : p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wn[i] = wfrag(ns, i, np);
+          }
+          const float av[4] = {ax[s].x, ax[s].y, ax[s].z, ax[s].w};
+          if (!(BGNN_DIAG && (a.dbg & 2))) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (s == 0 && i == 0) {                   // the pair's first MFMAs start from an inline zero (no 32 v_mov per pair)
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].x, av[i], zero16, 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].y, av[i], zero16, 0, 0, 0);
+              } else {
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].x, av[i], acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].y, av[i], acc[2 * p + 1], 0, 0, 0);
+              }
+            }
+          } else if (s == 0) {
+            acc[2 * p] = zero16; acc[2 * p + 1] = zero16;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (p > 0) epilogue_slot(p - 1, s);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+        }
+      }
+#pragma unroll
+      for (int slot = 0; slot < 8; ++slot) epilogue_slot(NP - 1, slot);   // the last pair's epilogue (the SIMD's other wave covers it)
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -442,7 +570,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
       const int64_t rr = row0 + (lane >> 4) + 4 * k;
       dst[k] = (rr < M ? reinterpret_cast<char *>(a.Y) + rr * a.ldy * YB : reinterpret_cast<char *>(a.dump)) + (lane & 15) * LB;
     }
-    float pts[ATT ? NT : 1], ptd[ATT ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float4 v[4];
@@ -533,7 +660,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
         else { p[0] = d0; if (H > 1) p[1] = d1; if (H > 2) p[2] = d2; }
       }
     }
-    if (ATT && !AMF) {
+    }   // !PM
+    if constexpr (PM) {
+      const int64_t row = row0 + r;
+#pragma unroll
+      for (int hd = 0; hd < NT / 2; ++hd) {
+        const float ps = pts[hd] + __shfl_xor(pts[hd], 32), pd = ptd[hd] + __shfl_xor(ptd[hd], 32);
+        if (row < M && h == 0) {
+          a.asd[row * NT + hd] = ps;                   // [alpha_src (H) | alpha_dst (H)], H = NT / 2
+          a.asd[row * NT + NT / 2 + hd] = pd;
+        }
+      }
+    } else if (ATT && !AMF) {
       const int64_t row = row0 + r;
       const int H = a.H, tph = a.C / 32;
       for (int hd = 0; hd < H; ++hd) {
@@ -552,12 +690,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
   }
 }
 
-template <int NT, bool ATT, int SP = 0, bool FRONT = false>
+template <int NT, bool ATT, int SP = 0, bool FRONT = false, bool PM = false>
 static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
   constexpr size_t lds_bytes = (size_t)((SP == 3 ? 32 : 64) * NT * 32 + (SP == 3 && ATT ? 1024 : 0) + 8 * (SP == 3 ? 32 * 64 : 32 * 68) +
                                         2 * NT * 32 + 64 + NT * 32) * 4;
   static std::atomic<uint64_t> configured{0};   // per instantiation: one bit per device (the attribute is per device)
-  auto kern = gemm_wres64_kernel<NT, ATT, SP, FRONT>;
+  auto kern = gemm_wres64_kernel<NT, ATT, SP, FRONT, PM>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
@@ -586,7 +724,7 @@ bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int spl
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
                     const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode,
-                    const float *front_W0t, const float *front_b0) {
+                    const float *front_W0t, const float *front_b0, const float *Wt_pm) {
   BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0 && ldy % 4 == 0,
                "gemm_f32: unsupported shape K=%d NC=%d ldx=%d ldy=%d", K, NC, ldx, ldy);
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
@@ -604,7 +742,11 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (K == 64 && (!no_wres || split_mode == 3) && (max_rows >= BGNN_WRES_MIN_ROWS || Wt_split)) {    // W-resident persistent form
     switch (NC / 32) {
 #define BGNN_WRES_CASE(NT) case NT:                                                                                 \
-        if (front_W0t) { if (split_mode == 3) a.Wt = Wt_split; return split_mode == 3 ? launch_wres64<NT, true, 3, true>(ctx, a) : launch_wres64<NT, true, 0, true>(ctx, a); } \
+        if (front_W0t) {                                                                                           \
+          if (split_mode == 3) { a.Wt = Wt_split; return launch_wres64<NT, true, 3, true>(ctx, a); }              \
+          if constexpr (NT >= 4) { if (Wt_pm && ctx->opts.gemm_pair_major && C == 64 && H == NT / 2) { a.Wt = Wt_pm; return launch_wres64<NT, true, 0, true, true>(ctx, a); } } \
+          return launch_wres64<NT, true, 0, true>(ctx, a);                                                        \
+        }                                                                                                          \
         if (Wt_split) { BGNN_REQUIRE(split_mode != 3, "gemm: the bf16 image is packed for the fused front"); a.Wt = Wt_split; return split_mode == 2 ? launch_wres64<NT, true, 2>(ctx, a) : launch_wres64<NT, true, 1>(ctx, a); } \
         return att_src ? launch_wres64<NT, true>(ctx, a) : launch_wres64<NT, false>(ctx, a);
       BGNN_WRES_CASE(2) BGNN_WRES_CASE(8)

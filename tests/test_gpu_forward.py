@@ -1055,6 +1055,34 @@ def test_extractor_layer_inside_the_lin0_gemm_is_bit_identical(gpu_device):
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("shape,n", [((256, 256), 2), ((250, 263), 1), ((181, 199), 2)])
+def test_pair_major_lin0_gemm_is_bit_identical(shape, n, gpu_device):
+    """Option gemm_pair_major (default on): the exact-f32 lin_0 GEMM with the extractor in front runs its MFMAs tile-pair-major with
+    the epilogue of pair p issued between the MFMAs of pair p + 1 (gemm_f32.hip, PM).  Same products in the same k order, same
+    summation order of the attention dots: every output must be bit-identical to the tile-major form -- full blocks, a partial last
+    block (row count not a multiple of 32: masked row stores), holes."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    model = _model(synthetic.synthetic_state_dict(seed=78))
+    gb = GraphBuilder(device=gpu_device)
+    tiles = [synthetic.synthetic_tile(shape[0], shape[1], 950 + i, "V1") for i in range(n)]
+    g = gb.build_graphs([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * n)
+    assert g.num_nodes >= 32768                          # the W-resident form (BGNN_WRES_MIN_ROWS)
+    ctx = rt.get_context(gpu_device)
+    try:
+        a = model.predict(g)
+        ha = model.hidden(g) if hasattr(model, "hidden") else None
+        ctx.set_option("gemm_pair_major", 0)
+        b = model.predict(g)
+        hb = model.hidden(g) if hasattr(model, "hidden") else None
+    finally:
+        ctx.set_option("gemm_pair_major", 1)
+    for k in ("class_logits", "confidence", "correction", "class_probs"):
+        assert torch.equal(a[k], b[k]), k
+    if ha is not None:
+        assert torch.equal(ha, hb)
+
+
 @pytest.mark.parametrize("connectivity,shape,n", [("8-connected", (250, 250), 5), ("4-connected", (256, 256), 4), ("8-connected", (64, 512), 9)])
 def test_persistent_fused_layer_is_bit_identical(connectivity, shape, n, gpu_device):
     """Option fused_persistent (opt-in): big uniform batches on the exact path run the 256 -> 256 fused layer in its persistent

@@ -2,6 +2,8 @@
 """A/B of two builds of the library on the same box: `bench.py --no-extras` per workload with BGNN_LIB pointing at each .so, the
 per-kernel-class times (HIP events, ms per step) side by side.
 
+A variant may also be an environment switch of ONE build: name=path:VAR=value[:VAR2=value2].
+
 usage: python tools/ab_bench.py [--libs base=bathymetric-gnn_amd/libbgnn_hip_base.so new=bathymetric-gnn_amd/libbgnn_hip.so]
                                 [--workloads tiles c3] [--steps 10] [--repeat 2]
 """
@@ -22,7 +24,9 @@ def run(lib, workload, steps, extra):
     if workload != "tiles":
         args += ["--workload", workload]
     args += extra
+    lib, *sets = lib.split(":")
     env = dict(os.environ, BGNN_LIB=os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib)
+    env.update(dict(x.split("=", 1) for x in sets))
     r = subprocess.run(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         raise SystemExit(f"{lib} {workload}: bench failed\n{r.stderr[-2000:]}")
