@@ -1120,6 +1120,7 @@ struct GridOut {             // optional fused node -> grid outputs (bgnn_infer_
 // training-mode forward: BatchNorm statistics of this batch, written layer by layer ([sum of layer widths] each)
 struct TrainOut {
   float *mean, *var_unbiased;
+  const bgnn_dropout *dp = nullptr;      // active dropout (bgnn_forward_train_dropout)
 };
 
 static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_auto, float thr_review,
@@ -1153,6 +1154,11 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   void *bnws = nullptr;
   if (tr) BGNN_TRY(ctx_workspace(ctx, 5, bn_train_workspace_bytes(maxw >= 256 ? 256 : maxw), &bnws));
   size_t tr_off = 0;
+  // training mode with active dropout: x [rows][width] *= keep / (1 - p) in place (stream ids: bgnn.h, bgnn_dropout)
+  const bgnn_dropout *dp = tr ? tr->dp : nullptr;
+  auto drop = [&](float *x, int width, float p, uint32_t stream) {
+    return dp && p > 0.0f ? launch_dropout(ctx, x, width, width, dm, rows, make_drop_spec(p, dp->seed, stream)) : BGNN_OK;
+  };
   auto batch_norm = [&](float *z, const BgnnLayer &L, int relu) {          // z [rows][L.width], in place
     const int rc = launch_bn_train(ctx, z, L.width, L.width, rows, dm, L.bn_w, L.bn_b, d.bn_eps, relu, bnws,
                                    tr->mean ? tr->mean + tr_off : nullptr, tr->var_unbiased ? tr->var_unbiased + tr_off : nullptr);
@@ -1176,6 +1182,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     // GCN / GraphSAGE / GIN backbones (gnn.py:120-143; torch_geometric default arguments): plain gathers + GEMMs.
     // Not the hot path: no fusion beyond BatchNorm / bias / ReLU folded into the neighbouring kernel.
     BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
+    if (dp) BGNN_TRY(drop(Y, hid, dp->p_extractor, 1));
     BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->fe_W1t, m->fe_b1, X, hid, dm, rows, hid, hid, 0));
     float *dinv = asdX;
     if (d.gnn_type == BGNN_GNN_GCN) BGNN_TRY(launch_degree_inv_sqrt(ctx, g, dinv));
@@ -1204,6 +1211,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
         if (tr) {
           BGNN_TRY(launch_neighbor_reduce(ctx, g, 1, Y, hid, dinv, m->ones, L.tr_bias, 0, X, hid, nullptr));
           BGNN_TRY(batch_norm(X, L, relu));
+          if (dp && relu) BGNN_TRY(drop(X, hid, dp->p_features, 64 + (uint32_t)l));
         } else {
           BGNN_TRY(launch_neighbor_reduce(ctx, g, 1, Y, hid, dinv, L.scale, L.shift, relu, X, hid, nullptr));
         }
@@ -1212,6 +1220,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
         if (tr) {
           BGNN_TRY(launch_gemm_f32(ctx, Y, 2 * hid, L.tr_Wt, L.tr_bias, X, hid, dm, rows, 2 * hid, hid, 0));
           BGNN_TRY(batch_norm(X, L, relu));
+          if (dp && relu) BGNN_TRY(drop(X, hid, dp->p_features, 64 + (uint32_t)l));
         } else {
           BGNN_TRY(launch_gemm_f32(ctx, Y, 2 * hid, L.Wt, L.b2, X, hid, dm, rows, 2 * hid, hid, relu));
         }
@@ -1221,6 +1230,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
         if (tr) {
           BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.tr_Wt, L.tr_bias, Y, hid, dm, rows, hid, hid, 0));
           BGNN_TRY(batch_norm(Y, L, relu));
+          if (dp && relu) BGNN_TRY(drop(Y, hid, dp->p_features, 64 + (uint32_t)l));
         } else {
           BGNN_TRY(launch_gemm_f32(ctx, X, hid, L.Wt2, L.b2, Y, hid, dm, rows, hid, hid, relu));
         }
@@ -1236,15 +1246,18 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       const float *wsplit = sm == 3 ? m->l0f_Wbf : sm == 2 && m->l0f_Wsp16 ? m->l0f_Wsp16 : sm ? m->l0f_Wsp : nullptr;
       // extractor layer 1 runs inside the lin_0 GEMM (same instructions, h1 never leaves the registers) wherever that GEMM takes
       // its W-resident form; below 32 768 rows (exact path) it keeps its own launch -- the results are bit-identical either way
-      const bool front = hid == 64 && gemm_front_available(ctx, rows, L0.heads * hid, smode);
+      // (active extractor dropout sits between the two: the first layer then keeps its own launch)
+      const bool front = hid == 64 && gemm_front_available(ctx, rows, L0.heads * hid, smode) && !(dp && dp->p_extractor > 0.0f);
       BGNN_REQUIRE(front || sm != 3, "matrix_path = bf16 needs fused_front = 1");
       if (!front) BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
+      if (!front && dp) BGNN_TRY(drop(Y, hid, dp->p_extractor, 1));
       BGNN_TRY(launch_gemm_f32(ctx, front ? g->d_x8 : Y, front ? 8 : hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid,
                                L0.heads * hid, 0, L0.att_src, L0.att_dst, asdX, L0.heads, hid, wsplit, smode,
                                front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr, front && smode == 0 ? m->l0f_Wpm : nullptr));
     } else {
       BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
+      if (dp) BGNN_TRY(drop(X, hid, dp->p_extractor, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));
       BGNN_TRY(launch_gemm_f32(ctx, Y, L0.d_in, L0.Wt, nullptr, X, L0.heads * hid, dm, rows, L0.d_in, L0.heads * hid, 0,
                                L0.att_src, L0.att_dst, asdX, L0.heads, hid));
@@ -1262,16 +1275,20 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
     Ltrain.scale = m->ones; Ltrain.shift = Leval.tr_bias;
     const BgnnLayer &L = tr ? Ltrain : Leval;
     const int relu = L.concat ? 1 : 0;
+    // GATConv(dropout = p) in training mode: the coefficients are thinned inside the plain aggregate kernel
+    const bool att_drop = dp && dp->p_attention > 0.0f;
+    const DropSpec att_spec = att_drop ? make_drop_spec(dp->p_attention, dp->seed, 16 + (uint32_t)l) : DropSpec{};
     if (l + 1 < nl) {
       const BgnnLayer &Ln = m->layers[l + 1];
       int rc = use_fused ? launch_fused_layer_next(ctx, g, L, Ln, hid, V3, X, asdX, Y, asdY) : BGNN_ERR_UNSUPPORTED;
       if (rc == BGNN_OK) { std::swap(X, Y); std::swap(asdX, asdY); continue; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
       BGNN_REQUIRE(!bf16, "matrix_path = bf16: no fused instance for layer %d of this model / graph", (int)l);
-      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
-      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
+      rc = att_drop ? BGNN_ERR_UNSUPPORTED : launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
+      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu, att_drop ? &att_spec : nullptr);
       BGNN_TRY(rc);
       if (tr) BGNN_TRY(batch_norm(Y, L, relu));
+      if (dp && relu) BGNN_TRY(drop(Y, L.width, dp->p_features, 64 + (uint32_t)l));
       BGNN_TRY(launch_gemm_f32(ctx, Y, Ln.d_in, Ln.Wt, nullptr, X, Ln.heads * hid, dm, rows, Ln.d_in, Ln.heads * hid, 0,
                                Ln.att_src, Ln.att_dst, asdX, Ln.heads, hid));
     } else {
@@ -1282,10 +1299,11 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       if (rc == BGNN_OK) { if (grids) grids->done = true; return BGNN_OK; }
       if (rc != BGNN_ERR_UNSUPPORTED) return rc;
       BGNN_REQUIRE(!bf16, "matrix_path = bf16: no fused instance for the last layer of this model / graph");
-      rc = launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
-      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
+      rc = att_drop ? BGNN_ERR_UNSUPPORTED : launch_gat_aggregate_tiled(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu);
+      if (rc == BGNN_ERR_UNSUPPORTED) rc = launch_gat_aggregate(ctx, g, L, hid, d.edge_dim, X, asdX, Y, tr ? 0 : relu, att_drop ? &att_spec : nullptr);
       BGNN_TRY(rc);
       if (tr) BGNN_TRY(batch_norm(Y, L, relu));
+      if (dp && relu) BGNN_TRY(drop(Y, L.width, dp->p_features, 64 + (uint32_t)l));     // (a single-layer backbone has no ReLU: never)
     }
   }
   if (o->hidden) {
@@ -1295,6 +1313,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   // heads (gnn.py:392-406)
   BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->hd_W0t, m->hd_b0, hidb, m->head_hidden_total, dm, rows, hid,
                            m->head_hidden_total, 1));
+  if (dp) BGNN_TRY(drop(hidb, m->head_hidden_total, dp->p_heads, 2));
   BGNN_TRY(launch_heads_final(ctx, m, hidb, m->head_hidden_total, dm, rows, thr_auto, thr_review, o));
   return BGNN_OK;
 }
@@ -1356,7 +1375,17 @@ int bgnn_heads(bgnn_ctx *ctx, bgnn_model *m, const float *hidden, int64_t n_node
 
 int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float *bn_batch_mean, float *bn_batch_var,
                        const bgnn_outputs *o) {
+  return bgnn_forward_train_dropout(ctx, m, g, nullptr, bn_batch_mean, bn_batch_var, o);
+}
+
+int bgnn_forward_train_dropout(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, const bgnn_dropout *dropout, float *bn_batch_mean,
+                               float *bn_batch_var, const bgnn_outputs *o) {
   BGNN_REQUIRE(ctx && m && g && o, "bgnn_forward_train: NULL argument");
+  if (dropout) {
+    const float ps[4] = {dropout->p_extractor, dropout->p_attention, dropout->p_features, dropout->p_heads};
+    for (float p : ps) BGNN_REQUIRE(p >= 0.0f && p < 1.0f, "bgnn_forward_train_dropout: dropout probability %g outside [0, 1)", (double)p);
+    if (ps[0] == 0.0f && ps[1] == 0.0f && ps[2] == 0.0f && ps[3] == 0.0f) dropout = nullptr;
+  }
   BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward_train: model/graph belong to another context");
   BGNN_REQUIRE(!o->action && !o->needs_review && !o->auto_correct, "bgnn_forward_train: the deployment flags belong to predict()");
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1365,7 +1394,7 @@ int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float *bn_ba
   BGNN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   // torch.nn.functional.batch_norm in training mode refuses a single row the same way
   BGNN_REQUIRE(c[0] != 1, "Expected more than 1 value per channel when training, got input size [1, %d]", m->layers[0].width);
-  TrainOut tr{bn_batch_mean, bn_batch_var};
+  TrainOut tr{bn_batch_mean, bn_batch_var, dropout};
   return forward_impl(ctx, m, g, 0.85f, 0.6f, o, nullptr, &tr);
 }
 

@@ -284,8 +284,34 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
                     int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0,
                     const float *front_W0t = nullptr, const float *front_b0 = nullptr, const float *Wt_pm = nullptr);
 bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode);
+// training-mode dropout (bgnn.h, bgnn_dropout): one counter-based draw per element, see there
+struct DropSpec {
+  uint32_t thr = 0;          // keep <=> hash >= thr   (floor(p * 2^32); 0: nothing is dropped)
+  float scale = 1.0f;        // 1 / (1 - p)
+  uint64_t seed = 0;
+  uint32_t stream = 0;
+};
+__host__ __device__ inline uint32_t bgnn_drop_hash(uint64_t seed, uint32_t stream, uint64_t index) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)stream + 1ull) + 0xD1B54A32D192ED03ull * index;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+inline DropSpec make_drop_spec(float p, uint64_t seed, uint32_t stream) {
+  DropSpec d;
+  if (p > 0.0f) {
+    const double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    d.scale = (float)(1.0 / (1.0 - (double)p));
+  }
+  d.seed = seed; d.stream = stream;
+  return d;
+}
+// x [M][width] (leading dimension ld) *= keep / (1 - p), in place; M from d_m
+int launch_dropout(bgnn_ctx *ctx, float *x, int width, int ld, const int64_t *d_m, int64_t max_rows, const DropSpec &d);
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
-                         const float *asd, float *out, int relu);
+                         const float *asd, float *out, int relu, const DropSpec *attention_drop = nullptr);
 int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
                                const float *asd, float *out, int relu);
 // fused K4 + next K3 (EPI_NEXT) / K4(last) + K5 + K6 (EPI_HEADS); BGNN_ERR_UNSUPPORTED when no instance fits

@@ -27,6 +27,7 @@ struct AggArgs {
   float *out;             // [N][HC]
   const int64_t *d_m;
   int K, H, C, ED, relu;
+  DropSpec drop;          // training mode: dropout on the attention coefficients (thr 0: none)
 };
 
 constexpr int AGG_MAXDEG = 16;   // ELL widths 4 / 8 / 16; longer CSR rows take the two-pass loop
@@ -127,6 +128,12 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
   const float pself = expf(self_lg - mx);
   den += pself;
   den += 1e-16f;
+  // training mode, GATConv(dropout = p): alpha of edge j -> i and head hh is kept (x 1 / (1 - p)) or zeroed after the softmax
+  auto dropped = [&](float al, int64_t j) -> float {
+    if (a.drop.thr == 0) return al;
+    const uint64_t idx = (((uint64_t)i << 32) | (uint64_t)(uint32_t)j) * (uint64_t)H + (uint64_t)hh;
+    return bgnn_drop_hash(a.drop.seed, a.drop.stream, idx) >= a.drop.thr ? al * a.drop.scale : 0.0f;
+  };
   // pass 3: weighted aggregate of neighbour rows
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const float *xwl = a.xw + l * 4;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
       if (beg + b < end) {
         const int j = a.nbr[beg + b];
         if (j >= 0) {
-          const float al = ev[b] / den;
+          const float al = dropped(ev[b] / den, j);
           const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HC);
           acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
         }
@@ -151,13 +158,13 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
       for (int f = 0; f < ED; ++f) dot += a.eattr[p * ED + f] * v[f];
       lg += dot;
       lg = lg > 0.0f ? lg : 0.2f * lg;
-      const float al = expf(lg - mx) / den;
+      const float al = dropped(expf(lg - mx) / den, j);
       const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HC);
       acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
     }
   }
   {
-    const float al = pself / den;
+    const float al = dropped(pself / den, i);
     const float4 x = *reinterpret_cast<const float4 *>(xwl + i * HC);
     acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
   }
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
 }
 
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
-                         const float *asd, float *out, int relu) {
+                         const float *asd, float *out, int relu, const DropSpec *attention_drop) {
   const int64_t max_rows = g->row_capacity;
   if (max_rows <= 0) return BGNN_OK;
   BGNN_TRY(ensure_stencil_table(g));
@@ -184,6 +191,7 @@ int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L,
   a.rowptr = g->kind == 1 ? g->d_rowptr : nullptr;
   a.V = L.V; a.scale = L.scale; a.shift = L.shift; a.out = out; a.d_m = g->d_counts;
   a.K = g->K; a.H = L.heads; a.C = C; a.ED = ED; a.relu = relu;
+  if (attention_drop) a.drop = *attention_drop;
   const int HC = L.heads * C, LPN = HC / 4;
   const int npw = 64 / LPN;
   const int64_t waves = (max_rows + npw - 1) / npw;

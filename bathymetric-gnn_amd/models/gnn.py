@@ -5,7 +5,7 @@ The module tree and parameter names equal the reference's (and torch_geometric's
 ``model.feature_extractor.mlp[0].in_features`` (read at ``scripts/inference_native.py:147``) works.
 The torch parameters are only the weight container: ``forward`` packs them once into the library's
 blob (``bgnn_model_create``) and runs the hand-written HIP kernels (``bgnn_forward``).  Inference
-(eval) semantics, plus the training-mode FORWARD with batch-statistics BatchNorm when every dropout probability is 0.
+(eval) semantics, plus the training-mode FORWARD: batch-statistics BatchNorm and the reference's four dropouts (counter-based draws).
 """
 from __future__ import annotations
 
@@ -399,8 +399,10 @@ class BathymetricGNN(nn.Module):
             widths = [n.module.num_features for n in self.gnn.norms]
             mean = torch.empty(sum(widths), dtype=torch.float32, device=dev)
             var = torch.empty_like(mean)
+            dp = self._dropout_spec()
             ctx.begin()
-            rt.check(ctx.lib.bgnn_forward_train(ctx.handle, model_h, g._handle, rt.ptr(mean), rt.ptr(var), C.byref(o)))
+            rt.check(ctx.lib.bgnn_forward_train_dropout(ctx.handle, model_h, g._handle, C.byref(dp) if dp is not None else None,
+                                                        rt.ptr(mean), rt.ptr(var), C.byref(o)))
             ctx.end()
             with torch.no_grad():                       # torch.nn.BatchNorm1d's bookkeeping (momentum None = cumulative average)
                 off = 0
@@ -445,25 +447,43 @@ class BathymetricGNN(nn.Module):
         ctx.end()
         return out
 
-    def _dropout_probabilities(self):
-        ps = [m.p for m in self.modules() if isinstance(m, nn.Dropout)]
-        ps += [c.dropout for c in self.gnn.convs if isinstance(c, GATConv)]      # attention dropout (gnn.py:125-132)
-        ps.append(self.gnn.dropout)                                              # F.dropout between the layers (:186)
-        return ps
+    def _dropout_spec(self):
+        """The four dropout probabilities of the reference's training-mode forward (models/gnn.py:57 extractor, :125-132 GATConv
+        attention, :186 between the layers, :206 / :229 / :253 heads) and a seed -> ``rt.Dropout``, or None when all are 0.
+        The seed is ``self.dropout_seed`` if set, else drawn from torch's default generator (so ``torch.manual_seed`` makes a
+        run reproducible); the one used is left in ``self.last_dropout_seed``.  WHICH values are dropped is a counter-based
+        draw of this library (include/bgnn.h), not torch's own stream."""
+        def one(ps, what):
+            ps = sorted(set(float(p) for p in ps))
+            if len(ps) > 1:
+                raise NotImplementedError(f"training-mode forward: the {what} dropout modules carry different probabilities {ps}")
+            return ps[0] if ps else 0.0
+        heads = [h for h in (self.classification_head, self.confidence_head, self.correction_head) if h is not None]
+        p_ext = one([m.p for m in self.feature_extractor.modules() if isinstance(m, nn.Dropout)], "feature extractor")
+        p_att = one([c.dropout for c in self.gnn.convs if isinstance(c, GATConv)], "GATConv")
+        p_feat = float(self.gnn.dropout)
+        p_head = one([m.p for h in heads for m in h.modules() if isinstance(m, nn.Dropout)], "head")
+        for p in (p_ext, p_att, p_feat, p_head):
+            if not 0.0 <= p < 1.0:
+                raise ValueError(f"dropout probability has to be in [0, 1), but got {p}")
+        if p_ext == p_att == p_feat == p_head == 0.0:
+            return None
+        seed = getattr(self, "dropout_seed", None)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self.last_dropout_seed = int(seed)
+        return rt.Dropout(p_ext, p_att, p_feat, p_head, int(seed))
 
     def forward(self, data) -> Dict[str, torch.Tensor]:
         """class_logits [N,C], class_probs [N,C], predicted_class [N] i64, confidence [N],
         correction [N] (reference :360-408).
 
         ``eval()``: running statistics, dropout the identity.  ``train()`` (forward only, there is no backward pass
-        here): every BatchNorm layer normalises with the statistics of this batch and moves its running statistics
-        (``bgnn_forward_train``); that needs every dropout probability to be 0 -- active dropout draws from torch's
-        generator and is refused rather than silently skipped."""
+        here): every BatchNorm layer normalises with the statistics of this batch and moves its running statistics, and
+        the four dropouts of the reference are active with their modules' probabilities (``bgnn_forward_train_dropout``;
+        see ``_dropout_spec`` for the seed)."""
         if not self.training:
             return self._run(data, 0.85, 0.6, with_flags=False)
-        if any(p > 0 for p in self._dropout_probabilities()):
-            raise NotImplementedError("BathymetricGNN.forward in training mode with dropout > 0: the MI355X path has no "
-                                      "random dropout (construct the model with dropout=0.0, or call .eval())")
         return self._run(data, 0.85, 0.6, with_flags=False, train=True)
 
     def predict(self, data, auto_correct_threshold: float = 0.85, review_threshold: float = 0.6):

@@ -26,7 +26,7 @@ EDGE_FEATURE_IDS = {"distance": 0, "depth_difference": 1, "slope": 2}
 EF_ZERO = 3
 
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4
-ABI_VERSION = 5
+ABI_VERSION = 6
 MATRIX_PATHS = {"exact_f32": 0, "bf16x3": 1, "fp16x3": 2, "bf16": 3}
 
 
@@ -54,6 +54,12 @@ class Outputs(C.Structure):
     _fields_ = [("class_logits", C.c_void_p), ("class_probs", C.c_void_p), ("predicted_class", C.c_void_p),
                 ("confidence", C.c_void_p), ("correction", C.c_void_p), ("action", C.c_void_p),
                 ("needs_review", C.c_void_p), ("auto_correct", C.c_void_p), ("hidden", C.c_void_p)]
+
+
+class Dropout(C.Structure):
+    """bgnn_dropout: the four dropout probabilities of a training-mode forward and the seed of its counter-based draws."""
+    _fields_ = [("p_extractor", C.c_float), ("p_attention", C.c_float), ("p_features", C.c_float), ("p_heads", C.c_float),
+                ("seed", C.c_uint64)]
 
 
 # symbol -> (restype, argtypes); every symbol include/bgnn.h declares
@@ -85,6 +91,8 @@ _SIGNATURES = {
     "bgnn_feature_extractor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgnn_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.POINTER(Outputs)]),
     "bgnn_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Outputs)]),
+    "bgnn_forward_train_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Dropout), C.c_void_p, C.c_void_p,
+                                             C.POINTER(Outputs)]),
     "bgnn_stitch_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
                           [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4),
     "bgnn_cut_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BGNN_ABI_VERSION 5
+#define BGNN_ABI_VERSION 6
 
 #define BGNN_OK 0
 #define BGNN_ERR_INVALID (-1)     /* bad argument (-> ValueError in the Python mirror)   */
@@ -241,6 +241,28 @@ int bgnn_heads(bgnn_ctx *ctx, bgnn_model *model, const float *hidden, int64_t n_
  * Synchronises the stream once (reads the node count). */
 int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, float *bn_batch_mean, float *bn_batch_var,
                        const bgnn_outputs *out);
+
+/* The same forward with ACTIVE dropout (ABI 6).  The reference drops at four places, all reproduced here:
+ *   p_extractor  nn.Dropout after the ReLU of LocalFeatureExtractor's first Linear (models/gnn.py:55-57)
+ *   p_attention  GATConv(dropout=...): on the attention coefficients after the softmax, self loops included (:125-132)
+ *   p_features   F.dropout after the ReLU of every GNN layer but the last (:184-186)
+ *   p_heads      nn.Dropout on the hidden units of the three heads (:206, :229, :253)
+ * A kept value is multiplied by 1 / (1 - p) (float32), a dropped one is 0.  WHICH values are dropped cannot follow torch's
+ * generator (its stream differs between CPU and GPU builds of torch itself); it is a documented counter-based Bernoulli
+ * draw instead, a pure function of (seed, place, element) -- reproducible, independent of launch geometry, and restated on
+ * the host by oracle/gat_cpu.py so that the parity tests run the oracle with the very same masks:
+ *   z = seed + 0x9E3779B97F4A7C15 * (stream + 1) + 0xD1B54A32D192ED03 * index        (mod 2^64)
+ *   z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;  z = (z ^ z >> 27) * 0x94D049BB133111EB;  z ^= z >> 31      (splitmix64's finaliser)
+ *   keep  <=>  (z >> 32) >= floor(p * 2^32)
+ * stream / index: extractor 1 / row * hidden + column; heads 2 / row * head_hidden_total + column (classification |
+ * confidence | correction units); features 64 + layer / row * width + column; attention 16 + layer /
+ * ((target << 32 | source) * heads + head), a self loop having source == target.  Every p must lie in [0, 1). */
+typedef struct bgnn_dropout {
+  float p_extractor, p_attention, p_features, p_heads;
+  uint64_t seed;
+} bgnn_dropout;
+int bgnn_forward_train_dropout(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, const bgnn_dropout *dropout,
+                               float *bn_batch_mean, float *bn_batch_var, const bgnn_outputs *out);
 
 /* BathymetricPipeline._process_tile (models/pipeline.py:243-314) and
  * NativeVRProcessor._extract_results_from_outputs (scripts/inference_native.py:181-204)

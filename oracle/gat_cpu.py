@@ -53,9 +53,53 @@ def num_layers_of(sd: Mapping) -> int:
     return n
 
 
+class CounterDropout:
+    """Training-mode dropout with the library's counter-based draws (include/bgnn.h, ``bgnn_dropout``): the reference's four
+    dropouts (models/gnn.py:57, :125-132, :186, :206 / :229 / :253) keep a value with probability 1 - p and multiply it by
+    1 / (1 - p); WHICH values go is a pure function of (seed, stream, index), restated here in numpy so that the oracle runs
+    with the very masks the kernels use (torch's own generator stream cannot be followed: it differs between torch's CPU and
+    GPU builds).  hash = splitmix64's finaliser of seed + 0x9E3779B97F4A7C15 (stream + 1) + 0xD1B54A32D192ED03 index."""
+
+    def __init__(self, seed: int, p_extractor: float = 0.0, p_attention: float = 0.0, p_features: float = 0.0, p_heads: float = 0.0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.p_extractor, self.p_attention, self.p_features, self.p_heads = p_extractor, p_attention, p_features, p_heads
+
+    @staticmethod
+    def hash32(seed: int, stream: int, index) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            idx = np.asarray(index, dtype=np.uint64)
+            z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(stream + 1) + np.uint64(0xD1B54A32D192ED03) * idx)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        return (z >> np.uint64(32)).astype(np.uint32)
+
+    def _mult(self, p: float, stream: int, index, dtype) -> torch.Tensor:
+        """keep / (1 - p) per element, the scale rounded to float32 as the kernels hold it."""
+        thr = min(int(float(np.float32(p)) * 4294967296.0), 4294967295)
+        keep = self.hash32(self.seed, stream, index) >= np.uint32(thr)
+        scale = np.float32(1.0 / (1.0 - float(np.float32(p))))
+        return torch.as_tensor(np.where(keep, scale, np.float32(0.0)).astype(np.float32)).to(dtype)
+
+    def elementwise(self, x: torch.Tensor, p: float, stream: int) -> torch.Tensor:
+        if p <= 0.0:
+            return x
+        n, w = x.shape
+        return x * self._mult(p, stream, np.arange(n * w, dtype=np.uint64), x.dtype).view(n, w)
+
+    def attention(self, alpha: torch.Tensor, src, dst, layer: int) -> torch.Tensor:
+        if self.p_attention <= 0.0:
+            return alpha
+        E, H = alpha.shape
+        with np.errstate(over="ignore"):
+            pair = (dst.numpy().astype(np.uint64) << np.uint64(32)) | src.numpy().astype(np.uint64)
+            idx = pair[:, None] * np.uint64(H) + np.arange(H, dtype=np.uint64)[None, :]
+        return alpha * self._mult(self.p_attention, 16 + layer, idx.reshape(-1), alpha.dtype).view(E, H)
+
+
 def gat_conv(x, edge_index, edge_attr, sd: Mapping, prefix: str, concat: bool, dtype,
-             return_alpha: bool = False):
-    """One torch_geometric GATConv forward (eval mode)."""
+             return_alpha: bool = False, dropout: "CounterDropout" = None, layer: int = 0):
+    """One torch_geometric GATConv forward (eval mode; ``dropout``: training mode's ``F.dropout`` on alpha)."""
     N = x.shape[0]
     W = _lin_weight(sd, prefix, dtype)                    # [H*C, D]
     att_src = _t(sd[prefix + "att_src"], dtype)           # [1,H,C]
@@ -91,6 +135,8 @@ def gat_conv(x, edge_index, edge_attr, sd: Mapping, prefix: str, concat: bool, d
     p = torch.exp(e - m.index_select(0, dst2))
     s = torch.zeros(N, H, dtype=dtype).index_add_(0, dst2, p)
     alpha = p / (s.index_select(0, dst2) + 1e-16)
+    if dropout is not None:
+        alpha = dropout.attention(alpha, src2, dst2, layer)
     msg = alpha.unsqueeze(-1) * xs.index_select(0, src2)           # [E',H,C]
     out = torch.zeros(N, H, C, dtype=dtype).index_add_(0, dst2, msg)
     out = out.reshape(N, H * C) if concat else out.mean(dim=1)
@@ -117,8 +163,10 @@ def batch_norm_train(x, sd: Mapping, prefix: str, dtype, stats: dict, eps: float
     return out
 
 
-def _mlp2(x, sd, p0, p1, dtype):
+def _mlp2(x, sd, p0, p1, dtype, hidden_mult=None):
     h = F.relu(F.linear(x, _t(sd[p0 + ".weight"], dtype), _t(sd[p0 + ".bias"], dtype)))
+    if hidden_mult is not None:                           # nn.Dropout between the two Linears, training mode
+        h = h * hidden_mult
     return F.linear(h, _t(sd[p1 + ".weight"], dtype), _t(sd[p1 + ".bias"], dtype))
 
 
@@ -173,16 +221,20 @@ def gin_conv(x, edge_index, sd: Mapping, prefix: str, dtype):
     return _mlp2(s, sd, prefix + "nn.0", prefix + "nn.2", dtype)
 
 
-def backbone(x, edge_index, edge_attr, sd: Mapping, dtype, train_stats: dict = None):
-    """feature extractor + GNN backbone -> [N, hidden].  ``train_stats`` (a dict): training-mode BatchNorm (dropout 0),
-    the updated running statistics are left in it."""
+def backbone(x, edge_index, edge_attr, sd: Mapping, dtype, train_stats: dict = None, dropout: CounterDropout = None):
+    """feature extractor + GNN backbone -> [N, hidden].  ``train_stats`` (a dict): training-mode BatchNorm, the updated
+    running statistics are left in it; ``dropout``: training mode's active dropouts (CounterDropout)."""
     L = num_layers_of(sd)
     kind = gnn_type_of(sd)
-    h = _mlp2(x, sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", dtype)
+    ext_mult = None
+    if dropout is not None and dropout.p_extractor > 0:
+        hid = _t(sd["feature_extractor.mlp.0.weight"], dtype).shape[0]
+        ext_mult = dropout.elementwise(torch.ones(x.shape[0], hid, dtype=dtype), dropout.p_extractor, 1)
+    h = _mlp2(x, sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", dtype, ext_mult)
     for l in range(L):
         last = l == L - 1
         if kind == "GAT":
-            h = gat_conv(h, edge_index, edge_attr, sd, f"gnn.convs.{l}.", concat=not last, dtype=dtype)
+            h = gat_conv(h, edge_index, edge_attr, sd, f"gnn.convs.{l}.", concat=not last, dtype=dtype, dropout=dropout, layer=l)
         elif kind == "GCN":
             h = gcn_conv(h, edge_index, sd, f"gnn.convs.{l}.", dtype)
         elif kind == "GraphSAGE":
@@ -195,28 +247,38 @@ def backbone(x, edge_index, edge_attr, sd: Mapping, dtype, train_stats: dict = N
             h = batch_norm_train(h, sd, f"gnn.norms.{l}.module.", dtype, train_stats)
         if not last:
             h = F.relu(h)
+            if dropout is not None:
+                h = dropout.elementwise(h, dropout.p_features, 64 + l)
     return h
 
 
-def forward(sd: Mapping, x, edge_index, edge_attr, dtype=torch.float32, train_stats: dict = None) -> Dict[str, torch.Tensor]:
-    """BathymetricGNN.forward (models/gnn.py:360-408): eval mode, or -- with ``train_stats`` a dict -- training mode with
-    every dropout probability 0 (batch-statistics BatchNorm)."""
+def forward(sd: Mapping, x, edge_index, edge_attr, dtype=torch.float32, train_stats: dict = None,
+            dropout: CounterDropout = None) -> Dict[str, torch.Tensor]:
+    """BathymetricGNN.forward (models/gnn.py:360-408): eval mode, or -- with ``train_stats`` a dict -- training mode
+    (batch-statistics BatchNorm; ``dropout``: the active dropouts with the library's counter-based masks)."""
     x = _t(x, dtype); edge_attr = _t(edge_attr, dtype)
     edge_index = _t(edge_index, torch.int64)
     with torch.no_grad():
-        h = backbone(x, edge_index, edge_attr, sd, dtype, train_stats)
-        logits = _mlp2(h, sd, "classification_head.mlp.0", "classification_head.mlp.3", dtype)
+        h = backbone(x, edge_index, edge_attr, sd, dtype, train_stats, dropout)
+        hm = [None, None, None]
+        if dropout is not None and dropout.p_heads > 0:
+            # the kernels hold the three heads' hidden units side by side: classification | confidence | correction
+            hh = _t(sd["classification_head.mlp.0.weight"], dtype).shape[0]
+            nh = 3 if "correction_head.mlp.0.weight" in sd else 2
+            m_all = dropout.elementwise(torch.ones(h.shape[0], nh * hh, dtype=dtype), dropout.p_heads, 2)
+            hm = [m_all[:, i * hh:(i + 1) * hh] if i < nh else None for i in range(3)]
+        logits = _mlp2(h, sd, "classification_head.mlp.0", "classification_head.mlp.3", dtype, hm[0])
         probs = F.softmax(logits, dim=-1)
         out = {
             "class_logits": logits,
             "class_probs": probs,
             "predicted_class": torch.argmax(probs, dim=-1),
             "confidence": torch.sigmoid(
-                _mlp2(h, sd, "confidence_head.mlp.0", "confidence_head.mlp.3", dtype)).squeeze(-1),
+                _mlp2(h, sd, "confidence_head.mlp.0", "confidence_head.mlp.3", dtype, hm[1])).squeeze(-1),
             "hidden": h,
         }
         if "correction_head.mlp.0.weight" in sd:
-            out["correction"] = _mlp2(h, sd, "correction_head.mlp.0", "correction_head.mlp.3", dtype).squeeze(-1)
+            out["correction"] = _mlp2(h, sd, "correction_head.mlp.0", "correction_head.mlp.3", dtype, hm[2]).squeeze(-1)
     return out
 
 

@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
   RESOLVE(bgnn_ctx_synchronize); RESOLVE(bgnn_ctx_stream); RESOLVE(bgnn_ctx_profile); RESOLVE(bgnn_ctx_profile_read);
   RESOLVE(bgnn_model_weight_count); RESOLVE(bgnn_model_create); RESOLVE(bgnn_model_destroy);
   RESOLVE(bgnn_graph_build); RESOLVE(bgnn_graph_from_edges); RESOLVE(bgnn_graph_destroy); RESOLVE(bgnn_graph_counts);
-  RESOLVE(bgnn_graph_export); RESOLVE(bgnn_graph_scatter); RESOLVE(bgnn_forward); RESOLVE(bgnn_forward_train); RESOLVE(bgnn_infer_tiles);
+  RESOLVE(bgnn_graph_export); RESOLVE(bgnn_graph_scatter); RESOLVE(bgnn_forward); RESOLVE(bgnn_forward_train); RESOLVE(bgnn_forward_train_dropout); RESOLVE(bgnn_infer_tiles);
   RESOLVE(bgnn_stitch_tiles); RESOLVE(bgnn_cut_tiles); RESOLVE(bgnn_tile_valid_counts); RESOLVE(bgnn_vr_unpack);
   RESOLVE(bgnn_vr_apply); RESOLVE(bgnn_feature_extractor); RESOLVE(bgnn_heads);
   RESOLVE(bgnn_ctx_set_option); RESOLVE(bgnn_ctx_get_option); RESOLVE(bgnn_build_id);

@@ -685,6 +685,101 @@ def test_training_mode_forward_batch_statistics(kind, layers, gpu_device):
     assert (m(g)["class_logits"].cpu() - ref_eval2["class_logits"]).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("kind,layers", [("GAT", 4), ("GAT", 1), ("GCN", 2), ("GraphSAGE", 2), ("GIN", 3)])
+def test_training_mode_forward_with_active_dropout(kind, layers, gpu_device):
+    """BathymetricGNN.forward in train() with the reference's four dropouts ACTIVE (models/gnn.py:57 extractor, :125-132
+    GATConv attention, :186 between the layers, :206 / :229 / :253 heads), each place with its own probability.  The draws are
+    the library's counter-based ones (include/bgnn.h, bgnn_dropout) -- torch's generator stream cannot be followed -- so the
+    oracle runs the same forward with the SAME masks (oracle.gat_cpu.CounterDropout, a numpy restatement of the hash pinned to
+    splitmix64's published output): 1e-4 on every output.  Also: same seed -> same bits, another seed -> other values, and the
+    drop fractions the outputs imply are the requested ones (checked on the masks the oracle shares with the kernels)."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    from bathymetric_gnn_amd.models.gnn import GATConv
+    sd = synthetic.synthetic_state_dict(in_channels=7, gnn_type=kind, num_layers=layers, seed=33)
+    m = BathymetricGNN(in_channels=7, gnn_type=kind, num_gnn_layers=layers, edge_dim=3, dropout=0.1)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device)
+    p_ext, p_att, p_feat, p_head = 0.1, 0.2, 0.15, 0.25
+    m.feature_extractor.mlp[2].p = p_ext
+    for c in m.gnn.convs:
+        if isinstance(c, GATConv):
+            c.dropout = p_att
+    m.gnn.dropout = p_feat
+    for h in (m.classification_head, m.confidence_head, m.correction_head):
+        h.mlp[2].p = p_head
+    gb = GraphBuilder()
+    tiles = [synthetic.synthetic_tile(37, 45, 3, "V1"), synthetic.synthetic_tile(20, 64, 4, "V0")]
+    g = gb.build_graphs([t[0] for t in tiles], [t[1] for t in tiles], None, [(0.5, 0.5)] * 2)
+    ogs = [graph_cpu.build_graph(t[0], t[1], None, (0.5, 0.5)) for t in tiles]
+    n0 = ogs[0].x.shape[0]
+    x = np.concatenate([o.x for o in ogs]); ea = np.concatenate([o.edge_attr for o in ogs])
+    ei = np.concatenate([ogs[0].edge_index, ogs[1].edge_index + n0], axis=1)
+
+    m.train()
+    m.dropout_seed = 20261005
+    out = {k: v.clone() for k, v in m(g).items()}
+    drop = gat_cpu.CounterDropout(m.last_dropout_seed, p_ext, p_att if kind == "GAT" else 0.0, p_feat, p_head)
+    stats = {}
+    ref = gat_cpu.forward(sd, x, ei, ea, train_stats=stats, dropout=drop)
+    for k in ("class_logits", "confidence", "correction"):
+        assert (out[k].cpu() - ref[k]).abs().max().item() < TOL, k
+    # the running statistics moved by the statistics of the THINNED activations, as torch would move them
+    for l, n in enumerate(m.gnn.norms):
+        pre = f"gnn.norms.{l}.module."
+        assert (n.module.running_mean.cpu() - stats[pre + "running_mean"]).abs().max().item() < 1e-5
+        assert (n.module.running_var.cpu() - stats[pre + "running_var"]).abs().max().item() < 1e-5
+    # dropout is visible: the same step without it gives other logits
+    nodrop = gat_cpu.forward(sd, x, ei, ea, train_stats={})
+    assert (ref["class_logits"] - nodrop["class_logits"]).abs().max().item() > 1e-3
+    # same seed -> same bits (a pure function of seed / place / element); another seed -> other draws
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    again = m(g)
+    for k in ("class_logits", "confidence", "correction"):
+        assert torch.equal(again[k], out[k]), k
+    m.dropout_seed = 7
+    assert (m(g)["class_logits"] - out["class_logits"]).abs().max().item() > 1e-3
+    # the masks themselves: drop fractions as requested (the oracle's masks ARE the kernels': the outputs above agree)
+    N = x.shape[0]
+    frac = lambda t: float((t == 0).float().mean())
+    assert abs(frac(drop.elementwise(torch.ones(N, 64), p_ext, 1)) - p_ext) < 0.01
+    assert abs(frac(drop.elementwise(torch.ones(N, 96), p_head, 2)) - p_head) < 0.01
+    if kind == "GAT":
+        keep = ei[0] != ei[1]
+        src = torch.as_tensor(np.concatenate([ei[0][keep], np.arange(N)])); dst = torch.as_tensor(np.concatenate([ei[1][keep], np.arange(N)]))
+        assert abs(frac(drop.attention(torch.ones(src.shape[0], 4), src, dst, 0)) - p_att) < 0.01
+
+
+def test_training_mode_dropout_through_the_unfolded_extractor_and_big_batches(gpu_device):
+    """Active extractor dropout sits between the extractor's two Linears: the first keeps its own launch (the lin_0 GEMM's fused
+    front is bypassed) at the batch sizes where it would otherwise run inside that GEMM, and with fold_extractor = 0 too."""
+    from bathymetric_gnn_amd import runtime as rt, synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    sd = synthetic.synthetic_state_dict(in_channels=7, num_layers=2, seed=34)
+    m = BathymetricGNN(in_channels=7, num_gnn_layers=2, edge_dim=3, dropout=0.2)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).train()
+    m.dropout_seed = 11
+    tile = synthetic.synthetic_tile(200, 200, 5, "V1")
+    g = GraphBuilder().build_graph(tile[0], tile[1], None, (0.5, 0.5))
+    assert g.num_nodes >= 32768                                                  # the W-resident lin_0 GEMM's range
+    og = graph_cpu.build_graph(tile[0], tile[1], None, (0.5, 0.5))
+    ref = gat_cpu.forward(sd, og.x, og.edge_index, og.edge_attr, train_stats={},
+                          dropout=gat_cpu.CounterDropout(11, 0.2, 0.2, 0.2, 0.2))
+    a = m(g)["class_logits"].clone()
+    assert (a.cpu() - ref["class_logits"]).abs().max().item() < TOL
+    ctx = rt.get_context(gpu_device)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    try:
+        ctx.set_option("fold_extractor", 0)
+        b = m(g)["class_logits"].clone()
+    finally:
+        ctx.set_option("fold_extractor", 1)
+    assert (b.cpu() - ref["class_logits"]).abs().max().item() < TOL
+
+
 def test_training_mode_refusals(gpu_device):
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import GraphBuilder

@@ -119,12 +119,34 @@ def test_apply_results_arithmetic():
     assert depth[1, 1] == np.float32(1.0e6)
 
 
-def test_training_mode_with_dropout_is_refused_loudly():
-    """forward() in train() mode with an active dropout would need torch's random stream: refused, never silently eval."""
+def test_training_mode_dropout_spec_and_counter_hash():
+    """forward() in train() mode runs the reference's four dropouts with a counter-based draw (include/bgnn.h, bgnn_dropout):
+    the probabilities come from the modules, the seed from torch's generator (or ``dropout_seed``); modules of one place that
+    disagree are refused.  The oracle's numpy restatement of the hash is pinned to splitmix64's published first output."""
     import pytest
+    import torch
     from bathymetric_gnn_amd.models import BathymetricGNN
+    from oracle.gat_cpu import CounterDropout
+    # splitmix64, state 0: first output 0xE220A8397B1DCDAF (seed 0, stream 0, index 0 -> z = the golden-ratio increment)
+    assert int(CounterDropout.hash32(0, 0, [0])[0]) == 0xE220A839
+    h = CounterDropout.hash32(7, 2, np.arange(200000))
+    assert abs(float((h < int(0.25 * 2 ** 32)).mean()) - 0.25) < 5e-3
+    assert not np.array_equal(h, CounterDropout.hash32(7, 3, np.arange(200000)))
     m = BathymetricGNN(in_channels=7, edge_dim=3)            # reference default dropout 0.1, module starts in train()
     assert m.training
-    with pytest.raises(NotImplementedError, match="dropout"):
-        m(object())
-    assert all(p == 0 for p in BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)._dropout_probabilities())
+    torch.manual_seed(5)
+    a = m._dropout_spec()
+    torch.manual_seed(5)
+    b = m._dropout_spec()
+    assert a.seed == b.seed == m.last_dropout_seed
+    assert [round(x, 6) for x in (a.p_extractor, a.p_attention, a.p_features, a.p_heads)] == [0.1] * 4
+    m.dropout_seed = 99
+    assert m._dropout_spec().seed == 99
+    m.gnn.dropout = 0.3
+    m.classification_head.mlp[2].p = 0.2
+    with pytest.raises(NotImplementedError, match="head"):
+        m._dropout_spec()
+    m.confidence_head.mlp[2].p = 0.2; m.correction_head.mlp[2].p = 0.2
+    s = m._dropout_spec()
+    assert round(s.p_features, 6) == 0.3 and round(s.p_heads, 6) == 0.2
+    assert BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)._dropout_spec() is None
