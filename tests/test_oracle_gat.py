@@ -184,3 +184,36 @@ def test_training_mode_batch_norm_matches_the_formula():
     assert (stats["p.running_mean"].double() - (0.9 * torch.from_numpy(sd["p.running_mean"]).double() + 0.1 * mean)).abs().max() < 1e-6
     assert (stats["p.running_var"].double() - (0.9 * torch.from_numpy(sd["p.running_var"]).double() + 0.1 * xd.var(0, unbiased=True))).abs().max() < 1e-6
     assert np.array_equal(sd["p.running_mean"], sd["p.running_mean"].copy())       # the state dict itself is not touched
+
+
+def test_counter_dropout_semantics_of_the_oracle():
+    """oracle.CounterDropout (the training-mode dropouts with the library's counter-based draws): a kept value is scaled by
+    1 / (1 - p) and a dropped one is 0 (torch's F.dropout / nn.Dropout), the expectation is preserved, p = 0 is the identity,
+    the attention mask is a function of (target, source, head) only -- so it does not depend on the order of the edge list -- and
+    the forward with every probability 0 equals the plain training-mode forward."""
+    d = gat_cpu.CounterDropout(seed=123, p_extractor=0.25, p_attention=0.5, p_features=0.1, p_heads=0.3)
+    x = torch.ones(4000, 16)
+    y = d.elementwise(x, 0.25, 1)
+    vals = set(np.unique(y.numpy()).tolist())
+    assert vals == {0.0, float(np.float32(1.0 / 0.75))}
+    assert abs(float(y.mean()) - 1.0) < 0.02 and abs(float((y == 0).float().mean()) - 0.25) < 0.01
+    assert d.elementwise(x, 0.0, 1) is x
+    assert not torch.equal(y, d.elementwise(x, 0.25, 2))                      # another place, another stream
+    rng = np.random.default_rng(1)
+    E, N, H = 5000, 300, 4
+    src = torch.as_tensor(rng.integers(0, N, E)); dst = torch.as_tensor(rng.integers(0, N, E))
+    a = d.attention(torch.ones(E, H), src, dst, layer=2)
+    perm = torch.as_tensor(rng.permutation(E))
+    assert torch.equal(d.attention(torch.ones(E, H), src[perm], dst[perm], layer=2), a[perm])
+    assert abs(float((a == 0).float().mean()) - 0.5) < 0.02
+    assert not torch.equal(a, d.attention(torch.ones(E, H), src, dst, layer=3))
+    # the whole forward: all-zero probabilities change nothing
+    sd = synth.synthetic_state_dict(in_channels=7, num_layers=2, seed=5)
+    t = synth.synthetic_tile(24, 30, 2, "V0")
+    g = graph_cpu.build_graph(t[0], t[1], None, (0.5, 0.5))
+    assert g.x.shape[0] > 100
+    base = gat_cpu.forward(sd, g.x, g.edge_index, g.edge_attr, train_stats={})
+    same = gat_cpu.forward(sd, g.x, g.edge_index, g.edge_attr, train_stats={}, dropout=gat_cpu.CounterDropout(9))
+    assert torch.equal(base["class_logits"], same["class_logits"])
+    thin = gat_cpu.forward(sd, g.x, g.edge_index, g.edge_attr, train_stats={}, dropout=gat_cpu.CounterDropout(9, 0.2, 0.2, 0.2, 0.2))
+    assert (thin["class_logits"] - base["class_logits"]).abs().max().item() > 1e-3
