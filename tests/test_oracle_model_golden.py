@@ -55,7 +55,7 @@ def test_oracle_forward_wiring_and_predict_flags_match_reference_fixture(monkeyp
     z = _load("model_predict_wiring.npz")
     sd = {k[3:]: v for k, v in z.items() if k.startswith("sd.")}
 
-    def stand_in(x, edge_index, edge_attr, sd_, prefix, concat, dtype, return_alpha=False):
+    def stand_in(x, edge_index, edge_attr, sd_, prefix, concat, dtype, return_alpha=False, dropout=None, layer=0):
         return F.linear(x, gat_cpu._t(sd_[prefix + "lin.weight"], dtype), gat_cpu._t(sd_[prefix + "lin.bias"], dtype))
 
     monkeypatch.setattr(gat_cpu, "gat_conv", stand_in)
