@@ -609,8 +609,11 @@ class Bench:
         # PMC traffic is collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh -> profiles/pmc_traffic.json, stamped
         # with the kernel-source hash it was collected on); attached only to the workload AND the kernels it was collected on
         pmc_key = None
-        if wl["kind"] == "tiles" and (wl["B"], wl["S"], self.layers) == (128, 256, 4):
-            pmc_key = ":c3" if (wl["deg"] == 16 and bf16) else None if (wl["deg"] != 8 or bf16) else ":split" if split else ""
+        # (the GAT model only -- a plain backbone runs other instances of the same kernel classes -- and of the operand-split paths
+        #  only bf16x3, the one the counter passes ran)
+        if wl["kind"] == "tiles" and (wl["B"], wl["S"], self.layers) == (128, 256, 4) and wl.get("gnn_type", "GAT") == "GAT":
+            pmc_key = (":c3" if (wl["deg"] == 16 and bf16) else None if (wl["deg"] != 8 or bf16) else
+                       ":split" if split == "bf16x3" else None if split else "")
         t = pmc_traffic_table(self.rt.build_id()) if pmc_key is not None else {}
         for v in roofs.values():
             e = t.get(v["kernel"] + pmc_key) if pmc_key else t.get(v["kernel"])
