@@ -256,7 +256,8 @@ int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, floa
  *   keep  <=>  (z >> 32) >= floor(p * 2^32)
  * stream / index: extractor 1 / row * hidden + column; heads 2 / row * head_hidden_total + column (classification |
  * confidence | correction units); features 64 + layer / row * width + column; attention 16 + layer /
- * ((target << 32 | source) * heads + head), a self loop having source == target.  Every p must lie in [0, 1). */
+ * ((target << 32 | source) * heads + head), a self loop having source == target (parallel edges of a foreign graph therefore
+ * share one draw).  Every p must lie in [0, 1). */
 typedef struct bgnn_dropout {
   float p_extractor, p_attention, p_features, p_heads;
   uint64_t seed;

@@ -751,6 +751,34 @@ def test_training_mode_forward_with_active_dropout(kind, layers, gpu_device):
         assert abs(frac(drop.attention(torch.ones(src.shape[0], 4), src, dst, 0)) - p_att) < 0.01
 
 
+def test_training_mode_dropout_on_a_foreign_graph(gpu_device):
+    """Active dropout on a Data assembled elsewhere (CSR path of the aggregate kernel): a hub with 40 in-edges (the two-pass loop
+    for rows longer than 16), isolated nodes, explicit self loops (GATConv replaces them).  The attention draw is keyed by
+    (target, source, head), so it does not depend on the edge order the CSR build chose."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import Data
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    sd = synthetic.synthetic_state_dict(in_channels=7, num_layers=3, seed=35)
+    m = BathymetricGNN(in_channels=7, num_gnn_layers=3, edge_dim=3, dropout=0.15)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).train()
+    m.dropout_seed = 4242
+    rng = np.random.default_rng(3)
+    N, E = 300, 1500
+    pairs = rng.permutation((N - 10) * (N - 10))[:E]                 # distinct (source, target) pairs; last 10 nodes isolated
+    ei = np.stack([pairs // (N - 10), pairs % (N - 10)]).astype(np.int64)
+    ei[1, :40] = 5; ei[0, :40] = np.arange(100, 140)                # hub: 40 distinct sources
+    ei[:, 100:110] = np.arange(20, 30)[None, :]                     # self loops
+    _, keep = np.unique(ei[0] * N + ei[1], return_index=True)
+    ei = ei[:, np.sort(keep)]
+    x = rng.standard_normal((N, 7)).astype(np.float32)
+    ea = rng.standard_normal((ei.shape[1], 3)).astype(np.float32)
+    out = m(Data(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei).cuda(), edge_attr=torch.from_numpy(ea).cuda()))
+    ref = gat_cpu.forward(sd, x, ei, ea, train_stats={}, dropout=gat_cpu.CounterDropout(4242, 0.15, 0.15, 0.15, 0.15))
+    for k in ("class_logits", "confidence", "correction"):
+        assert (out[k].cpu() - ref[k]).abs().max().item() < TOL, k
+
+
 def test_training_mode_dropout_through_the_unfolded_extractor_and_big_batches(gpu_device):
     """Active extractor dropout sits between the extractor's two Linears: the first keeps its own launch (the lin_0 GEMM's fused
     front is bypassed) at the batch sizes where it would otherwise run inside that GEMM, and with fold_extractor = 0 too."""
