@@ -453,13 +453,17 @@ static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst, int
 
 int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
   BGNN_REQUIRE(ctx && d && w && out, "bgnn_model_create: NULL argument");
-  BGNN_REQUIRE(d->hidden == 32 || d->hidden == 64, "hidden_channels=%d unsupported (32 or 64)", d->hidden);
+  // (the generic kernels take 32 / 64 / 128 as long as a layer stays within 256 columns -- the heads' hidden/2 has to be a multiple of
+  //  16 and their three first layers side by side a multiple of 32; the fused kernels exist for hidden 64 only, the reference's
+  //  default: config/config.py:41)
+  BGNN_REQUIRE(d->hidden == 32 || d->hidden == 64 || d->hidden == 128, "hidden_channels=%d unsupported (32, 64 or 128)", d->hidden);
   BGNN_REQUIRE(d->in_channels >= 1 && d->in_channels <= 8, "in_channels=%d unsupported (1..8)", d->in_channels);
   BGNN_REQUIRE(d->num_layers >= 1 && d->num_layers <= 64, "num_gnn_layers=%d unsupported", d->num_layers);
-  BGNN_REQUIRE(d->heads >= 1 && d->heads * d->hidden <= 256 && (d->heads & (d->heads - 1)) == 0,
-               "heads=%d unsupported (power of two, heads*hidden <= 256)", d->heads);
   BGNN_REQUIRE(d->gnn_type >= BGNN_GNN_GAT && d->gnn_type <= BGNN_GNN_GIN, "gnn_type=%d unknown", d->gnn_type);
   const bool gat = d->gnn_type == BGNN_GNN_GAT;
+  // (`heads` only shapes a GAT backbone: models/gnn.py:125-143)
+  BGNN_REQUIRE(!gat || (d->heads >= 1 && d->heads * d->hidden <= 256 && (d->heads & (d->heads - 1)) == 0),
+               "heads=%d unsupported (power of two, heads*hidden <= 256)", d->heads);
   BGNN_REQUIRE(!gat || (d->edge_dim >= 1 && d->edge_dim <= 4), "edge_dim=%d unsupported (1..4)", d->edge_dim);
   BGNN_REQUIRE(d->num_classes >= 1 && d->num_classes <= 16, "num_classes=%d unsupported", d->num_classes);
   BGNN_REQUIRE(n_weights == bgnn_model_weight_count(d), "weight blob has %zu floats, expected %zu", n_weights,

@@ -107,7 +107,7 @@ int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const f
                            const float *scale, const float *shift, int relu, float *out, int ldo, float *copy_self) {
   const int64_t rows = g->row_capacity;
   if (rows <= 0) return BGNN_OK;
-  BGNN_REQUIRE(D == 32 || D == 64, "neighbor_reduce: width %d unsupported (32 or 64)", D);
+  BGNN_REQUIRE(D == 32 || D == 64 || D == 128, "neighbor_reduce: width %d unsupported (32, 64 or 128)", D);
   BGNN_TRY(ensure_stencil_table(g));
   ReduceArgs a{x, g->d_nbr, g->kind == 0 ? nullptr : g->d_rowptr, dinv, scale, shift, out,
                copy_self, g->d_counts, g->K, D, ldo, mode, relu, g->kind == 0 ? g->include_self_loops : 0};
@@ -115,7 +115,8 @@ int launch_neighbor_reduce(bgnn_ctx *ctx, const bgnn_graph *g, int mode, const f
   const int lpn = D / 4, npw = 64 / lpn;
   const int64_t waves = (rows + npw - 1) / npw;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  if (lpn == 16) hipLaunchKernelGGL(neighbor_reduce_kernel<16>, grid, block, 0, ctx->stream, a);
+  if (lpn == 32) hipLaunchKernelGGL(neighbor_reduce_kernel<32>, grid, block, 0, ctx->stream, a);
+  else if (lpn == 16) hipLaunchKernelGGL(neighbor_reduce_kernel<16>, grid, block, 0, ctx->stream, a);
   else hipLaunchKernelGGL(neighbor_reduce_kernel<8>, grid, block, 0, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;

@@ -134,8 +134,8 @@ def test_variants_heads_hidden_nocorr_legacy_keys(gpu_device):
     d, m, _ = synthetic.synthetic_tile(30, 30, 21, "V1")
     g = GraphBuilder().build_graph(d, m, None, (0.5, 0.5))
     og = graph_cpu.build_graph(d, m, None, (0.5, 0.5))
-    for kw in (dict(heads=2, hidden=64), dict(heads=4, hidden=32), dict(heads=1, hidden=64),
-               dict(predict_correction=False), dict(legacy=True)):
+    for kw in (dict(heads=2, hidden=64), dict(heads=4, hidden=32), dict(heads=1, hidden=64), dict(heads=2, hidden=128),
+               dict(heads=1, hidden=128), dict(hidden=128, heads=2, predict_correction=False), dict(predict_correction=False), dict(legacy=True)):
         legacy = kw.pop("legacy", False)
         heads, hidden, pc = kw.get("heads", 4), kw.get("hidden", 64), kw.get("predict_correction", True)
         sd = calibrate_heads(synthetic.synthetic_state_dict(hidden=hidden, heads=heads, predict_correction=pc, seed=5, legacy_lin_src=legacy),
@@ -483,6 +483,33 @@ def test_other_backbones_match_oracle(kind, loops, gpu_device):
         ref = gat_cpu.process_tile(sd, og, 0.85, 0.6)
         assert np.abs(r["confidence"] - ref["confidence"]).max() < TOL
         assert np.abs(r["correction"] - ref["correction"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("kind", ["GCN", "GraphSAGE", "GIN"])
+@pytest.mark.parametrize("hidden", [32, 128])
+def test_other_backbones_other_hidden_widths(kind, hidden, gpu_device):
+    """hidden_channels 32 and 128 (config/config.py:41 allows any width; 64 is the default and the only one with fused kernels): the
+    plain backbones run their generic reduce + GEMM kernels, eval and training mode, within the same 1e-4."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    d, mk, _ = synthetic.synthetic_tile(40, 56, 90, "V1")
+    og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=7, hidden=hidden, gnn_type=kind, num_layers=3, seed=78),
+                         og.x, og.edge_index, og.edge_attr)
+    m = BathymetricGNN(in_channels=7, hidden_channels=hidden, gnn_type=kind, num_gnn_layers=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).eval()
+    g = GraphBuilder().build_graph(d, mk, None, (0.5, 0.5))
+    _compare(m.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
+    # training mode on the uncalibrated weights, like test_training_mode_forward_batch_statistics (calibrated heads multiply the
+    # float32 noise of the batch statistics by their gain)
+    sd0 = synthetic.synthetic_state_dict(in_channels=7, hidden=hidden, gnn_type=kind, num_layers=3, seed=78)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd0.items()})
+    m.train()
+    out = m(g)
+    ref = gat_cpu.forward(sd0, og.x, og.edge_index, og.edge_attr, train_stats={})
+    assert (out["class_logits"].cpu() - ref["class_logits"]).abs().max().item() < TOL
 
 
 @pytest.mark.parametrize("kind,conn", [("GCN", "16-dilated"), ("GraphSAGE", "4-connected"), ("GIN", "16-dilated"), ("GCN", "4-connected")])
