@@ -108,9 +108,9 @@ enum { /* GNNBackbone gnn_type (models/gnn.py:120-143); GAT is the hot path, the
 };
 typedef struct bgnn_model_desc {
   int32_t in_channels;        /* 7, or 8 with the uncertainty column                     */
-  int32_t hidden;             /* 64 (must be a multiple of 32, <= 64)                    */
+  int32_t hidden;             /* 64 (the fused kernels' width); 32 and 128 run generic kernels */
   int32_t num_layers;         /* num_gnn_layers (>= 1)                                   */
-  int32_t heads;              /* 4; last layer always uses 1 head, mean (gnn.py:125-132) */
+  int32_t heads;              /* 4; GAT only, power of two, heads * hidden <= 256; last layer: 1 head, mean (gnn.py:125-132) */
   int32_t num_classes;        /* 3                                                       */
   int32_t edge_dim;           /* 3                                                       */
   int32_t predict_correction; /* correction head present                                 */
