@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Race hunt for the uniform-batch paths: random tile sizes / masks / batch sizes; every option pair that must not change a bit
-(fused_persistent, fused_front, bf16_two_phase) is toggled and compared, every configuration is run twice (run-to-run equality), and the bf16 path
+(fused_persistent, fused_front, gemm_pair_major, bf16_two_phase) is toggled and compared, every configuration is run twice (run-to-run equality), and the bf16 path
 is checked for finiteness and distance to the exact path."""
 import argparse, os, sys, time
 import numpy as np, torch
@@ -28,11 +28,11 @@ for rnd in range(args.rounds):
     hw, res, d, m, u = gb.upload_tiles([t[0] for t in tiles], mask, None, [(0.5, 0.5)] * n)
     outs = []
     for pers in (0, 1):
-        for front in (1, 0):
-            ctx.set_option("fused_persistent", pers); ctx.set_option("fused_front", front)
+        for front, pm in ((1, 1), (1, 0), (0, 1)):        # (the lin_0 GEMM: pair-major with the front, tile-major with it, without it)
+            ctx.set_option("fused_persistent", pers); ctx.set_option("fused_front", front); ctx.set_option("gemm_pair_major", pm)
             a = eng.infer_device(hw, res, d, m, u).clone(); b = eng.infer_device(hw, res, d, m, u).clone()
             outs += [a, b]
-    ctx.set_option("fused_persistent", 0); ctx.set_option("fused_front", 1)
+    ctx.set_option("fused_persistent", 0); ctx.set_option("fused_front", 1); ctx.set_option("gemm_pair_major", 1)
     ok = all(torch.equal(o, outs[0]) for o in outs[1:])
     ctx.set_option("matrix_path", "bf16")
     bf = eng.infer_device(hw, res, d, m, u).clone(); bf2 = eng.infer_device(hw, res, d, m, u).clone()
