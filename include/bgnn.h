@@ -77,6 +77,12 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
  *                     float64 slope of an edge once for both of its directions (K = 8 / 16, 3 edge features) for uniform batches
  *                     of tiles at least 64 cells wide; 0: always the thread-per-cell kernel (bit-identical results; the form the
  *                     tiled one is tested against); 2: the tiled kernel for every shape (tests)
+ *   "gemm_pair_major" 1 (default): the exact-f32 lin_0 GEMM with the extractor in front runs its MFMAs tile-pair-major, the
+ *                     epilogue of pair p issued between the MFMAs of pair p + 1; 0: tile-major, epilogue after (bit-identical;
+ *                     the form it is tested against)                                              [BGNN_NO_PAIR_MAJOR]
+ *   "bf16_two_phase"  1 (default): matrix_path 3 runs its 256 -> 256 fused layer in two phases (aggregate to bf16 registers, then
+ *                     the GEMM in column passes; bit-identical to 0, the one-phase instance)          [BGNN_NO_TWO_PHASE]
+ *   "stats_narrow"    -1 (default): 16-wide box-statistics workgroups when the 64-wide launch would leave CUs idle; 0 / 1 force
  * plus experiment / diagnostic knobs ("fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",
  * "diag_stamps", "gemm_diag" exist only in the diagnostic build of the library).  Unknown names -> BGNN_ERR_INVALID. */
 int bgnn_ctx_set_option(bgnn_ctx *ctx, const char *name, int value);
