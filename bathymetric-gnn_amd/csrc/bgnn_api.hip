@@ -443,6 +443,13 @@ static void pack_alpha_tile(const float *Wt, const float *bias, const float *att
 // column-permuted f32 image for the fused exact-f32 kernel: column 32 t + r of a row goes to (t / TG) * 32 TG + r * TG + t % TG,
 // TG = 4 / 2 / 1 tiles per LDS read (gat_layer_fused.hip: WTileGroup)
 // (tg > 0 forces the group width: the lin_0 GEMM's pair-major form reads TWO tiles per ds_read_b64, gemm_f32.hip PM)
+// [D][NC] -> [NC / 256][D][256]: the 256-column blocks of a wide layer, each a contiguous image for the generic GEMM
+static void pack_col_blocks(const float *Wt, int D, int NC, float *dst) {
+  for (int b = 0; b < NC / 256; ++b)
+    for (int k = 0; k < D; ++k)
+      for (int c = 0; c < 256; ++c) dst[((size_t)b * D + k) * 256 + c] = Wt[(size_t)k * NC + b * 256 + c];
+}
+
 static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst, int tg = 0) {
   const int NT = NC / 32, TG = tg > 0 ? tg : NT % 4 == 0 ? 4 : NT % 2 == 0 ? 2 : 1;
   for (int k = 0; k < D; ++k)
@@ -462,8 +469,10 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   BGNN_REQUIRE(d->gnn_type >= BGNN_GNN_GAT && d->gnn_type <= BGNN_GNN_GIN, "gnn_type=%d unknown", d->gnn_type);
   const bool gat = d->gnn_type == BGNN_GNN_GAT;
   // (`heads` only shapes a GAT backbone: models/gnn.py:125-143)
-  BGNN_REQUIRE(!gat || (d->heads >= 1 && d->heads * d->hidden <= 256 && (d->heads & (d->heads - 1)) == 0),
-               "heads=%d unsupported (power of two, heads*hidden <= 256)", d->heads);
+  // (up to 256 columns a layer is one launch per kernel; 512 columns -- 8 heads of 64, 4 of 128 -- run the generic kernels in two
+  //  256-column blocks: Wt_blk)
+  BGNN_REQUIRE(!gat || (d->heads >= 1 && d->heads * d->hidden <= 512 && (d->heads & (d->heads - 1)) == 0),
+               "heads=%d unsupported (power of two, heads*hidden <= 512)", d->heads);
   BGNN_REQUIRE(!gat || (d->edge_dim >= 1 && d->edge_dim <= 4), "edge_dim=%d unsupported (1..4)", d->edge_dim);
   BGNN_REQUIRE(d->num_classes >= 1 && d->num_classes <= 16, "num_classes=%d unsupported", d->num_classes);
   BGNN_REQUIRE(n_weights == bgnn_model_weight_count(d), "weight blob has %zu floats, expected %zu", n_weights,
@@ -580,8 +589,8 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     std::copy(bias, bias + W, pk.begin() + lo[l].tr_bias);
     std::copy(bw, bw + W, pk.begin() + lo[l].tr_bw); std::copy(bb, bb + W, pk.begin() + lo[l].tr_bb);
   }
-  const size_t o_ones = reserve(256);
-  std::fill(pk.begin() + o_ones, pk.begin() + o_ones + 256, 1.0f);
+  const size_t o_ones = reserve(512);                     // (as wide as the widest layer: heads * hidden <= 512)
+  std::fill(pk.begin() + o_ones, pk.begin() + o_ones + 512, 1.0f);
   // heads: first layers concatenated column-wise, second layers packed
   size_t o_hW0t = reserve((size_t)hid * HT), o_hb0 = reserve(HT);
   size_t o_hW1 = reserve((size_t)d->num_classes * hh + 2 * hh), o_hb1 = reserve(d->num_classes + 2);
@@ -676,6 +685,23 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     }
   }
 
+  // layers wider than 256 columns: blocked images for the generic GEMM (layer 0: the folded and the unfolded weight)
+  std::vector<size_t> o_wblk(L, 0);
+  size_t o_l0f_blk = 0;
+  if (gat && d->heads * hid > 256) {
+    for (int l = 0; l + 1 < L; ++l) o_wblk[l] = reserve((size_t)(l == 0 ? hid : hid * d->heads) * d->heads * hid);
+    if (L > 1) o_l0f_blk = reserve((size_t)hid * HC0);
+    for (int l = 0; l + 1 < L; ++l) {                      // (reserve may reallocate pk: sources taken afterwards)
+      const int D = l == 0 ? hid : hid * d->heads, HC = d->heads * hid;
+      std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
+      pack_col_blocks(src.data(), D, HC, pk.data() + o_wblk[l]);
+    }
+    if (o_l0f_blk) {
+      std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
+      pack_col_blocks(src0.data(), hid, HC0, pk.data() + o_l0f_blk);
+    }
+  }
+
   bgnn_model *m = new bgnn_model();
   m->ctx = ctx; m->desc = *d; m->blob_floats = pk.size();
   hipError_t e = hipMalloc((void **)&m->blob, pk.size() * sizeof(float));
@@ -688,6 +714,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
   m->l0f_Wsp16 = gat && f16_ok ? m->blob + o_l0fsp16 : nullptr;
   m->l0f_Wbf = gat ? m->blob + o_l0fbf : nullptr;
   m->l0f_Wpm = gat && o_l0fpm ? m->blob + o_l0fpm : nullptr;
+  m->l0f_Wt_blk = o_l0f_blk ? m->blob + o_l0f_blk : nullptr;
   m->hd_W0bf = gat ? m->blob + o_hW0bf : nullptr;
   m->hd_W0fp = gat ? m->blob + o_hW0fp : nullptr;
   m->layers.resize(L);
@@ -710,6 +737,7 @@ int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, s
     Ly.heads = last ? 1 : d->heads; Ly.d_in = l == 0 ? hid : hid * d->heads;
     Ly.width = last ? hid : Ly.heads * hid; Ly.concat = !last;
     Ly.Wt = m->blob + lo[l].Wt; Ly.att_src = m->blob + lo[l].as; Ly.att_dst = m->blob + lo[l].ad;
+    Ly.Wt_blk = o_wblk[l] ? m->blob + o_wblk[l] : nullptr;
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
     Ly.Wsp16 = l > 0 && f16_ok ? m->blob + o_wsp16[l] : nullptr;
@@ -1163,9 +1191,13 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   auto drop = [&](float *x, int width, float p, uint32_t stream) {
     return dp && p > 0.0f ? launch_dropout(ctx, x, width, width, dm, rows, make_drop_spec(p, dp->seed, stream)) : BGNN_OK;
   };
-  auto batch_norm = [&](float *z, const BgnnLayer &L, int relu) {          // z [rows][L.width], in place
-    const int rc = launch_bn_train(ctx, z, L.width, L.width, rows, dm, L.bn_w, L.bn_b, d.bn_eps, relu, bnws,
-                                   tr->mean ? tr->mean + tr_off : nullptr, tr->var_unbiased ? tr->var_unbiased + tr_off : nullptr);
+  auto batch_norm = [&](float *z, const BgnnLayer &L, int relu) {          // z [rows][L.width], in place (256 columns per launch)
+    int rc = BGNN_OK;
+    for (int c0 = 0; c0 < L.width && rc == BGNN_OK; c0 += 256) {
+      const int w = std::min(256, L.width - c0);
+      rc = launch_bn_train(ctx, z + c0, L.width, w, rows, dm, L.bn_w + c0, L.bn_b + c0, d.bn_eps, relu, bnws,
+                           tr->mean ? tr->mean + tr_off + c0 : nullptr, tr->var_unbiased ? tr->var_unbiased + tr_off + c0 : nullptr);
+    }
     tr_off += (size_t)L.width;
     return rc;
   };
@@ -1257,14 +1289,15 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       if (!front && dp) BGNN_TRY(drop(Y, hid, dp->p_extractor, 1));
       BGNN_TRY(launch_gemm_f32(ctx, front ? g->d_x8 : Y, front ? 8 : hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid,
                                L0.heads * hid, 0, L0.att_src, L0.att_dst, asdX, L0.heads, hid, wsplit, smode,
-                               front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr, front && smode == 0 ? m->l0f_Wpm : nullptr));
+                               front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr, front && smode == 0 ? m->l0f_Wpm : nullptr,
+                               m->l0f_Wt_blk));
     } else {
       BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
       if (dp) BGNN_TRY(drop(X, hid, dp->p_extractor, 1));
       BGNN_TRY(launch_gemm_f32(ctx, X, hid, m->fe_W1t, m->fe_b1, Y, hid, dm, rows, hid, hid, 0));
       BGNN_TRY(launch_gemm_f32(ctx, Y, L0.d_in, L0.Wt, nullptr, X, L0.heads * hid, dm, rows, L0.d_in, L0.heads * hid, 0,
-                               L0.att_src, L0.att_dst, asdX, L0.heads, hid));
+                               L0.att_src, L0.att_dst, asdX, L0.heads, hid, nullptr, 0, nullptr, nullptr, nullptr, L0.Wt_blk));
     }
   }
   // GNN backbone (gnn.py:173-188).  Invariant at the top of each iteration: X = lin_l(h_l), asdX = its dots.
@@ -1294,7 +1327,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       if (tr) BGNN_TRY(batch_norm(Y, L, relu));
       if (dp && relu) BGNN_TRY(drop(Y, L.width, dp->p_features, 64 + (uint32_t)l));
       BGNN_TRY(launch_gemm_f32(ctx, Y, Ln.d_in, Ln.Wt, nullptr, X, Ln.heads * hid, dm, rows, Ln.d_in, Ln.heads * hid, 0,
-                               Ln.att_src, Ln.att_dst, asdX, Ln.heads, hid));
+                               Ln.att_src, Ln.att_dst, asdX, Ln.heads, hid, nullptr, 0, nullptr, nullptr, nullptr, Ln.Wt_blk));
     } else {
       int rc = use_fused ? launch_fused_layer_heads(ctx, g, m, L, hid, V3, X, asdX, thr_auto, thr_review,
                                                     grids ? grids->norm_floor : 0.01f, o, grids ? grids->cls : nullptr,
@@ -1317,7 +1350,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   // heads (gnn.py:392-406)
   BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->hd_W0t, m->hd_b0, hidb, m->head_hidden_total, dm, rows, hid,
                            m->head_hidden_total, 1));
-  if (dp) BGNN_TRY(drop(hidb, m->head_hidden_total, dp->p_heads, 2));
+  if (dp && dp->p_heads > 0.0f)      // (the draw is indexed over the heads' own units; the table may carry pad columns up to a multiple of 32)
+    BGNN_TRY(launch_dropout(ctx, hidb, head_count(&d) * (hid / 2), m->head_hidden_total, dm, rows, make_drop_spec(dp->p_heads, dp->seed, 2)));
   BGNN_TRY(launch_heads_final(ctx, m, hidb, m->head_hidden_total, dm, rows, thr_auto, thr_review, o));
   return BGNN_OK;
 }

@@ -137,6 +137,7 @@ struct BgnnLayer {
   int d_in, heads, width;   // width = heads*hidden (concat) or hidden (last)
   int concat;
   float *Wt;        // [d_in][heads*hidden]   (lin.weight transposed)
+  float *Wt_blk = nullptr;   // layers wider than 256 columns: Wt as [columns / 256][d_in][256] (the GEMM runs one launch per 256 columns)
   float *att_src;   // [heads*hidden]
   float *att_dst;   // [heads*hidden]
   float *V;         // [heads][edge_dim]   folded lin_edge . att_edge
@@ -167,6 +168,7 @@ struct bgnn_model {
   float *l0f_Wsp = nullptr, *l0f_Wsp16 = nullptr;   // l0f_Wt as bf16 / float16 hi / lo split images
   float *l0f_Wbf = nullptr, *hd_W0bf = nullptr;     // l0f_Wt / hd_W0t as bf16 (hi only) images
   float *l0f_Wpm = nullptr;                         // l0f_Wt with the columns of tile pairs interleaved (gemm_f32.hip, PM form)
+  float *l0f_Wt_blk = nullptr;                      // l0f_Wt in 256-column blocks (layer 0 wider than 256 columns)
   float *hd_W0fp = nullptr;                         // hd_W0t column-permuted for the fused exact-f32 kernel
   std::vector<BgnnLayer> layers;
   float *ones = nullptr;      // [256] of 1.0f: the identity scale of an unfolded epilogue
@@ -282,7 +284,8 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
                     int ldy, const int64_t *d_m, int64_t max_rows, int K, int NC, int relu,
                     const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
                     int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0,
-                    const float *front_W0t = nullptr, const float *front_b0 = nullptr, const float *Wt_pm = nullptr);
+                    const float *front_W0t = nullptr, const float *front_b0 = nullptr, const float *Wt_pm = nullptr,
+                    const float *Wt_blk = nullptr);
 bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode);
 // training-mode dropout (bgnn.h, bgnn_dropout): one counter-based draw per element, see there
 struct DropSpec {

@@ -27,6 +27,7 @@ struct AggArgs {
   float *out;             // [N][HC]
   const int64_t *d_m;
   int K, H, C, ED, relu;
+  int ld, hd0, Htot;      // row stride of xw / out, first head and head count of the layer (a launch covers at most 256 columns of it)
   DropSpec drop;          // training mode: dropout on the attention coefficients (thr 0: none)
 };
 
@@ -42,8 +43,9 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
   const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t i = wave_id * NPW + sub;
   if (i >= M) return;
-  const int H = a.H, ED = a.ED;
-  const int hh = (l * 4) / a.C;
+  const int H = a.Htot, ED = a.ED;                  // (asd rows and the dropout key are the LAYER's: all its heads)
+  const int hh = a.hd0 + (l * 4) / a.C;
+  const int HCL = a.ld;                             // row stride
   int64_t beg, end;
   if (a.rowptr) { beg = a.rowptr[i]; end = a.rowptr[i + 1]; }
   else { beg = i * a.K; end = beg + a.K; }
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
         const int j = a.nbr[beg + b];
         if (j >= 0) {
           const float al = dropped(ev[b] / den, j);
-          const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HC);
+          const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HCL);
           acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
         }
       }
@@ -159,13 +161,13 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
       lg += dot;
       lg = lg > 0.0f ? lg : 0.2f * lg;
       const float al = dropped(expf(lg - mx) / den, j);
-      const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HC);
+      const float4 x = *reinterpret_cast<const float4 *>(xwl + (int64_t)j * HCL);
       acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
     }
   }
   {
     const float al = dropped(pself / den, i);
-    const float4 x = *reinterpret_cast<const float4 *>(xwl + i * HC);
+    const float4 x = *reinterpret_cast<const float4 *>(xwl + i * HCL);
     acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
   }
   // epilogue: (+bias, BatchNorm eval) folded into scale/shift, ReLU
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a) {
   if (a.relu) {
     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
   }
-  *reinterpret_cast<float4 *>(a.out + i * HC + l * 4) = o;
+  *reinterpret_cast<float4 *>(a.out + i * HCL + l * 4) = o;
 }
 
 int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, int C, int ED, const float *xw,
@@ -192,7 +194,24 @@ int launch_gat_aggregate(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L,
   a.V = L.V; a.scale = L.scale; a.shift = L.shift; a.out = out; a.d_m = g->d_counts;
   a.K = g->K; a.H = L.heads; a.C = C; a.ED = ED; a.relu = relu;
   if (attention_drop) a.drop = *attention_drop;
-  const int HC = L.heads * C, LPN = HC / 4;
+  const int HC = L.heads * C;
+  a.ld = HC; a.hd0 = 0; a.Htot = L.heads;
+  if (HC > 256) {
+    // a layer wider than 256 columns: one launch per 256-column block (whole heads: 256 % C == 0), every block reading the layer's
+    // alpha table with its first head's offset
+    BGNN_REQUIRE(HC % 256 == 0 && 256 % C == 0, "gat_aggregate: heads*hidden = %d unsupported", HC);
+    const int64_t waves = max_rows;                  // 64 lanes per node
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    for (int b = 0; b < HC / 256; ++b) {
+      AggArgs ab = a;
+      ab.xw = xw + b * 256; ab.out = out + b * 256; ab.scale = L.scale + b * 256; ab.shift = L.shift + b * 256;
+      ab.hd0 = b * (256 / C);
+      hipLaunchKernelGGL(gat_aggregate_kernel<64>, grid, block, 0, ctx->stream, ab);
+      BGNN_HIP_CHECK(hipGetLastError());
+    }
+    return BGNN_OK;
+  }
+  const int LPN = HC / 4;
   const int npw = 64 / LPN;
   const int64_t waves = (max_rows + npw - 1) / npw;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);

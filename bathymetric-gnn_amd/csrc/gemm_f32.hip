@@ -44,6 +44,9 @@ struct GemmArgs {
   // W-resident form with the feature extractor's first Linear in front (FRONT): X is then the [M][8] node feature table and
   const float *W0t;       // [8][64]  extractor layer 1 (transposed)
   const float *b0;        // [64]
+  // one 256-column block of a wider layer (generic kernel only): the attention dots of this block's heads go to columns
+  // asd_hd0 .. of the [M][2 asd_H] table (0 / 0: the whole layer in one launch, asd_H = H)
+  int asd_H, asd_hd0;
 };
 
 template <int NT>
@@ -212,8 +215,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
       ps += __shfl_xor(ps, 32);
       pd += __shfl_xor(pd, 32);
       if (ok && h == 0) {
-        a.asd[row * 2 * H + hd] = ps;
-        a.asd[row * 2 * H + H + hd] = pd;
+        const int HT = a.asd_H ? a.asd_H : H;
+        a.asd[row * 2 * HT + a.asd_hd0 + hd] = ps;
+        a.asd[row * 2 * HT + HT + a.asd_hd0 + hd] = pd;
       }
     }
   }
@@ -724,14 +728,32 @@ bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int spl
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
                     const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode,
-                    const float *front_W0t, const float *front_b0, const float *Wt_pm) {
+                    const float *front_W0t, const float *front_b0, const float *Wt_pm, const float *Wt_blk) {
+  if (NC > 256) {
+    // a layer wider than 256 columns (heads x hidden up to 512): one launch of the generic kernel per 256-column block of the
+    // blocked weight image; a block's heads write their attention dots into their columns of the shared [M][2 H] table
+    BGNN_REQUIRE(Wt_blk && NC % 256 == 0 && NC <= 512 && split_mode == 0 && !front_W0t && (!att_src || (C > 0 && 256 % C == 0)),
+                 "gemm_f32: NC=%d needs the blocked weight image (exact path, no fused front)", NC);
+    for (int b = 0; b < NC / 256; ++b) {
+      ProfScope ps(ctx, BGNN_K_GEMM);
+      GemmArgs a{X, Wt_blk + (size_t)b * K * 256, bias ? bias + b * 256 : nullptr, Y + b * 256, d_m, att_src ? att_src + b * 256 : nullptr,
+                 att_dst ? att_dst + b * 256 : nullptr, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, att_src ? 256 / C : 0, C, 0, nullptr, nullptr,
+                 att_src ? H : 0, att_src ? b * (256 / C) : 0};
+      if (max_rows <= 0) return BGNN_OK;
+      dim3 grid((unsigned)((max_rows + 127) / 128)), block(256);
+      if (att_src) hipLaunchKernelGGL((gemm_f32_kernel<8, true>), grid, block, 0, ctx->stream, a);
+      else hipLaunchKernelGGL((gemm_f32_kernel<8, false>), grid, block, 0, ctx->stream, a);
+      BGNN_HIP_CHECK(hipGetLastError());
+    }
+    return BGNN_OK;
+  }
   BGNN_REQUIRE(K % 8 == 0 && NC % 32 == 0 && NC <= 256 && ldx % 4 == 0 && ldy % 4 == 0,
                "gemm_f32: unsupported shape K=%d NC=%d ldx=%d ldy=%d", K, NC, ldx, ldy);
   if (att_src) BGNN_REQUIRE(C % 32 == 0 && H * C == NC, "gemm_f32: attention epilogue needs NC == H*C, C %% 32 == 0");
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
   const int gemm_dbg = BGNN_DIAG ? ctx->opts.gemm_diag : 0;
-  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg, front_W0t, front_b0};
+  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg, front_W0t, front_b0, 0, 0};
   if (front_W0t) BGNN_REQUIRE(K == 64 && att_src && gemm_front_available(ctx, max_rows, NC, split_mode) && (split_mode != 3 || Wt_split),
                               "gemm: the fused front needs the W-resident K = 64 attention form");
   const bool no_wres = ctx->opts.gemm_no_wres != 0;

@@ -116,7 +116,7 @@ typedef struct bgnn_model_desc {
   int32_t in_channels;        /* 7, or 8 with the uncertainty column                     */
   int32_t hidden;             /* 64 (the fused kernels' width); 32 and 128 run generic kernels */
   int32_t num_layers;         /* num_gnn_layers (>= 1)                                   */
-  int32_t heads;              /* 4; GAT only, power of two, heads * hidden <= 256; last layer: 1 head, mean (gnn.py:125-132) */
+  int32_t heads;              /* 4; GAT only, power of two, heads * hidden <= 512 (above 256: generic kernels, two column blocks); last layer: 1 head, mean (gnn.py:125-132) */
   int32_t num_classes;        /* 3                                                       */
   int32_t edge_dim;           /* 3                                                       */
   int32_t predict_correction; /* correction head present                                 */
@@ -260,8 +260,8 @@ int bgnn_forward_train(bgnn_ctx *ctx, bgnn_model *model, bgnn_graph *graph, floa
  *   z = seed + 0x9E3779B97F4A7C15 * (stream + 1) + 0xD1B54A32D192ED03 * index        (mod 2^64)
  *   z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;  z = (z ^ z >> 27) * 0x94D049BB133111EB;  z ^= z >> 31      (splitmix64's finaliser)
  *   keep  <=>  (z >> 32) >= floor(p * 2^32)
- * stream / index: extractor 1 / row * hidden + column; heads 2 / row * head_hidden_total + column (classification |
- * confidence | correction units); features 64 + layer / row * width + column; attention 16 + layer /
+ * stream / index: extractor 1 / row * hidden + column; heads 2 / row * (number of heads * hidden / 2) + column (classification |
+ * confidence | correction units side by side); features 64 + layer / row * width + column; attention 16 + layer /
  * ((target << 32 | source) * heads + head), a self loop having source == target (parallel edges of a foreign graph therefore
  * share one draw).  Every p must lie in [0, 1). */
 typedef struct bgnn_dropout {

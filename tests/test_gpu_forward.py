@@ -147,6 +147,34 @@ def test_variants_heads_hidden_nocorr_legacy_keys(gpu_device):
         assert ("correction" in out) == pc
 
 
+@pytest.mark.parametrize("heads,hidden,layers", [(8, 64, 3), (4, 128, 2), (8, 32, 4)])
+def test_layers_wider_than_256_columns(heads, hidden, layers, gpu_device):
+    """heads x hidden up to 512 (config/config.py:41-46 allows any): the generic GEMM / aggregate / BatchNorm kernels run a 512-column
+    layer as two 256-column blocks (whole heads per block, one shared attention table).  Eval and training mode, dropout included,
+    against the oracle at the same 1e-4."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    d, mk, _ = synthetic.synthetic_tile(45, 52, 31, "V1")
+    og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5))
+    sd0 = synthetic.synthetic_state_dict(in_channels=7, hidden=hidden, heads=heads, num_layers=layers, seed=41)
+    sd = calibrate_heads(sd0, og.x, og.edge_index, og.edge_attr)
+    m = BathymetricGNN(in_channels=7, hidden_channels=hidden, heads=heads, num_gnn_layers=layers, edge_dim=3, dropout=0.1)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).eval()
+    g = GraphBuilder().build_graph(d, mk, None, (0.5, 0.5))
+    _compare(m.predict(g), gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr))
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd0.items()})
+    m.train()
+    m.dropout_seed = 5
+    out = m(g)
+    stats = {}
+    ref = gat_cpu.forward(sd0, og.x, og.edge_index, og.edge_attr, train_stats=stats, dropout=gat_cpu.CounterDropout(5, 0.1, 0.1, 0.1, 0.1))
+    assert (out["class_logits"].cpu() - ref["class_logits"]).abs().max().item() < TOL
+    for l, n in enumerate(m.gnn.norms):
+        assert (n.module.running_mean.cpu() - stats[f"gnn.norms.{l}.module.running_mean"]).abs().max().item() < 1e-5
+
+
 def test_batched_equals_per_graph_and_vr_processor(gpu_device):
     """NativeVRProcessor semantics (scripts/inference_native.py:249-342): batched flush == per-grid
     processing == oracle; empty grids return zeros immediately.  Heads calibrated on the first eight grids' block-diagonal
