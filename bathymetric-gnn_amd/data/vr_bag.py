@@ -330,11 +330,20 @@ class VRBagWriter:
         """Bulk write-back used by the device path: ``records`` (structured or float32 [n, 2]) replace
         ``varres_refinements[0, start:start+n]`` in one slice assignment."""
         rec = np.asarray(records)
+        n = rec.shape[0]
+        tgt = self._refinements
+        if self._file is None and rec.dtype == np.float32 and rec.ndim == 2 and rec.shape[1] == 2 and tgt.dtype == VARRES_REFINEMENT_DTYPE \
+                and tgt.flags.c_contiguous:
+            # array-backed, plain {depth, depth_uncrt} float32 records: ONE memcpy through a float32 view (numpy assigns structured
+            # arrays field by field: 10x slower)
+            np.copyto(tgt.reshape(-1).view(np.float32).reshape(-1, 2)[start:start + n], rec)
+            self._corrections_applied += int(corrections_applied)
+            return
         if rec.dtype.names is None:
             rec = np.ascontiguousarray(rec, dtype=np.float32).reshape(-1, 2).view(VARRES_REFINEMENT_DTYPE).reshape(-1)
-        cur = self._refinements[0, start:start + rec.shape[0]]
+        cur = self._refinements[0, start:start + n]
         cur["depth"] = rec["depth"]; cur["depth_uncrt"] = rec["depth_uncrt"]
-        self._refinements[0, start:start + rec.shape[0]] = cur
+        self._refinements[0, start:start + n] = cur
         self._corrections_applied += int(corrections_applied)
 
     def close(self):

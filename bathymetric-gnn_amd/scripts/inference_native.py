@@ -50,6 +50,10 @@ class _BatchSlot:
         mk = lambda dt, shape: torch.empty(shape, dtype=dt, device=self.dev)
         self.rec_t, self.depth_t, self.unc_t = mk(torch.float32, (cap, 2)), mk(torch.float32, cap), mk(torch.float32, cap)
         self.mask_t, self.out_t = mk(torch.uint8, cap), mk(torch.float32, 3 * cap)
+        self.scratch_t = None
+        # The buffers are used on the ENGINES' streams (either of two), not on the stream torch's caching allocator made them on: a
+        # block it hands out may still be read by work queued on its old stream.  Growing is rare -- wait the device out once.
+        torch.cuda.synchronize(self.dev)
         self.cap = cap
 
     def reset(self):
@@ -86,6 +90,46 @@ class _BatchSlot:
             self.mask_h.numpy()[self.n:self.n + n] = m.reshape(-1)
         self.hw.append((h, w)); self.res.append((float(resolution[0]), float(resolution[1])))
         self.n += n
+
+
+class _BagSlot:
+    """Staging of ONE chunk of a whole-BAG pass (``process_refinements``): a pinned record slab (the chunk's records on their way up,
+    the corrected ones on their way down), the device buffers the chunk is unpacked / classified / corrected in, a pinned result
+    buffer, and one small "tail" -- counters {noise, corrected, changed} int64, confidence sum float64, per-grid valid counts
+    int64, per-grid keep flags uint8 -- that comes back in one copy.  Bound to one engine: everything of a chunk runs on that engine's
+    stream."""
+
+    def __init__(self, eng):
+        self.eng, self.dev = eng, eng.ctx.device
+        self.cap = self.gcap = self.res_cap = 0
+        self.done = torch.cuda.Event()
+        self.res_h = None
+
+    def ensure(self, cells: int, grids: int, results: bool):
+        pin = lambda dt, shape: torch.empty(shape, dtype=dt, pin_memory=True)
+        mk = lambda dt, shape: torch.empty(shape, dtype=dt, device=self.dev)
+        grown = False
+        if cells > self.cap:
+            cap = max(int(cells), self.cap + self.cap // 2)
+            self.rec_h = pin(torch.float32, (cap, 2)); self.rec_np = self.rec_h.numpy()
+            self.out_rec_h = pin(torch.float32, (cap, 2))      # (its own slab: chunk k + S is staged while chunk k is written back)
+            self.rec_t, self.depth_t, self.unc_t = mk(torch.float32, (cap, 2)), mk(torch.float32, cap), mk(torch.float32, cap)
+            self.mask_t, self.out_t = mk(torch.uint8, cap), mk(torch.float32, 3 * cap)
+            self.cap, grown = cap, True
+        if grids > self.gcap:
+            gcap = max(int(grids), 2 * self.gcap, 256)
+            self.off_h = pin(torch.int64, gcap + 1); self.off_np = self.off_h.numpy()
+            self.off_t = mk(torch.int64, gcap + 1)
+            self.tail_h = pin(torch.uint8, 32 + 9 * gcap); self.tail_t = mk(torch.uint8, 32 + 9 * gcap)
+            self.gcap, grown = gcap, True
+        if grown:       # (used on the engine's stream, allocated on the caller's: see _BatchSlot._grow)
+            torch.cuda.synchronize(self.dev)
+        if results and self.res_cap < self.cap:
+            self.res_h = pin(torch.float32, 3 * self.cap); self.res_cap = self.cap
+
+    def tail_views(self, g: int):
+        """Device views of the tail for a chunk of ``g`` grids: (valid counts int64 [g], keep flags uint8 [g])."""
+        return self.tail_t[32:32 + 8 * g].view(torch.int64), self.tail_t[32 + 8 * g:32 + 9 * g]
 
 
 class NativeVRProcessor:
@@ -193,6 +237,16 @@ class NativeVRProcessor:
         return (self._batch_node_count >= self.BATCH_NODE_BUDGET or
                 (self._fill is not None and len(self._fill.hw) >= self.MAX_GRIDS_PER_BATCH))     # (a raised budget and tiny grids)
 
+    PIPELINE_COALESCE = 4            # reference-size batches per pipelined submission (run_refinements)
+
+    @property
+    def submit_ready(self) -> bool:
+        """``batch_ready`` for a PIPELINED submission: ``PIPELINE_COALESCE`` node budgets' worth of grids -- a 50 000-node batch is one
+        round of workgroups per kernel; four of them in one submission run at 1.3x the device rate and cost one host round instead of
+        four.  The results of a grid do not depend on the batch it travels in."""
+        return (self._batch_node_count >= self.PIPELINE_COALESCE * self.BATCH_NODE_BUDGET or
+                (self._fill is not None and len(self._fill.hw) >= self.MAX_GRIDS_PER_BATCH))
+
     @property
     def batch_pending(self) -> bool:
         return self._fill is not None and self._fill.n > 0
@@ -209,17 +263,25 @@ class NativeVRProcessor:
     # ---- two batches in flight (MI355X-first extension of the batching API; run_refinements uses it) --------------------------
     MAX_IN_FLIGHT = 2
 
-    def _engine_for_next(self) -> TileBatchEngine:
+    def _engine_at(self, i: int) -> TileBatchEngine:
+        """The processor's i-th engine (0: the device's default library context; 1: a second context -- own HIP stream, own arenas --
+        created when batches are first pipelined, with the first one's run-time switches)."""
         from .. import runtime as rt
-        i = self._next_engine % self.MAX_IN_FLIGHT
-        self._next_engine += 1
-        while len(self._engines) <= i:              # the second library context is only created when batches are pipelined
+        while len(self._engines) <= i:
             ctx = rt.new_context(self._engine.ctx.device)
             for k in ("matrix_path", "fused", "fold_extractor", "ragged_atlas", "fused_front", "features_tiled"):
                 ctx.set_option(k, self._engine.ctx.get_option(k))
             self._engines.append(TileBatchEngine(self.model, self.graph_builder, self._engine.ctx.device, self.auto_correct_threshold,
                                                  self._engine.review_threshold, self._engine.norm_floor, ctx=ctx))
         return self._engines[i]
+
+    def _second_engine(self) -> TileBatchEngine:
+        return self._engine_at(1)
+
+    def _engine_for_next(self) -> TileBatchEngine:
+        i = self._next_engine % self.MAX_IN_FLIGHT
+        self._next_engine += 1
+        return self._engine_at(i)
 
     def _launch(self, eng: TileBatchEngine) -> _BatchSlot:
         """Everything of the queued batch that runs on the GPU, asynchronously: H2D of the record slab, unpack + valid mask
@@ -243,8 +305,9 @@ class NativeVRProcessor:
             # (host masks -- a batch that mixes nodata values: the kernel's own mask goes to a scratch plane and is not used)
             mask_out = slot.mask_t[:n]
             if slot.host_masks:
-                if getattr(slot, "scratch_t", None) is None or slot.scratch_t.numel() < n:
+                if slot.scratch_t is None or slot.scratch_t.numel() < n:
                     slot.scratch_t = torch.empty(slot.cap, dtype=torch.uint8, device=slot.dev)
+                    torch.cuda.synchronize(slot.dev)                                              # (as in _grow)
                 mask_out = slot.scratch_t[:n]
             rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(slot.rec_t), n, C.c_float(slot.nodata), 0, None, C.c_double(0.0),
                                             rt.ptr(slot.depth_t), rt.ptr(unc_t), rt.ptr(mask_out), None, None))
@@ -314,23 +377,50 @@ class NativeVRProcessor:
         return self._results_of(slot, *self._finish(slot))
 
     # ---- whole-BAG device path (MI355X-first replacement of the main loop, :445-538) ---------------------
+    BAG_SLOTS = 4                    # chunks in flight (two per library context)
+    BAG_CHUNK_MIN, BAG_CHUNK_MAX = 256 << 10, 512 << 10   # automatic chunk size: half of the BAG, within these cell counts
+
+    def _bag_threads(self):
+        """The two helper threads of the whole-BAG path (staging copies / collection + write-back), made on first use."""
+        t = self.__dict__.get("_bag_pool")
+        if t is None:
+            from concurrent.futures import ThreadPoolExecutor
+            t = self.__dict__["_bag_pool"] = (ThreadPoolExecutor(1, thread_name_prefix="bgnn-stage"),
+                                              ThreadPoolExecutor(1, thread_name_prefix="bgnn-collect"))
+        return t
+
+    def _bag_slot(self, i: int, cells: int, grids: int, results: bool) -> "_BagSlot":
+        slots = self.__dict__.setdefault("_bag_slots", {})
+        s = slots.get(i)
+        if s is None:
+            eng = self._engine if i % 2 == 0 else self._second_engine()
+            s = slots[i] = _BagSlot(eng)
+        s.ensure(cells, grids, results)
+        return s
+
     def process_refinements(self, handler, writer=None, min_valid_ratio: float = 0.0,
-                            cell_budget: int = 8 << 20, return_results: bool = False):
+                            cell_budget: Optional[int] = None, return_results: bool = False, results_sink=None,
+                            auto_correct_threshold: Optional[float] = None):
         """Classify and correct every refinement grid of a VR BAG with the records resident in HBM.
 
         ``varres_refinements`` is already the concatenated-grid layout ``bgnn_infer_tiles`` consumes
         (grids row-major, one after another in ``varres_metadata.index`` order), so the records are uploaded
-        as they are, in chunks of about ``cell_budget`` cells cut at grid boundaries (the reference batches
-        50 000 nodes because PyG materialises per-edge tensors; here the bound is HBM).  Per chunk:
-        ``bgnn_vr_unpack`` (planes, valid mask, ``min_valid_ratio`` filter) -> ``bgnn_infer_tiles`` ->
-        ``bgnn_vr_apply`` (the write-back arithmetic of ``apply_results``) -> one D2H of the corrected
-        records into ``writer``.  Returns the statistics the reference's ``main`` logs (:540-559); with
-        ``return_results`` also per-record classification / confidence / correction arrays (what the
-        sidecar builder consumes).  Results equal ``run_refinements`` (the grid-by-grid loop) bit for bit."""
+        as they are, in chunks cut at grid boundaries (the reference batches 50 000 nodes because PyG materialises
+        per-edge tensors; here a chunk is sized to keep the copies of one chunk under the kernels of another:
+        ``cell_budget`` cells, default half of the BAG within ``BAG_CHUNK_MIN`` .. ``BAG_CHUNK_MAX``; measured flat between 256 k and 1 M cells).  Per chunk, all on
+        one library context's stream and asynchronous to the host: H2D of the records from a pinned slab ->
+        ``bgnn_vr_unpack`` (planes, valid mask, ``min_valid_ratio`` filter) -> ``bgnn_infer_tiles`` -> ``bgnn_vr_apply`` (the
+        write-back arithmetic of ``apply_results``) -> D2H of the corrected records, the per-grid valid counts / keep flags
+        and the counters (and, when asked for, the three result planes).  Up to ``BAG_SLOTS`` chunks are in flight on two
+        contexts; a finished chunk goes into ``writer`` with one slice assignment and, per grid in iteration order, to
+        ``results_sink(grid, classification, confidence, correction)`` (where the sidecar builder is fed).
+
+        Returns the statistics the reference's ``main`` logs (:540-559); with ``return_results`` also per-record
+        classification / confidence / correction arrays.  Results equal ``run_refinements(pipelined=False)`` (the
+        reference's grid-by-grid loop) bit for bit; ``total_confidence`` is a float64 sum in device order."""
         import ctypes as C
         from .. import runtime as rt
-        eng = self._engine
-        ctx, dev = eng.ctx, eng.ctx.device
+        thr = self.auto_correct_threshold if auto_correct_threshold is None else auto_correct_threshold
         tab = handler.refinement_table()
         n_grids = len(tab["cells"])
         stats = {"grids_processed": 0, "cells_processed": 0, "cells_classified_noise": 0, "cells_corrected": 0,
@@ -341,64 +431,150 @@ class NativeVRProcessor:
             return (stats, res_all) if return_results else stats
         ref = handler.varres_refinements[0, :]
         plain = (ref.dtype.itemsize == 8 and ref.dtype.fields["depth"][1] == 0 and ref.dtype.fields["depth_uncrt"][1] == 4
-                 and ref.dtype.fields["depth"][0] == np.dtype("<f4"))
+                 and ref.dtype.fields["depth"][0] == np.dtype("<f4") and ref.dtype.fields["depth_uncrt"][0] == np.dtype("<f4"))
         start0 = int(tab["index"][0])
-        if tab["contiguous"] and plain:
-            rec_all = np.ascontiguousarray(ref[start0:start0 + total]).view(np.float32).reshape(total, 2)
-            perm = None
-        else:       # records not laid out in iteration order (or foreign record layout): pack on the host once
-            perm = np.concatenate([np.arange(i, i + c, dtype=np.int64) for i, c in zip(tab["index"], tab["cells"])])
-            rec_all = np.empty((total, 2), np.float32)
-            rec_all[:, 0] = ref["depth"][perm]; rec_all[:, 1] = ref["depth_uncrt"][perm]
-        use_unc = self.expected_in_channels != 7
+        index = tab["index"]
         off = np.zeros(n_grids + 1, np.int64); np.cumsum(tab["cells"], out=off[1:])
+        if tab["contiguous"] and plain:
+            rec_all = np.ascontiguousarray(ref[start0:start0 + total]).view(np.float32).reshape(total, 2)   # (a view when it can be)
+            depth_f = unc_f = None
+        else:       # records not laid out in iteration order (or a foreign record layout): gathered chunk by chunk
+            rec_all = None
+            depth_f, unc_f = ref["depth"], ref["depth_uncrt"]
+        use_unc = self._uses_uncertainty(ref)
         hw = np.stack([tab["dims_y"], tab["dims_x"]], 1).astype(np.int32)
         res = np.stack([tab["res_x"], tab["res_y"]], 1).astype(np.float64)
-        counts_t = torch.zeros(3, dtype=torch.int64, device=dev)
-        csum_t = torch.zeros(1, dtype=torch.float64, device=dev)
-        g0 = 0
+        want_res = return_results or results_sink is not None
+        if cell_budget is None:
+            cell_budget = min(max(total // 2 + 1, self.BAG_CHUNK_MIN), self.BAG_CHUNK_MAX)
+        nodata = C.c_float(getattr(handler, "NODATA", 1.0e6))
+        grids_it = iter(handler.iterate_refinements(min_valid_ratio)) if results_sink is not None else None
+        # ---- the chunks, and one staging slot per chunk in flight (sized once, while nothing is in flight) ----
+        chunks, g0 = [], 0
         while g0 < n_grids:
             g1 = int(np.searchsorted(off, off[g0] + cell_budget, side="right")) - 1
             g1 = min(max(g1, g0 + 1), n_grids, g0 + self.MAX_GRIDS_PER_BATCH)
+            chunks.append((g0, g1)); g0 = g1
+        nch, S = len(chunks), self.BAG_SLOTS
+        max_cells = max(int(off[b] - off[a]) for a, b in chunks); max_grids = max(b - a for a, b in chunks)
+        slots = [self._bag_slot(i, max_cells, max_grids, want_res) for i in range(min(S, nch))]
+
+        def stage(k):
+            """Host copy of chunk k's records into its slot's pinned slab (on the staging thread, a chunk ahead of the launches)."""
+            if k >= S:
+                collected[k - S].wait()                       # the slot's previous chunk has been collected
+            g0, g1 = chunks[k]
             lo, hi = int(off[g0]), int(off[g1])
-            n = hi - lo
-            rec_t = torch.from_numpy(rec_all[lo:hi]).to(dev)
-            off_t = torch.from_numpy(off[g0:g1 + 1] - lo).to(dev)
-            depth_t = torch.empty(n, dtype=torch.float32, device=dev)
-            unc_t = torch.empty(n, dtype=torch.float32, device=dev) if use_unc else None
-            mask_t = torch.empty(n, dtype=torch.uint8, device=dev)
-            cnt_t = torch.empty(g1 - g0, dtype=torch.int64, device=dev)
-            keep_t = torch.empty(g1 - g0, dtype=torch.uint8, device=dev)
-            ctx.begin()
-            rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(rec_t), n, C.c_float(handler.NODATA), g1 - g0, rt.ptr(off_t),
-                                            C.c_double(min_valid_ratio), rt.ptr(depth_t), rt.ptr(unc_t), rt.ptr(mask_t),
-                                            rt.ptr(cnt_t), rt.ptr(keep_t)))
-            ctx.end()
-            out = eng.infer_device(hw[g0:g1], res[g0:g1], depth_t, mask_t, unc_t)
-            before = counts_t[2].item() if writer is not None else 0
-            ctx.begin()
-            rt.check(ctx.lib.bgnn_vr_apply(ctx.handle, rt.ptr(rec_t), n, rt.ptr(mask_t), rt.ptr(out[0]), rt.ptr(out[1]),
-                                           rt.ptr(out[2]), C.c_float(self.auto_correct_threshold), rt.ptr(counts_t),
-                                           rt.ptr(csum_t)))
-            ctx.end()
-            keep = keep_t.cpu().numpy().astype(bool); cnt = cnt_t.cpu().numpy()
-            stats["grids_processed"] += int(keep.sum()); stats["grids_skipped"] += int((~keep).sum())
-            stats["cells_processed"] += int(cnt[keep].sum())
-            if return_results:
-                res_all[:, lo:hi] = out.cpu().numpy()
-            if writer is not None:
-                rec_np = rec_t.cpu().numpy()
-                changed = counts_t[2].item() - before
-                if perm is None:
-                    writer.write_records(start0 + lo, rec_np, corrections_applied=changed)
-                else:
-                    for g in range(g0, g1):
-                        writer.write_records(int(tab["index"][g]), rec_np[off[g] - lo:off[g + 1] - lo],
-                                             corrections_applied=changed if g == g0 else 0)
-            g0 = g1
-        c = counts_t.cpu().numpy()
-        stats["cells_classified_noise"] = int(c[0]); stats["cells_corrected"] = int(c[1])
-        stats["total_confidence"] = float(csum_t.item())
+            n, slot = hi - lo, slots[k % S]
+            if rec_all is not None:
+                np.copyto(slot.rec_np[:n], rec_all[lo:hi])
+            else:
+                idx = np.repeat(index[g0:g1] - (off[g0:g1] - lo), tab["cells"][g0:g1]) + np.arange(n, dtype=np.int64)
+                slot.rec_np[:n, 0] = depth_f[idx]; slot.rec_np[:n, 1] = unc_f[idx]
+            np.subtract(off[g0:g1 + 1], lo, out=slot.off_np[:g1 - g0 + 1])
+
+        def launch(k):
+            g0, g1 = chunks[k]
+            lo, hi = int(off[g0]), int(off[g1])
+            n, g, slot = hi - lo, g1 - g0, slots[k % S]
+            eng, ctx = slot.eng, slot.eng.ctx
+            cnt_t, keep_t = slot.tail_views(g)
+            # (all on the engine's stream.  A copy stream per slot -- upload / download either side of the kernels, ordered by events --
+            #  was measured SLOWER here: 1.30 instead of 1.14 ms per 256 k-cell chunk; the cross-stream waits cost more than the copies)
+            with torch.cuda.stream(ctx.stream):
+                slot.rec_t[:n].copy_(slot.rec_h[:n], non_blocking=True)
+                slot.off_t[:g + 1].copy_(slot.off_h[:g + 1], non_blocking=True)
+                slot.tail_t[:32].zero_()
+                unc_t = slot.unc_t[:n] if use_unc else None
+                rt.check(ctx.lib.bgnn_vr_unpack(ctx.handle, rt.ptr(slot.rec_t), n, nodata, g, rt.ptr(slot.off_t),
+                                                C.c_double(min_valid_ratio), rt.ptr(slot.depth_t), rt.ptr(unc_t), rt.ptr(slot.mask_t),
+                                                rt.ptr(cnt_t), rt.ptr(keep_t)))
+                out = slot.out_t[:3 * n].view(3, n)
+                eng.infer_device(hw[g0:g1], res[g0:g1], slot.depth_t[:n], slot.mask_t[:n], unc_t, out=out, defer_end=True, begin=False)
+                rt.check(ctx.lib.bgnn_vr_apply(ctx.handle, rt.ptr(slot.rec_t), n, rt.ptr(slot.mask_t), rt.ptr(out[0]), rt.ptr(out[1]),
+                                               rt.ptr(out[2]), C.c_float(thr), rt.ptr(slot.tail_t), rt.ptr(slot.tail_t[24:])))
+                if writer is not None:
+                    slot.out_rec_h[:n].copy_(slot.rec_t[:n], non_blocking=True)
+                slot.tail_h[:32 + 9 * g].copy_(slot.tail_t[:32 + 9 * g], non_blocking=True)
+                if want_res:
+                    slot.res_h[:3 * n].copy_(slot.out_t[:3 * n], non_blocking=True)
+                slot.done.record(ctx.stream)
+
+        def collect(k):
+            try:
+                g0, g1 = chunks[k]
+                lo, hi = int(off[g0]), int(off[g1])
+                n, g, slot = hi - lo, g1 - g0, slots[k % S]
+                slot.done.synchronize()
+                tail = slot.tail_h.numpy()
+                counts = tail[:24].view(np.int64)
+                cnt = tail[32:32 + 8 * g].view(np.int64); keep = tail[32 + 8 * g:32 + 9 * g].view(bool)
+                kept = int(np.count_nonzero(keep))
+                stats["grids_processed"] += kept; stats["grids_skipped"] += g - kept
+                stats["cells_processed"] += int(cnt.sum()) if kept == g else int(cnt[keep].sum())
+                stats["cells_classified_noise"] += int(counts[0]); stats["cells_corrected"] += int(counts[1])
+                stats["total_confidence"] += float(tail[24:32].view(np.float64)[0])
+                if writer is not None:
+                    changed, rec_o = int(counts[2]), slot.out_rec_h.numpy()
+                    if rec_all is not None:
+                        writer.write_records(start0 + lo, rec_o[:n], corrections_applied=changed)
+                    else:
+                        for j in range(g0, g1):
+                            writer.write_records(int(index[j]), rec_o[off[j] - lo:off[j + 1] - lo],
+                                                 corrections_applied=changed if j == g0 else 0)
+                if want_res:
+                    r = slot.res_h.numpy()[:3 * n].reshape(3, n)
+                    if return_results:
+                        res_all[:, lo:hi] = r
+                        r = res_all[:, lo:hi]
+                    elif results_sink is not None:
+                        r = np.array(r)                           # (the sink may keep the arrays; the pinned buffer is reused)
+                    if results_sink is not None:
+                        for j in np.nonzero(keep)[0].tolist():    # the grids iterate_refinements yields, in its order
+                            grid = next(grids_it)
+                            a, b = int(off[g0 + j]) - lo, int(off[g0 + j + 1]) - lo
+                            assert grid.start_index == int(index[g0 + j])
+                            shp = grid.depth.shape
+                            results_sink(grid, r[0, a:b].reshape(shp), r[1, a:b].reshape(shp), r[2, a:b].reshape(shp))
+            finally:
+                collected[k].set()
+
+        # Three roles: THIS thread queues the GPU work of chunk k; a staging thread copies chunk k + 1 into its pinned slab
+        # meanwhile; a collector thread waits for finished chunks and writes them back (array-backed writers only: a sink, or a
+        # file-backed writer, is served from this thread).  The copies are plain memcpy's that release the GIL -- per 256 k-cell
+        # chunk the host otherwise spends as long copying (2 x 2 MB) and issuing as the GPU spends classifying.
+        import threading
+        collected = [threading.Event() for _ in range(nch)]
+        own_collect = results_sink is not None or not (writer is None or getattr(writer, "_file", 0) is None)
+        stager, collector = self._bag_threads()
+        f_stage, f_coll, next_collect = [None] * nch, [], 0
+        try:
+            f_stage[0] = stager.submit(stage, 0)
+            for k in range(nch):
+                if k + 1 < nch:
+                    if own_collect and k + 1 >= S:            # the slot chunk k + 1 is staged into must have been collected
+                        while next_collect <= k + 1 - S:
+                            collect(next_collect); next_collect += 1
+                    f_stage[k + 1] = stager.submit(stage, k + 1)
+                f_stage[k].result()
+                launch(k)
+                if not own_collect:
+                    f_coll.append(collector.submit(collect, k))
+            if own_collect:
+                while next_collect < nch:
+                    collect(next_collect); next_collect += 1
+            for f in f_coll:
+                f.result()
+        finally:                                               # (also after an exception: nothing of ours stays queued or blocked)
+            for e in collected:
+                e.set()
+            for f in [f for f in f_stage if f is not None] + f_coll:
+                try:
+                    f.result()
+                except Exception:
+                    pass
+            for slot in slots:
+                slot.done.synchronize()
         stats["mean_confidence"] = stats["total_confidence"] / stats["cells_processed"] if stats["cells_processed"] else 0
         return (stats, res_all) if return_results else stats
 
@@ -417,7 +593,8 @@ def apply_results(depth: np.ndarray, uncertainty: Optional[np.ndarray], classifi
 
 
 def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_ratio: float = 0.0,
-                    auto_correct_threshold: Optional[float] = None, results_sink=None, pipelined: bool = True):
+                    auto_correct_threshold: Optional[float] = None, results_sink=None, pipelined: bool = True,
+                    records_resident: Optional[bool] = None):
     """The grid-by-grid loop of the reference's ``main`` (:445-538): iterate the refinement grids, queue them
     with ``add_to_batch``, flush when ``batch_ready``, apply each grid's results (``apply_results`` closure,
     :480-503) and write it back with ``update_refinement_batch``.  Kept as the API-level mirror and as the
@@ -432,8 +609,25 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
     queues.  Same records, same sink calls in the same order and the same counts as the synchronous loop
     (``pipelined=False``: one ``flush_batch`` per full batch, exactly the reference's control flow, grid for grid);
     ``total_confidence`` is summed per batch in float64 instead of per grid in numpy's float32 pairwise order (it feeds the
-    logged mean only): equal to ~1e-7 relative, not bit for bit."""
+    logged mean only): equal to ~1e-7 relative, not bit for bit.
+
+    ``records_resident`` (default: decided here): when the handler exposes the BAG's two arrays (``refinement_table()`` /
+    ``varres_refinements``: ``VRBagHandler``) and the writer takes records in bulk (``write_records``), the pipelined call does not
+    walk the grids in Python at all: the records go to the GPU as they are and come back corrected
+    (``NativeVRProcessor.process_refinements``); the sink is still fed grid by grid, in iteration order.  Any other handler /
+    writer (e.g. ``SRBagHandler``, the reference's own classes) takes the loop below, where a pipelined submission gathers
+    ``processor.PIPELINE_COALESCE`` reference-size batches (the results do not depend on how grids are batched)."""
     thr = processor.auto_correct_threshold if auto_correct_threshold is None else auto_correct_threshold
+    can_route = (hasattr(handler, "refinement_table") and hasattr(handler, "varres_refinements") and hasattr(writer, "write_records")
+                 and hasattr(processor, "process_refinements"))
+    if records_resident is None:
+        records_resident = pipelined and can_route
+    if records_resident:
+        if not can_route:
+            raise ValueError("records_resident=True needs a handler with refinement_table() / varres_refinements and a writer with write_records()")
+        st = processor.process_refinements(handler, writer, min_valid_ratio, results_sink=results_sink, auto_correct_threshold=thr)
+        st.pop("grids_skipped", None)                      # (the loop's statistics, key for key)
+        return st
     stats = {"grids_processed": 0, "cells_processed": 0, "cells_classified_noise": 0, "cells_corrected": 0,
              "total_confidence": 0.0}
     nodata = getattr(handler, "NODATA", 1.0e6)
@@ -467,15 +661,23 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
 
     def flat_of(gl, name):
         """The grids' arrays back to back.  Grids of one handler are views of ONE plane (iterate_refinements) and a batch is usually
-        a run of consecutive grids: then this is a slice of that plane, not a concatenation."""
-        a0, a1 = getattr(gl[0], name), getattr(gl[-1], name)
+        a run of consecutive grids: then this is a slice of that plane, not a concatenation.  Only when EVERY grid starts where the
+        one before it ends (the test update_refinements_bulk makes too): a BAG whose metadata index is not monotonic in iteration
+        order can fill the same total span with its grids in another order."""
+        a0 = getattr(gl[0], name)
         base = a0.base
-        if base is not None and a1.base is base and base.ndim == 1 and base.flags.c_contiguous:
+        if base is not None and base.ndim == 1 and base.flags.c_contiguous:
             lo = gl[0].start_index
-            hi = gl[-1].start_index + a1.size
-            if hi - lo == sum(g.depth.size for g in gl) and 0 <= lo and hi <= base.shape[0] and \
-                    a0.ctypes.data == base.ctypes.data + lo * base.itemsize:
-                return base[lo:hi]
+            pos, ok = lo, 0 <= lo and a0.ctypes.data == base.ctypes.data + lo * base.itemsize
+            if ok:
+                for g in gl:
+                    a = getattr(g, name)
+                    if g.start_index != pos or a.base is not base:
+                        ok = False
+                        break
+                    pos += a.size
+            if ok and pos <= base.shape[0]:
+                return base[lo:pos]
         return np.concatenate([getattr(g, name).reshape(-1) for g in gl])
 
     def apply_flat(plist, flat, hw):
@@ -552,7 +754,7 @@ def run_refinements(processor: NativeVRProcessor, handler, writer, min_valid_rat
             # (the iterator already knows the valid-cell count: no second mask pass in add_to_batch)
             pending.append((grid, processor.add_to_batch(grid.depth, grid.uncertainty, grid.resolution, nodata=nodata,
                                                          valid_count=grid.num_valid if nodata == 1.0e6 else None)))
-            if processor.batch_ready:
+            if processor.submit_ready:
                 submit()
         submit()
         while submitted:

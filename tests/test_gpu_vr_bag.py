@@ -112,7 +112,7 @@ def test_process_refinements_equals_grid_loop(in_channels, ratio, budget, gpu_de
     w_loop = h.copy_and_open_for_writing()
     sink = {}
     proc.BATCH_NODE_BUDGET = 4000
-    st_loop = run_refinements(proc, h, w_loop, ratio, results_sink=lambda g, a, b, c: sink.__setitem__(g.start_index, (a, b, c)))
+    st_loop = run_refinements(proc, h, w_loop, ratio, pipelined=False, results_sink=lambda g, a, b, c: sink.__setitem__(g.start_index, (a, b, c)))
     # device path
     w_dev = h.copy_and_open_for_writing()
     st_dev, res = proc.process_refinements(h, w_dev, ratio, cell_budget=budget, return_results=True)
@@ -174,7 +174,7 @@ def test_config4_scale_stream_device_equals_loop(base, min_grids, gpu_device):
     h = VRBagHandler.from_arrays(md, ref)
     assert h.num_refinement_cells >= min_grids
     w_loop, w_dev = h.copy_and_open_for_writing(), h.copy_and_open_for_writing()
-    st_loop = run_refinements(proc, h, w_loop, 0.01)
+    st_loop = run_refinements(proc, h, w_loop, 0.01, pipelined=False)
     st_dev = proc.process_refinements(h, w_dev, 0.01)
     assert np.array_equal(w_dev.refinements.view(np.uint32), w_loop.refinements.view(np.uint32))
     for k in ("grids_processed", "cells_processed", "cells_classified_noise", "cells_corrected"):
@@ -183,37 +183,51 @@ def test_config4_scale_stream_device_equals_loop(base, min_grids, gpu_device):
 
 
 def test_pipelined_grid_loop_equals_the_synchronous_one(gpu_device):
-    """run_refinements with two batches in flight (submit_batch / collect_batch on two library contexts) writes the same
-    records, feeds the sink the same per-grid arrays in the same order and reports the same statistics as the reference-shaped
-    synchronous loop (one flush_batch per full batch); the submit / collect API itself keeps submission order and refuses a
-    third batch in flight."""
+    """run_refinements(pipelined=True) -- (i) the grid loop with two coalesced submissions in flight (submit_batch / collect_batch on two
+    library contexts; ``records_resident=False``), (ii) what it does by default for a VRBagHandler + VRBagWriter: the records-resident
+    whole-BAG path (process_refinements, several chunks in flight) -- writes the same records, feeds the sink the same per-grid
+    arrays in the same order and reports the same statistics as the reference-shaped synchronous loop (one flush_batch per full
+    batch); the submit / collect API itself keeps submission order and refuses a third batch in flight."""
     from bathymetric_gnn_amd import synthetic
     from bathymetric_gnn_amd.data import VRBagHandler
     from bathymetric_gnn_amd.scripts.inference_native import run_refinements
     proc = _processor(8)
-    proc.BATCH_NODE_BUDGET = 3000
+    proc.BATCH_NODE_BUDGET = 1500
+    proc.PIPELINE_COALESCE = 2
+    proc.BAG_CHUNK_MIN = 2500                                             # (the whole-BAG path in ~4 chunks on this small BAG)
     md, ref = synthetic.synthetic_vr_bag(7, 8, seed=123, lo=3, hi=30, empty_fraction=0.1, sparse_fraction=0.05)
     h = VRBagHandler.from_arrays(md, ref)
     runs = {}
-    for mode in (False, True):
+    for name, kw in (("sync", dict(pipelined=False)), ("loop", dict(pipelined=True, records_resident=False)), ("routed", dict(pipelined=True))):
         w = h.copy_and_open_for_writing()
         order, sink = [], {}
-        st = run_refinements(proc, h, w, 0.0, pipelined=mode,
+        chunks = []
+        if name == "routed":
+            launched = proc._bag_slot
+            proc._bag_slot = lambda *a: (chunks.append(a[0]), launched(*a))[1]
+        st = run_refinements(proc, h, w, 0.0, **kw,
                              results_sink=lambda g, a, b, c: (order.append(g.start_index), sink.__setitem__(g.start_index, (a.copy(), b.copy(), c.copy()))))
-        runs[mode] = (w.refinements.copy(), st, order, sink)
+        runs[name] = (w.refinements.copy(), st, order, sink, w._corrections_applied)
         assert proc.batches_in_flight == 0
-    assert len(proc._engines) == 2                                        # the second context was really used
-    a, b = runs[False], runs[True]
-    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-    assert a[2] == b[2] and len(a[2]) > 30
-    for k in a[1]:
-        if k in ("total_confidence", "mean_confidence"):     # per batch in float64 vs per grid in float32 pairwise order (logged mean only)
-            assert abs(a[1][k] - b[1][k]) <= 1e-6 * max(1.0, abs(a[1][k])), k
-        else:
-            assert a[1][k] == b[1][k], k
-    for s0 in a[3]:
-        for x, y in zip(a[3][s0], b[3][s0]):
-            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        if name == "loop":
+            assert len(proc._engines) == 2                                # the second context was really used
+        if name == "routed":
+            del proc._bag_slot
+            assert len(chunks) >= 3 and set(chunks) >= {0, 1, 2}         # several chunks, on several slots (two contexts)
+    a = runs["sync"]
+    for name in ("loop", "routed"):
+        b = runs[name]
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), name
+        assert a[2] == b[2] and len(a[2]) > 30 and a[4] == b[4] > 0, name
+        assert set(a[1]) == set(b[1])
+        for k in a[1]:
+            if k in ("total_confidence", "mean_confidence"):     # per batch in float64 vs per grid in float32 pairwise order (logged mean only)
+                assert abs(a[1][k] - b[1][k]) <= 1e-6 * max(1.0, abs(a[1][k])), (name, k)
+            else:
+                assert a[1][k] == b[1][k], (name, k)
+        for s0 in a[3]:
+            for x, y in zip(a[3][s0], b[3][s0]):
+                assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), name
     # the API: order of collection = order of submission; at most two in flight
     grids = synthetic.vr_grid_stream(9, seed0=900)
     single = [proc.process_grid(d, u, r) for d, u, r in grids]
@@ -326,13 +340,20 @@ def test_pipelined_loop_with_a_foreign_writer_takes_the_per_grid_path(gpu_device
             self.w.update_refinement_batch(grid, d, u)
 
     w_bulk = h.copy_and_open_for_writing()
-    st_bulk = run_refinements(proc, h, w_bulk, 0.0, pipelined=True)
+    st_bulk = run_refinements(proc, h, w_bulk, 0.0, pipelined=True, records_resident=False)     # the loop, bulk write-back
     w_plain = PerGridOnly(h.copy_and_open_for_writing())
-    st_plain = run_refinements(proc, h, w_plain, 0.0, pipelined=True)
+    st_plain = run_refinements(proc, h, w_plain, 0.0, pipelined=True)        # no write_records: cannot be routed, per-grid calls
     assert w_plain.calls == st_plain["grids_processed"] == h.num_refinement_cells
     assert np.array_equal(w_bulk.refinements.view(np.uint32), w_plain.w.refinements.view(np.uint32))
     assert w_bulk._corrections_applied == w_plain.w._corrections_applied
     assert st_bulk == st_plain
+    with pytest.raises(ValueError, match="records_resident"):
+        run_refinements(proc, h, w_plain, 0.0, records_resident=True)
+    w_dev = h.copy_and_open_for_writing()
+    st_dev = run_refinements(proc, h, w_dev, 0.0)                            # default for this handler / writer: records resident
+    assert np.array_equal(w_bulk.refinements.view(np.uint32), w_dev.refinements.view(np.uint32))
+    assert w_bulk._corrections_applied == w_dev._corrections_applied
+    assert all(st_dev[k] == st_bulk[k] for k in st_bulk if "confidence" not in k) and set(st_dev) == set(st_bulk)
 
 
 def test_grid_count_cap_closes_a_batch_and_the_library_names_its_limit(gpu_device):

@@ -191,3 +191,101 @@ def test_bulk_write_back_equals_the_per_grid_calls():
     assert w1._corrections_applied == w2._corrections_applied == changed > 0
     with pytest.raises(ValueError):
         w2.update_refinements_bulk(grids, np.zeros(3, np.float32), None)
+
+
+class _FakeProcessor:
+    """The processor API run_refinements drives (add_to_batch / batch_ready / flush_batch / submit_batch / collect_batch_flat), with
+    per-cell results that are a pure function of the cell's depth -- host logic of the loop without a GPU."""
+    CLASS_NOISE = 2
+    MAX_IN_FLIGHT = 2
+
+    def __init__(self, budget):
+        self.auto_correct_threshold = 0.5
+        self.budget, self.fill, self.count, self.inflight = budget, [], 0, []
+
+    @staticmethod
+    def _results(d):
+        valid = (d != np.float32(1.0e6)) & np.isfinite(d)
+        frac = np.abs(np.where(valid, d, 0)).astype(np.float32) % np.float32(1.0)
+        cls = np.where(valid, np.floor(frac * 3).astype(np.float32), 0).astype(np.float32)
+        conf = np.where(valid, frac, 0).astype(np.float32)
+        corr = np.where(valid, np.float32(0.25) + frac, 0).astype(np.float32)
+        return cls, conf, corr
+
+    def add_to_batch(self, depth, uncertainty, resolution, nodata=1.0e6, valid_count=None):
+        nv = int(np.count_nonzero((depth != nodata) & np.isfinite(depth)))
+        if nv == 0:
+            z = np.zeros(depth.shape, np.float32)
+            return (z, z.copy(), z.copy())
+        self.fill.append(np.array(depth, np.float32)); self.count += nv
+        return None
+
+    batch_ready = property(lambda self: self.count >= self.budget)
+    submit_ready = property(lambda self: self.count >= 2 * self.budget)
+    batch_pending = property(lambda self: bool(self.fill))
+    batches_in_flight = property(lambda self: len(self.inflight))
+
+    def _take(self):
+        grids, self.fill, self.count = self.fill, [], 0
+        return grids
+
+    def flush_batch(self):
+        return [self._results(d) for d in self._take()]
+
+    def submit_batch(self):
+        assert len(self.inflight) < self.MAX_IN_FLIGHT
+        self.inflight.append(self._take())
+
+    def collect_batch_flat(self, copy=True):
+        grids = self.inflight.pop(0)
+        flat = np.stack([np.concatenate([r[k].ravel() for r in map(self._results, grids)]) for k in range(3)])
+        return flat, [d.shape for d in grids]
+
+
+def _permuted_index_bag(seed=21):
+    """A BAG whose metadata index is NOT monotonic in iteration order: the grids' record ranges are dealt out in a shuffled order
+    (still gap-free), so that a batch of consecutive grids spans one contiguous record range in another order."""
+    md, ref = synthetic.synthetic_vr_bag(5, 6, seed=seed, lo=3, hi=14, empty_fraction=0.0, sparse_fraction=0.0)
+    t = vr_bag.refinement_table(md)
+    n_g = len(t["cells"])
+    # (first and last grid stay where they are: a batch that holds the whole BAG then starts at the first record, ends at the last and
+    #  covers exactly its cell count -- everything a check of the END POINTS can see -- with the grids in between in another order)
+    order = np.concatenate([[0], 1 + np.random.default_rng(seed).permutation(n_g - 2), [n_g - 1]])
+    md2, ref2, pos = md.copy(), ref.copy(), 0
+    for k in order:
+        n, i = int(t["cells"][k]), int(t["index"][k])
+        ref2[0, pos:pos + n] = ref[0, i:i + n]
+        md2[t["base_row"][k], t["base_col"][k]]["index"] = pos
+        pos += n
+    return md, ref, md2, ref2
+
+
+@pytest.mark.parametrize("budget", [150, 600, 10 ** 9])
+def test_pipelined_loop_on_a_bag_with_a_non_monotonic_index(budget):
+    """run_refinements(pipelined=True) applies a collected batch in one pass over the grids' arrays 'back to back': that is a slice
+    of the handler's plane only when every grid starts where the one before it ends.  On a BAG with a permuted index the slice
+    shortcut would pair results with the wrong grids' depths; records, sink calls and statistics must equal the synchronous loop's
+    -- and, grid for grid, those of the same BAG stored in iteration order."""
+    from bathymetric_gnn_amd.scripts.inference_native import run_refinements
+    md, ref, md2, ref2 = _permuted_index_bag()
+    h, h2 = VRBagHandler.from_arrays(md, ref), VRBagHandler.from_arrays(md2, ref2)
+    assert h.refinement_table()["contiguous"] and not h2.refinement_table()["contiguous"]
+    runs = {}
+    for name, handler, mode in (("plain", h, False), ("sync", h2, False), ("pipe", h2, True)):
+        w, calls = handler.copy_and_open_for_writing(), []
+        st = run_refinements(_FakeProcessor(budget), handler, w, 0.0, pipelined=mode, records_resident=False,
+                             results_sink=lambda g, a, b, c: calls.append((g.base_row, g.base_col, a.copy(), b.copy(), c.copy())))
+        runs[name] = (w, st, calls)
+    (w_s, st_s, c_s), (w_p, st_p, c_p), (w_0, st_0, c_0) = runs["sync"], runs["pipe"], runs["plain"]
+    assert np.array_equal(w_s.refinements.view(np.uint8), w_p.refinements.view(np.uint8))
+    assert np.any(w_s.refinements["depth"] != ref2["depth"]) and w_s._corrections_applied == w_p._corrections_applied > 0
+    for k in ("grids_processed", "cells_processed", "cells_classified_noise", "cells_corrected"):
+        assert st_s[k] == st_p[k] == st_0[k], k
+    assert abs(st_s["total_confidence"] - st_p["total_confidence"]) < 1e-4 * st_s["total_confidence"]
+    assert len(c_s) == len(c_p) == len(c_0) == h.num_refinement_cells
+    for x, y, z in zip(c_s, c_p, c_0):
+        assert x[:2] == y[:2] == z[:2] and all(np.array_equal(a, b) and np.array_equal(a, c) for a, b, c in zip(x[2:], y[2:], z[2:]))
+    # grid for grid the corrected records of the permuted BAG are those of the BAG in iteration order
+    t, t2 = vr_bag.refinement_table(md), vr_bag.refinement_table(md2)
+    for i, j, n in zip(t["index"], t2["index"], t["cells"]):
+        assert np.array_equal(w_0.refinements[0, i:i + n], w_p.refinements[0, j:j + n])

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""BASELINE config 4 as a whole VR BAG: a synthetic varres_metadata / varres_refinements pair (refinement grids
-3x3 .. 50x50) through NativeVRProcessor.process_refinements (records resident in HBM, one D2H of corrected records)
-and, for comparison, through the reference-shaped grid-by-grid loop (run_refinements, 50 000-node batches).
-Wall clock includes H2D of the records and D2H of the corrected records."""
+"""BASELINE config 4 through the drop-in API on HOST arrays: a synthetic varres_metadata / varres_refinements pair (refinement
+grids 3x3 .. 50x50) through
+  * NativeVRProcessor.process_refinements (records resident in HBM, chunks in flight on two contexts) at several chunk sizes,
+  * run_refinements: synchronous (the reference's control flow), the pipelined grid loop (coalesced submissions), and its default
+    for a VRBagHandler (routed to process_refinements), with and without a results sink.
+Wall clock includes H2D of the records and D2H of the corrected records; the output writer is opened before the clock."""
 import argparse, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,31 +14,42 @@ from bathymetric_gnn_amd.models import BathymetricGNN
 from bathymetric_gnn_amd.scripts.inference_native import NativeVRProcessor, run_refinements
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--base", type=int, default=70, help="base grid is base x base cells (70 -> ~4 100 refinement grids)")
-ap.add_argument("--budget", type=int, default=8 << 20)
-ap.add_argument("--loop", action="store_true", help="also time the grid-by-grid loop")
+ap.add_argument("--base", type=int, nargs="+", default=[28, 70], help="base grid is base x base cells (28 -> 676 grids, 70 -> ~4 100)")
+ap.add_argument("--chunks", type=int, nargs="+", default=[0, 64 << 10, 128 << 10, 256 << 10, 512 << 10, 1 << 20, 8 << 20],
+                help="cell budgets of process_refinements to sweep (0 = its automatic choice)")
+ap.add_argument("--reps", type=int, default=5)
 args = ap.parse_args()
-md, ref = synthetic.synthetic_vr_bag(args.base, args.base, seed=1000)
-h = VRBagHandler.from_arrays(md, ref)
 sd = synthetic.synthetic_state_dict(in_channels=8, seed=1234)
 m = BathymetricGNN(in_channels=8, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
 proc = NativeVRProcessor(m.to("cuda:0").eval(), GraphBuilder(), torch.device("cuda:0"))
-out = {"grids": h.num_refinement_cells, "cells": h.total_refinement_nodes}
-small = VRBagHandler.from_arrays(*synthetic.synthetic_vr_bag(6, 6, seed=1))
-proc.process_refinements(small, small.copy_and_open_for_writing(), 0.01)          # warm-up
-walls = []
-for rep in range(6):                                  # the first repetition still grows the pinned staging buffers
-    w = h.copy_and_open_for_writing()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    st = proc.process_refinements(h, w, 0.01, cell_budget=args.budget)
-    torch.cuda.synchronize(); walls.append(time.perf_counter() - t0)
-dt = float(np.median(walls[1:]))
-out["device_path"] = {"wall_s": dt, "wall_s_all": walls, "nodes_per_s": st["cells_processed"] / dt, "stats": st}
-if args.loop:
-    w2 = h.copy_and_open_for_writing()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    st2 = run_refinements(proc, h, w2, 0.01)
-    torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
-    out["grid_loop"] = {"wall_s": dt2, "nodes_per_s": st2["cells_processed"] / dt2}
-    out["records_equal"] = bool(np.array_equal(w.refinements.view(np.uint32), w2.refinements.view(np.uint32)))
-print(json.dumps(out))
+
+
+def timed(fn, h):
+    walls, st = [], None
+    for _ in range(args.reps + 1):                    # (the first repetition grows the pinned staging buffers)
+        w = h.copy_and_open_for_writing()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        st = fn(h, w)
+        torch.cuda.synchronize(); walls.append(time.perf_counter() - t0)
+    best = min(walls[1:])
+    return {"best_ms": 1e3 * best, "median_ms": 1e3 * float(np.median(walls[1:])), "M_nodes_per_s": st["cells_processed"] / best / 1e6}, w
+
+
+for base in args.base:
+    md, ref = synthetic.synthetic_vr_bag(base, base, seed=4242)
+    h = VRBagHandler.from_arrays(md, ref)
+    out = {"base": base, "grids": h.num_refinement_cells, "cells": h.total_refinement_nodes}
+    for c in args.chunks:
+        out[f"process_refinements chunk={c or 'auto'}"], w_dev = timed(lambda h, w: proc.process_refinements(h, w, 0.0, cell_budget=c or None), h)
+    out["run_refinements synchronous"], w_sync = timed(lambda h, w: run_refinements(proc, h, w, 0.0, pipelined=False), h)
+    out["run_refinements pipelined loop"], w_loop = timed(lambda h, w: run_refinements(proc, h, w, 0.0, records_resident=False), h)
+    out["run_refinements default (routed)"], w_def = timed(lambda h, w: run_refinements(proc, h, w, 0.0), h)
+    n_sink = [0]
+    def sink(g, a, b, c):
+        n_sink[0] += 1
+    out["run_refinements default + sink"], _ = timed(lambda h, w: run_refinements(proc, h, w, 0.0, results_sink=sink), h)
+    out["run_refinements loop + sink"], _ = timed(lambda h, w: run_refinements(proc, h, w, 0.0, results_sink=sink, records_resident=False), h)
+    out["records_equal"] = bool(np.array_equal(w_dev.refinements.view(np.uint32), w_sync.refinements.view(np.uint32)) and
+                                np.array_equal(w_loop.refinements.view(np.uint32), w_sync.refinements.view(np.uint32)) and
+                                np.array_equal(w_def.refinements.view(np.uint32), w_sync.refinements.view(np.uint32)))
+    print(json.dumps(out), flush=True)
