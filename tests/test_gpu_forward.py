@@ -271,6 +271,52 @@ def test_full_batch_properties(gpu_device):
         "calibrated heads: the permutation / repeat checks above compared mixed class and action maps"
 
 
+def test_headline_full_batch_exact_f32_k8_against_the_oracle(gpu_device):
+    """The workload bench.py's headline times, at its own size: 128 tiles of 256 x 256, 8-connected, exact float32, through the
+    per-batch entry (bgnn_infer_tiles).  Size-independent properties -- node count, determinism (the same batch twice: bit-identical),
+    tile independence (a permuted batch gives the permuted grids bit for bit), invalid cells exactly 0 -- and the FIRST and the LAST
+    tile of the batch against the float32 oracle within 1e-4 (confidence, correction; classes equal wherever the oracle's decision
+    is not a tie), with calibrated heads (classes mix on both tiles)."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    B, n, n_distinct = 128, 256, 16
+    depth, mask, _ = synthetic.synthetic_tile_batch(n_distinct, n, n, 100, "V1")
+    depth = np.concatenate([depth + np.float32(0.25 * r) for r in range(B // n_distinct)])      # 128 distinct inputs
+    mask = np.concatenate([mask] * (B // n_distinct))
+    og0 = graph_cpu.build_graph(depth[0], mask[0], None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(seed=1234), og0.x, og0.edge_index, og0.edge_attr)
+    model = _model(sd)
+    gb = GraphBuilder()
+    eng = TileBatchEngine(model, gb, gpu_device)
+    hw = np.tile(np.array([[n, n]], np.int32), (B, 1)); res = np.full((B, 2), 0.5)
+    up = lambda dd, mm: (torch.from_numpy(np.ascontiguousarray(dd)).cuda().reshape(-1),
+                         torch.from_numpy(np.ascontiguousarray(mm).view(np.uint8)).cuda().reshape(-1))
+    nn = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d_t, m_t = up(depth, mask)
+    out = eng.infer_device(hw, res, d_t, m_t, None, n_nodes_out=nn).clone()
+    assert int(nn.item()) == int(mask.sum())
+    assert torch.equal(out, eng.infer_device(hw, res, d_t, m_t, None))                  # deterministic at full size
+    perm = np.random.default_rng(5).permutation(B)
+    out_p = eng.infer_device(hw, res, *up(depth[perm], mask[perm]), None)
+    assert torch.equal(out.reshape(3, B, n * n)[:, perm], out_p.reshape(3, B, n * n))
+    del out_p
+    assert float(out[:, ~m_t.bool()].abs().max()) == 0.0 and bool(torch.isfinite(out).all())
+    grids = out.reshape(3, B, n, n).cpu().numpy()
+    for t in (0, B - 1):
+        og = graph_cpu.build_graph(depth[t], mask[t], None, (0.5, 0.5))
+        ref = gat_cpu.process_tile(sd, og)
+        assert np.abs(grids[1, t] - ref["confidence"]).max() < TOL, (t, float(np.abs(grids[1, t] - ref["confidence"]).max()))
+        assert np.abs(grids[2, t] - ref["correction"]).max() < 2e-4, (t, float(np.abs(grids[2, t] - ref["correction"]).max()))
+        assert len(np.unique(ref["classification"][mask[t]])) == 3, "calibrated heads: the three classes occur on this tile"
+        sure = _sure_grid(sd, og)
+        assert sure.mean() > 0.9 and np.array_equal(grids[0, t][sure], ref["classification"][sure])
+        # and per node through predict(): logits within 1e-4 (the same kernels: the grids above hold these bits)
+        o1 = model.predict(gb.build_graph(depth[t], mask[t], None, (0.5, 0.5)))
+        _compare(o1, gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr), require_mixed=True)
+        assert np.array_equal(grids[1, t][mask[t]], o1["confidence"].cpu().numpy())
+
+
 def test_pipeline_process_grid_matches_oracle(gpu_device):
     """BathymetricPipeline.process (models/pipeline.py:134-241) minus file I/O: overlapping tiles, batched
     fused inference, Hann-ramp stitch, unprocessed-cell preservation, _apply_corrections.  Heads calibrated on a crop of the
