@@ -135,11 +135,6 @@ ProfScope::~ProfScope() {
   if (idx >= 0) (void)hipEventRecord(ctx->prof_records[idx].stop, ctx->stream);
 }
 
-__global__ void copy_rows_kernel(const float *src, float *dst, int width, const int64_t *d_m) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < *d_m * width) dst[i] = src[i];
-}
-
 // x [n][in] -> x8 [n][8], zero padded (the node-feature layout of the graph build)
 __global__ void pad_rows8_kernel(const float *x, int in, float *x8, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,8 +453,123 @@ static void pack_tilegroup_image(const float *Wt, int D, int NC, float *dst, int
         dst[(size_t)k * NC + (t / TG) * 32 * TG + r * TG + t % TG] = Wt[(size_t)k * NC + t * 32 + r];
 }
 
-int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
-  BGNN_REQUIRE(ctx && d && w && out, "bgnn_model_create: NULL argument");
+// ---- model widths the kernels have no instance for: zero padding -------------------------------------------------------------
+// The kernels exist for hidden 32 / 64 / 128 and power-of-two head counts.  Any other width the reference's config allows
+// (config/config.py:43-45: any gnn_hidden_channels / gnn_heads) is embedded in the next supported one: channel c of head h goes to
+// column h * Cp + c, everything else is zero weight, zero bias, BatchNorm (weight 1, bias 0, mean 0, var 1).  A padded channel is
+// then exactly 0.0 at every stage (Linear: 0, ReLU: 0, GATConv: alpha * 0 summed, + bias 0, BatchNorm: (0 - 0) s + 0), a padded
+// head's attention logits are all leaky_relu(0) (a uniform softmax over zeros), and a real channel only ever sees added +0.0 terms:
+// the results of the logical model, in another summation grouping.  Input: the flat blob in bgnn_model_weight_count's order.
+static inline int pad_hidden(int c) { return c <= 32 ? 32 : c <= 64 ? 64 : 128; }
+static inline int pad_heads(int h) { int p = 1; while (p < h) p <<= 1; return p; }
+
+static void pad_model_weights(const bgnn_model_desc *d, const float *w, bgnn_model_desc *dp, std::vector<float> &out) {
+  const bool gat = d->gnn_type == BGNN_GNN_GAT;
+  *dp = *d;
+  dp->hidden = pad_hidden(d->hidden);
+  if (gat) dp->heads = pad_heads(d->heads);
+  const int C = d->hidden, Cp = dp->hidden, Hh = d->heads, in = d->in_channels, hh = C / 2, hhp = Cp / 2, L = d->num_layers, ED = d->edge_dim;
+  out.assign(bgnn_model_weight_count(dp), 0.0f);
+  const float *p = w;
+  float *q = out.data();
+  // index maps: a plain width-C vector, and the concatenation of H heads of C channels
+  auto ident = [](int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; };
+  auto headmap = [&](int H) { std::vector<int> m((size_t)H * C); for (int h = 0; h < H; ++h) for (int c = 0; c < C; ++c) m[(size_t)h * C + c] = h * Cp + c; return m; };
+  // matrix [rows][cols] (torch Linear weight: [out][in]) -> [rows_p][cols_p], vector likewise; `fill` for the pad entries of a vector
+  auto mat = [&](const std::vector<int> &rm, int rows_p, const std::vector<int> &cm, int cols_p) {
+    for (size_t r = 0; r < rm.size(); ++r)
+      for (size_t c = 0; c < cm.size(); ++c) q[(size_t)rm[r] * cols_p + cm[c]] = p[r * cm.size() + c];
+    p += rm.size() * cm.size(); q += (size_t)rows_p * cols_p;
+  };
+  auto vec = [&](const std::vector<int> &m, int n_p, float fill = 0.0f) {
+    for (int i = 0; i < n_p; ++i) q[i] = fill;
+    for (size_t i = 0; i < m.size(); ++i) q[m[i]] = p[i];
+    p += m.size(); q += n_p;
+  };
+  auto batch_norm = [&](const std::vector<int> &m, int n_p) { vec(m, n_p, 1.0f); vec(m, n_p); vec(m, n_p); vec(m, n_p, 1.0f); };   // w, b, mean, var
+  const std::vector<int> mC = ident(C), mIn = ident(in), mHh = ident(hh), mED = ident(ED);
+  mat(mC, Cp, mIn, in); vec(mC, Cp);
+  mat(mC, Cp, mC, Cp); vec(mC, Cp);
+  for (int l = 0; l < L && !gat; ++l) {
+    mat(mC, Cp, mC, Cp); vec(mC, Cp);                                                  // GCN: lin, bias; SAGE: lin_l, bias; GIN: nn.0
+    if (d->gnn_type == BGNN_GNN_SAGE) mat(mC, Cp, mC, Cp);                             // lin_r
+    if (d->gnn_type == BGNN_GNN_GIN) { mat(mC, Cp, mC, Cp); vec(mC, Cp); }             // nn.2
+    batch_norm(mC, Cp);
+  }
+  for (int l = 0; l < L && gat; ++l) {
+    const bool last = l == L - 1;
+    const int H = last ? 1 : Hh, Hp = last ? 1 : dp->heads;
+    const std::vector<int> mOut = headmap(H), mInL = l == 0 ? mC : headmap(Hh);
+    const int outp = Hp * Cp, inp = l == 0 ? Cp : dp->heads * Cp;
+    mat(mOut, outp, mInL, inp);                                                        // lin.weight [HC][D]
+    vec(mOut, outp); vec(mOut, outp); vec(mOut, outp);                                 // att_src, att_dst, att_edge
+    mat(mOut, outp, mED, ED);                                                          // lin_edge.weight [HC][ED]
+    const std::vector<int> &mW = last ? mC : mOut;                                     // (last layer: mean over its one head -> [C])
+    const int wp = last ? Cp : outp;
+    vec(mW, wp);                                                                       // bias
+    batch_norm(mW, wp);
+  }
+  const int nh = head_count(d);
+  for (int k = 0; k < nh; ++k) {
+    const int nout = k == 0 ? d->num_classes : 1;
+    mat(mHh, hhp, mC, Cp); vec(mHh, hhp);                                              // mlp.0
+    mat(ident(nout), nout, mHh, hhp); vec(ident(nout), nout);                          // mlp.3
+  }
+}
+
+__global__ void copy_cols_kernel(const float *src, int src_stride, float *dst, int dst_stride, int n_copy, const int64_t *d_m) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *d_m * dst_stride) return;
+  const int64_t r = i / dst_stride;
+  const int c = (int)(i - r * dst_stride);
+  dst[i] = c < n_copy ? src[r * src_stride + c] : 0.0f;
+}
+
+// rows [*d_m][src_stride] -> [*d_m][dst_stride]: the first n_copy columns, the rest of a destination row zero
+static int launch_copy_cols(bgnn_ctx *ctx, const float *src, int src_stride, float *dst, int dst_stride, int n_copy, const int64_t *d_m,
+                            int64_t rows_cap) {
+  const int64_t n = rows_cap * dst_stride;
+  if (n <= 0) return BGNN_OK;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src, src_stride, dst, dst_stride,
+                     n_copy, d_m);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out);
+
+int bgnn_model_create(bgnn_ctx *ctx, const bgnn_model_desc *d_in, const float *w, size_t n_weights, bgnn_model **out) {
+  BGNN_REQUIRE(ctx && d_in && w && out, "bgnn_model_create: NULL argument");
+  bgnn_model_desc dl = *d_in;                                  // the LOGICAL model
+  BGNN_REQUIRE(dl.gnn_type >= BGNN_GNN_GAT && dl.gnn_type <= BGNN_GNN_GIN, "gnn_type=%d unknown", dl.gnn_type);
+  const bool gat = dl.gnn_type == BGNN_GNN_GAT;
+  if (!gat) dl.heads = 1;                                      // (`heads` only shapes a GAT backbone: models/gnn.py:125-143)
+  BGNN_REQUIRE(dl.hidden >= 2 && dl.hidden <= 128, "hidden_channels=%d unsupported (2..128)", dl.hidden);
+  BGNN_REQUIRE(dl.heads >= 1 && dl.heads <= 256 && pad_heads(dl.heads) * pad_hidden(dl.hidden) <= 512,
+               "heads=%d x hidden_channels=%d unsupported: the layer is laid out as %d heads of %d channels (next power of two x next of "
+               "32 / 64 / 128), which must stay within 512 columns", dl.heads, dl.hidden, pad_heads(dl.heads), pad_hidden(dl.hidden));
+  BGNN_REQUIRE(dl.in_channels >= 1 && dl.in_channels <= 8, "in_channels=%d unsupported (1..8)", dl.in_channels);
+  BGNN_REQUIRE(dl.num_layers >= 1 && dl.num_layers <= 64, "num_gnn_layers=%d unsupported", dl.num_layers);
+  BGNN_REQUIRE(!gat || (dl.edge_dim >= 1 && dl.edge_dim <= 4), "edge_dim=%d unsupported (1..4)", dl.edge_dim);
+  BGNN_REQUIRE(dl.num_classes >= 1 && dl.num_classes <= 16, "num_classes=%d unsupported", dl.num_classes);
+  BGNN_REQUIRE(n_weights == bgnn_model_weight_count(&dl), "weight blob has %zu floats, expected %zu", n_weights,
+               bgnn_model_weight_count(&dl));
+  const bool padded = pad_hidden(dl.hidden) != dl.hidden || (gat && pad_heads(dl.heads) != dl.heads);
+  int rc;
+  if (!padded) {
+    rc = model_create_native(ctx, &dl, w, n_weights, out);
+  } else {
+    bgnn_model_desc dp;
+    std::vector<float> wp;
+    pad_model_weights(&dl, w, &dp, wp);
+    rc = model_create_native(ctx, &dp, wp.data(), wp.size(), out);
+  }
+  if (rc != BGNN_OK) return rc;
+  (*out)->logical_hidden = dl.hidden; (*out)->logical_heads = dl.heads; (*out)->padded = padded;
+  return BGNN_OK;
+}
+
+static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const float *w, size_t n_weights, bgnn_model **out) {
   // (the generic kernels take 32 / 64 / 128 as long as a layer stays within 256 columns -- the heads' hidden/2 has to be a multiple of
   //  16 and their three first layers side by side a multiple of 32; the fused kernels exist for hidden 64 only, the reference's
   //  default: config/config.py:41)
@@ -1343,10 +1453,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       if (dp && relu) BGNN_TRY(drop(Y, L.width, dp->p_features, 64 + (uint32_t)l));     // (a single-layer backbone has no ReLU: never)
     }
   }
-  if (o->hidden) {
-    const int64_t n = rows * hid;
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, Y, o->hidden, hid, dm);
-  }
+  if (o->hidden)                  // [N][logical hidden]: a padded model's pad columns (all zero) stay inside
+    BGNN_TRY(launch_copy_cols(ctx, Y, hid, o->hidden, m->logical_hidden, m->logical_hidden, dm, rows));
   // heads (gnn.py:392-406)
   BGNN_TRY(launch_gemm_f32(ctx, Y, hid, m->hd_W0t, m->hd_b0, hidb, m->head_hidden_total, dm, rows, hid,
                            m->head_hidden_total, 1));
@@ -1388,7 +1496,11 @@ int bgnn_feature_extractor(bgnn_ctx *ctx, bgnn_model *m, const float *x, int64_t
                      (float *)px8, n_nodes);
   BGNN_HIP_CHECK(hipGetLastError());
   BGNN_TRY(launch_gemm_f32(ctx, (const float *)px8, 8, m->fe_W0t, m->fe_b0, (float *)ph, hid, dn, n_nodes, 8, hid, 1));
-  BGNN_TRY(launch_gemm_f32(ctx, (const float *)ph, hid, m->fe_W1t, m->fe_b1, out, hid, dn, n_nodes, hid, hid, 0));
+  if (!m->padded) return launch_gemm_f32(ctx, (const float *)ph, hid, m->fe_W1t, m->fe_b1, out, hid, dn, n_nodes, hid, hid, 0);
+  void *po;                                               // padded width: out is [n][logical hidden]
+  BGNN_TRY(ctx_workspace(ctx, 2, (size_t)n_nodes * hid * sizeof(float), &po));
+  BGNN_TRY(launch_gemm_f32(ctx, (const float *)ph, hid, m->fe_W1t, m->fe_b1, (float *)po, hid, dn, n_nodes, hid, hid, 0));
+  BGNN_TRY(launch_copy_cols(ctx, (const float *)po, hid, out, m->logical_hidden, m->logical_hidden, dn, n_nodes));
   return BGNN_OK;
 }
 
@@ -1405,6 +1517,12 @@ int bgnn_heads(bgnn_ctx *ctx, bgnn_model *m, const float *hidden, int64_t n_node
   BGNN_TRY(ctx_workspace(ctx, 3, (size_t)n_nodes * m->head_hidden_total * sizeof(float), &phid));
   int64_t *dn;
   BGNN_TRY(row_count_on_device(ctx, n_nodes, &dn));
+  if (m->padded) {                                        // hidden is [n][logical hidden]: widen it with zero columns
+    void *pw;
+    BGNN_TRY(ctx_workspace(ctx, 1, (size_t)n_nodes * hid * sizeof(float), &pw));
+    BGNN_TRY(launch_copy_cols(ctx, hidden, m->logical_hidden, (float *)pw, hid, m->logical_hidden, dn, n_nodes));
+    hidden = (const float *)pw;
+  }
   BGNN_TRY(launch_gemm_f32(ctx, hidden, hid, m->hd_W0t, m->hd_b0, (float *)phid, m->head_hidden_total, dn, n_nodes, hid,
                            m->head_hidden_total, 1));
   BGNN_TRY(launch_heads_final(ctx, m, (const float *)phid, m->head_hidden_total, dn, n_nodes, thr_auto, thr_review, o));
@@ -1425,6 +1543,11 @@ int bgnn_forward_train_dropout(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, cons
     if (ps[0] == 0.0f && ps[1] == 0.0f && ps[2] == 0.0f && ps[3] == 0.0f) dropout = nullptr;
   }
   BGNN_REQUIRE(m->ctx == ctx && g->ctx == ctx, "bgnn_forward_train: model/graph belong to another context");
+  if (m->padded) {      // (batch statistics and dropout draws are laid out over the layer widths the caller sees)
+    set_error("bgnn_forward_train: hidden_channels=%d / heads=%d run zero-padded to %d / %d; the training-mode forward exists for "
+              "hidden 32 / 64 / 128 and power-of-two head counts only", m->logical_hidden, m->logical_heads, m->desc.hidden, m->desc.heads);
+    return BGNN_ERR_UNSUPPORTED;
+  }
   BGNN_REQUIRE(!o->action && !o->needs_review && !o->auto_correct, "bgnn_forward_train: the deployment flags belong to predict()");
   BGNN_HIP_CHECK(hipSetDevice(ctx->device));
   int64_t c[4];

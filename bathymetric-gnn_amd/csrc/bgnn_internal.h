@@ -160,7 +160,9 @@ struct BgnnLayer {
 
 struct bgnn_model {
   bgnn_ctx *ctx;
-  bgnn_model_desc desc;
+  bgnn_model_desc desc;       // the shape the KERNELS run: hidden / heads zero-padded to a supported width (bgnn_model_create)
+  int logical_hidden = 0, logical_heads = 0;   // the caller's shape: widths of `hidden` in / out, bgnn_model_weight_count
+  bool padded = false;
   float *blob = nullptr;      // one device allocation holding everything below
   size_t blob_floats = 0;
   float *fe_W0t, *fe_b0, *fe_W1t, *fe_b1;     // [in8][hid], [hid], [hid][hid], [hid]

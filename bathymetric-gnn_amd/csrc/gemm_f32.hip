@@ -731,9 +731,11 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
                     const float *front_W0t, const float *front_b0, const float *Wt_pm, const float *Wt_blk) {
   if (NC > 256) {
     // a layer wider than 256 columns (heads x hidden up to 512): one launch of the generic kernel per 256-column block of the
-    // blocked weight image; a block's heads write their attention dots into their columns of the shared [M][2 H] table
-    BGNN_REQUIRE(Wt_blk && NC % 256 == 0 && NC <= 512 && split_mode == 0 && !front_W0t && (!att_src || (C > 0 && 256 % C == 0)),
-                 "gemm_f32: NC=%d needs the blocked weight image (exact path, no fused front)", NC);
+    // blocked weight image; a block's heads write their attention dots into their columns of the shared [M][2 H] table.  The opt-in
+    // operand-split paths (split_mode 1 / 2) have no instance here and run exact f32, like every other shape without one.
+    BGNN_REQUIRE(split_mode != 3, "gemm_f32: NC=%d has no bf16-output form", NC);
+    BGNN_REQUIRE(Wt_blk && NC % 256 == 0 && NC <= 512 && !front_W0t && (!att_src || (C > 0 && 256 % C == 0)),
+                 "gemm_f32: NC=%d needs the blocked weight image (no fused front)", NC);
     for (int b = 0; b < NC / 256; ++b) {
       ProfScope ps(ctx, BGNN_K_GEMM);
       GemmArgs a{X, Wt_blk + (size_t)b * K * 256, bias ? bias + b * 256 : nullptr, Y + b * 256, d_m, att_src ? att_src + b * 256 : nullptr,

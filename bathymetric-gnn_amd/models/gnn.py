@@ -203,6 +203,19 @@ class BathymetricGNN(nn.Module):
         self.gnn_type = gnn_type
         self.predict_correction = predict_correction
         self.num_classes = num_classes
+        # The reference's config takes any hidden_channels / heads (config/config.py:43-45).  The kernels exist for hidden 32 / 64 /
+        # 128 and power-of-two head counts; any other shape runs zero-padded to the next of those (bgnn_model_create: results
+        # unchanged), as long as the padded layer -- heads rounded up to a power of two x hidden rounded up to 32 / 64 / 128 -- stays
+        # within 512 columns.  What does not fit is refused HERE, by the constructor the reference's user calls.
+        if not 2 <= int(hidden_channels) <= 128:
+            raise ValueError(f"hidden_channels={hidden_channels} is not supported by the MI355X kernels (2..128)")
+        if gnn_type == "GAT":
+            pad_c = 32 if hidden_channels <= 32 else 64 if hidden_channels <= 64 else 128
+            pad_h = 1 << max(0, int(heads) - 1).bit_length()
+            if int(heads) < 1 or pad_h * pad_c > 512:
+                raise ValueError(f"heads={heads} x hidden_channels={hidden_channels} is not supported by the MI355X kernels: a layer is "
+                                 f"laid out as {pad_h} heads of {pad_c} channels (next power of two x next of 32 / 64 / 128), which must "
+                                 "stay within 512 columns")
         self.in_channels, self.hidden_channels, self.heads = in_channels, hidden_channels, heads
         self.num_gnn_layers, self.edge_dim = num_gnn_layers, edge_dim
         self.feature_extractor = LocalFeatureExtractor(in_channels, hidden_channels, hidden_channels, 2, dropout)

@@ -171,7 +171,7 @@ def compact_line(line, budget=LINE_BUDGET):
     """The stdout line within `budget` bytes: optional keys are dropped (least important first) until it fits; the contract
     keys, roofline and cpu_baseline are never dropped."""
     out = dict(line)
-    for k in ("opt_in_split", "matrix_path", "path", "gnn_types", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
+    for k in ("opt_in_split", "matrix_path", "path", "generic_shape", "gnn_types", "pcie_inclusive", "single_tile", "gpu_over_cpu", "survey", "config5", "config4", "config3", "detail"):
         if len(json.dumps(out)) <= budget:
             break
         out.pop(k, None)
@@ -299,10 +299,11 @@ def spawn_ranks(n, argv, env=None, python=None, poll_s=0.2):
 class Bench:
     """Model, graph builders and engines of one rank; builds the workloads and times them with one protocol."""
 
-    def __init__(self, dev, rank, world, layers, dist=None):
+    def __init__(self, dev, rank, world, layers, dist=None, hidden=64, heads=4):
         from bathymetric_gnn_amd import runtime as rt, synthetic
         self.rt, self.syn = rt, synthetic
         self.dev, self.rank, self.world, self.layers, self.dist = dev, rank, world, layers, dist
+        self.hidden, self.heads = hidden, heads
         self._models = {}
         self.ctx = rt.get_context(dev)
         self.nn_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -311,8 +312,10 @@ class Bench:
         from bathymetric_gnn_amd.models import BathymetricGNN
         key = (in_ch, gnn_type)
         if key not in self._models:
-            sd = self.syn.synthetic_state_dict(in_channels=in_ch, num_layers=self.layers, seed=1234, gnn_type=gnn_type)
-            m = BathymetricGNN(in_channels=in_ch, num_gnn_layers=self.layers, gnn_type=gnn_type, edge_dim=3, dropout=0.0)
+            sd = self.syn.synthetic_state_dict(in_channels=in_ch, num_layers=self.layers, seed=1234, gnn_type=gnn_type,
+                                               hidden=self.hidden, heads=self.heads)
+            m = BathymetricGNN(in_channels=in_ch, num_gnn_layers=self.layers, gnn_type=gnn_type, edge_dim=3, dropout=0.0,
+                               hidden_channels=self.hidden, heads=self.heads)
             m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
             self._models[key] = (m.to(self.dev).eval(), sd)
         return self._models[key]
@@ -357,7 +360,7 @@ class Bench:
                 "unfused": unfused, "B": B, "S": S, "eng": eng, "gb": gb, "host": (depth, mask), "dev_in": (d_t, m_t),
                 "events_in_timed_region": True, "scaling": "weak", "gnn_type": gnn_type,
                 "name": (f"{B} tiles of {S}x{S} per GPU per step, {conn} (k={DEG[conn]}), {self.layers}-layer {gnn_type} "
-                         f"(hidden 64{', heads 4' if gnn_type == 'GAT' else ''}), mask {variant}, inputs resident in HBM"
+                         f"(hidden {self.hidden}{f', heads {self.heads}' if gnn_type == 'GAT' else ''}), mask {variant}, inputs resident in HBM"
                          + (", layer activations stored as bf16 (bf16 MFMA, f32 softmax / aggregation / accumulation)" if bf16 else ""))}
 
     # -- configs[3]: ragged refinement grids, packed greedily in stream order until the node budget is reached -----------
@@ -593,7 +596,7 @@ class Bench:
         """value / ms_per_step / rooflines / kernels of one measured workload (rank 0's kernel events)."""
         steps, prof = m["steps"], m["prof"]
         am = algorithmic_model(num_layers=self.layers, deg=wl["deg"], act_bytes=2 if wl["bf16"] else 4,
-                               in_ch=8 if wl["kind"] == "vr" else 7)
+                               in_ch=8 if wl["kind"] == "vr" else 7, hidden=self.hidden, heads=self.heads)
         n_local = wl["nodes_per_step"] * steps
         kernels = {k: {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps} for k, v in prof.items() if v["launches"]}
 
@@ -706,6 +709,9 @@ def main():
     ap.add_argument("--tile-size", type=int, default=256)
     ap.add_argument("--variant", default="V0", choices=["V0", "V1"])
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--hidden", type=int, default=64, help="gnn_hidden_channels (config/config.py:43): 64 is the fused kernels' shape; "
+                    "32 / 128 run the generic GEMM + aggregate kernels, anything else zero-padded to the next of those")
+    ap.add_argument("--heads", type=int, default=4, help="gnn_heads (config/config.py:45): 1 / 2 / 4 fused (hidden 64), otherwise generic kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (no config3 / config4 / config5 / PCIe-inclusive / split-path / single-tile side "
@@ -766,7 +772,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)     # RCCL: the timing barrier / max; the survey workload's halo rows
 
-    bench = Bench(dev, rank, world, args.layers, dist)
+    bench = Bench(dev, rank, world, args.layers, dist, hidden=args.hidden, heads=args.heads)
     S, B = args.tile_size, args.tiles
     mp = "bf16" if (args.bf16 or args.workload == "c3") else "fp16x3" if args.split_f16 else "bf16x3" if args.split_bf16 else None
     if args.workload in ("tiles", "c3"):
@@ -962,6 +968,19 @@ def main():
                 line["config4"]["whole_bag"] = api["whole_bag"]["value"]
             guarded("config4", _c4)
             torch.cuda.empty_cache()
+
+            def _generic_shape():
+                # a model shape OUTSIDE the fused kernels' (hidden 64, heads <= 4): what leaving the fused path costs.  96 x 2 heads runs
+                # zero-padded as 128 x 2 on the generic GEMM + LDS-tiled aggregate kernels.
+                b2 = Bench(dev, rank, world, args.layers, dist, hidden=96, heads=2)
+                w = b2.tiles(B, S, args.variant, "8-connected")
+                r = b2.report(w, b2.measure(w, max(3, min(args.steps, 5)), 1))
+                detail["generic_shape"] = dict(r, shape="hidden 96, heads 2 (zero-padded to 128 x 2; generic kernels)")
+                line["generic_shape"] = {"hidden": 96, "heads": 2, "value": r["value"], "ms_per_step": r["ms_per_step"]}
+                del w, b2
+            if (args.hidden, args.heads) == (64, 4):
+                guarded("generic_shape", _generic_shape)
+                torch.cuda.empty_cache()
 
             def _backbones():
                 detail["gnn_types"], line["gnn_types"] = {}, {}

@@ -175,6 +175,64 @@ def test_layers_wider_than_256_columns(heads, hidden, layers, gpu_device):
         assert (n.module.running_mean.cpu() - stats[f"gnn.norms.{l}.module.running_mean"]).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("heads,hidden,layers,gnn_type", [(3, 48, 4, "GAT"), (2, 96, 3, "GAT"), (3, 20, 2, "GAT"), (5, 24, 3, "GAT"),
+                                                          (1, 72, 1, "GAT"), (4, 48, 3, "GCN"), (4, 100, 2, "GraphSAGE"), (4, 40, 2, "GIN")])
+def test_model_widths_the_kernels_have_no_instance_for(heads, hidden, layers, gnn_type, gpu_device):
+    """The reference's config takes any gnn_hidden_channels / gnn_heads (config/config.py:43-45).  Shapes outside hidden 32 / 64 / 128
+    and power-of-two heads run zero-padded to the next supported shape inside bgnn_model_create; against the oracle of the LOGICAL
+    model at the same 1e-4 -- logits, probabilities, confidence, correction, flags, and the backbone output [N, hidden] at its
+    logical width.  48 x 3 heads lands on the fused kernels' shape (64 x 4)."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    d, mk, _ = synthetic.synthetic_tile(41, 37, 13, "V1")
+    og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=7, hidden=hidden, heads=heads, num_layers=layers, seed=41, gnn_type=gnn_type),
+                         og.x, og.edge_index, og.edge_attr)
+    m = BathymetricGNN(in_channels=7, hidden_channels=hidden, heads=heads, num_gnn_layers=layers, gnn_type=gnn_type, edge_dim=3, dropout=0.0)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.to(gpu_device).eval()
+    g = GraphBuilder().build_graph(d, mk, None, (0.5, 0.5))
+    ref = gat_cpu.predict(sd, og.x, og.edge_index, og.edge_attr)
+    _compare(m.predict(g), ref)
+    out = m._run(g, 0.85, 0.6, with_flags=False, want_hidden=True)
+    assert out["hidden"].shape == (og.x.shape[0], hidden)
+    assert (out["hidden"].cpu() - ref["hidden"]).abs().max().item() < TOL
+    # the sub-modules at their logical widths: extractor out [N, hidden], heads in [N, hidden]
+    x = torch.from_numpy(og.x).to(gpu_device)
+    fe = m.feature_extractor(x)
+    assert fe.shape == (og.x.shape[0], hidden)
+    fe_ref = gat_cpu._mlp2(torch.from_numpy(og.x), sd, "feature_extractor.mlp.0", "feature_extractor.mlp.3", torch.float32)
+    assert (fe.cpu() - fe_ref).abs().max().item() < TOL
+    assert (m.confidence_head(out["hidden"]).cpu().reshape(-1) - ref["confidence"]).abs().max().item() < TOL
+    # the fused tile path (bgnn_infer_tiles) on the same model
+    from bathymetric_gnn_amd.models.pipeline import TileBatchEngine
+    grids = TileBatchEngine(m, GraphBuilder(), gpu_device).infer([d], [mk], None, [(0.5, 0.5)])[0]
+    pt = gat_cpu.process_tile(sd, og)
+    assert np.abs(grids["confidence"] - pt["confidence"]).max() < TOL and np.abs(grids["correction"] - pt["correction"]).max() < 2e-4
+    # training-mode forward: laid out over the caller's widths -- native shapes only
+    m.train()
+    with pytest.raises(NotImplementedError, match="zero-padded"):
+        m(g)
+
+
+def test_wide_layer_with_an_operand_split_path_runs_exact(gpu_device):
+    """heads x hidden = 512 under the opt-in bf16x3 / fp16x3 matrix paths: no split instance exists for the blocked generic GEMM, so those
+    layers run exact f32 like every other shape without one (it used to fail on layer 0); the narrow last layer and the heads
+    still take their split instances, so the logits sit within the split paths' distance of the exact ones, not on them."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.data import GraphBuilder
+    d, mk, _ = synthetic.synthetic_tile(33, 40, 3, "V1")
+    og = graph_cpu.build_graph(d, mk, None, (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(heads=8, num_layers=3, seed=9), og.x, og.edge_index, og.edge_attr)
+    model = _model(sd, heads=8, num_layers=3)
+    g = GraphBuilder().build_graph(d, mk, None, (0.5, 0.5))
+    exact = model.predict(g)["class_logits"].clone()
+    for path in ("bf16x3", "fp16x3"):
+        _set_matrix_path(path)
+        assert (model.predict(g)["class_logits"] - exact).abs().max().item() < 2e-5
+
+
 def test_batched_equals_per_graph_and_vr_processor(gpu_device):
     """NativeVRProcessor semantics (scripts/inference_native.py:249-342): batched flush == per-grid
     processing == oracle; empty grids return zeros immediately.  Heads calibrated on the first eight grids' block-diagonal

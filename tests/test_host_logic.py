@@ -150,3 +150,14 @@ def test_training_mode_dropout_spec_and_counter_hash():
     s = m._dropout_spec()
     assert round(s.p_features, 6) == 0.3 and round(s.p_heads, 6) == 0.2
     assert BathymetricGNN(in_channels=7, edge_dim=3, dropout=0.0)._dropout_spec() is None
+
+
+def test_model_shapes_that_stay_refused_say_so_in_the_constructor():
+    from bathymetric_gnn_amd.models import BathymetricGNN
+    for kw, what in ((dict(hidden_channels=160), "hidden_channels=160"), (dict(hidden_channels=1), "hidden_channels=1"),
+                     (dict(hidden_channels=96, heads=5), "8 heads of 128"), (dict(hidden_channels=64, heads=9), "16 heads of 64"),
+                     (dict(heads=0), "heads=0")):
+        with pytest.raises(ValueError, match=what):
+            BathymetricGNN(in_channels=7, **kw)
+    BathymetricGNN(in_channels=7, hidden_channels=80, heads=4)                            # 4 heads of 128: fits
+    BathymetricGNN(in_channels=7, hidden_channels=100, heads=9, gnn_type="GCN")           # heads does not shape a plain backbone
