@@ -56,21 +56,38 @@ __global__ __launch_bounds__(256, 3) void gat_aggregate_tiled_kernel(TiledArgs a
   if (my >= 0) attention_coefficients<H, K, 0, H>(my, self_idx, hid, has, a.asd, a.eattr, a.V, a.ED, alf);
 
   // ---- phase B: slab by slab --------------------------------------------------------------------
-#pragma unroll
-  for (int s = 0; s < NSLAB; ++s) {
-    constexpr int NLOAD = (HR * 8 + 255) / 256;
+  // The rows of slab s + 1 are requested (into registers) right after slab s's sums have gone to the stage, i.e. BEFORE the slab's
+  // output stores: their latency runs under the BatchNorm / store pass and the two barriers around it instead of at the head of the
+  // next step.  (The accumulators are dead by then, so the 11 float4 of a thread's share fit where they were.)
+  constexpr int NLOAD = (HR * 8 + 255) / 256;
+  float4 pre[NLOAD];
+  // (every step derives its lane geometry from an OPAQUE copy of the thread id: after the full unroll hipcc otherwise shares the
+  //  cell / row indices of all eight steps, keeps them alive side by side and spills them -- 16 to 76 bytes per lane at k = 8)
+  auto request = [&](int s) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
 #pragma unroll
     for (int p = 0; p < NLOAD; ++p) {
-      const int it = tid + p * 256;
+      const int it = t + p * 256;
+      pre[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it < HR * 8) {
         const int row = it >> 3, q = it & 7;
         int id = hid[row];
         asm volatile("" : "+v"(id));        // re-derive the row address per slab: as loop invariants the 11 + 8 pointers
                                             // are spilled, and every reload waits for the previous slab's stores
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0) v = *reinterpret_cast<const float4 *>(a.xw + (int64_t)id * HC + s * 32 + q * 4);
-        *reinterpret_cast<float4 *>(slab + row * TILED_PITCH + q * 4) = v;
+        if (id >= 0) pre[p] = *reinterpret_cast<const float4 *>(a.xw + (int64_t)id * HC + s * 32 + q * 4);
       }
+    }
+  };
+  request(0);
+#pragma unroll
+  for (int s = 0; s < NSLAB; ++s) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int p = 0; p < NLOAD; ++p) {
+      const int it = t + p * 256;
+      if (it < HR * 8) *reinterpret_cast<float4 *>(slab + (it >> 3) * TILED_PITCH + (it & 7) * 4) = pre[p];
     }
     __syncthreads();
     const int hh = s / SPH;   // compile-time after the full unroll
@@ -90,15 +107,16 @@ __global__ __launch_bounds__(256, 3) void gat_aggregate_tiled_kernel(TiledArgs a
     }
     __syncthreads();                      // every gather of this slab is done: reuse it as the stage
 #pragma unroll
-    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(slab + tid * TILED_PITCH + q * 4) = acc[q];
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(slab + t * TILED_PITCH + q * 4) = acc[q];
+    if (s + 1 < NSLAB) request(s + 1);
     __syncthreads();
     {
-      const int q = tid & 7;
+      const int q = t & 7;
       const float4 sc = *reinterpret_cast<const float4 *>(a.scale + s * 32 + q * 4);
       const float4 sh = *reinterpret_cast<const float4 *>(a.shift + s * 32 + q * 4);
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const int cell = p * 32 + (tid >> 3);
+        const int cell = p * 32 + (t >> 3);
         int id = hid[(cell / TW + 1) * HW_ + (cell % TW) + 1];
         asm volatile("" : "+v"(id));
         if (id >= 0) {

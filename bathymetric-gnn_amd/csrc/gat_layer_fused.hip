@@ -549,7 +549,10 @@ struct FusedLds {       // LDS budget of one workgroup, in floats (kernel and la
 // and for 1 .. 3 the layer is aggregate -> GEMM -> per-column scale / shift (+ ReLU) -> h_{l+1}: the post-op vectors ride where the
 // attention vectors ride (a.att_src = scale, a.att_dst = shift), the pre-GEMM scale / shift are the identity.  (GCN: A (X W) = (A X) W.)
 template <int HC, int C, int K, int NT, int EPI, int SP = 0, int AGG = 0>     // SP: 0 exact f32, 1 bf16x3, 2 fp16x3, 3 bf16 storage + MFMA
-__global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) void gat_layer_fused_kernel(FusedArgs a) {
+// (register budget: what the LDS footprint allows per CU -- except the plain backbones on the 16-slot stencil, whose aggregate
+//  coefficients (GCN's degree products / GIN's ones over 17 sources, in full float32) do not fit three workgroups' 168 registers:
+//  they spilled 140 bytes per lane there and run two per CU instead)
+__global__ __launch_bounds__(256, (AGG != 0 && K == 16 ? 2 : FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) void gat_layer_fused_kernel(FusedArgs a) {
   static_assert(AGG == 0 || (SP == 0 && EPI == EPI_NEXT), "the plain backbones run on the exact path, layer form");
   static_assert(AGG != 2 || HC == 2 * C, "GraphSAGE: two virtual heads");
   constexpr int SRCW = AGG == 2 ? C : HC;                // channels of a SOURCE row (GraphSAGE: both virtual heads read the same C)
@@ -1213,9 +1216,15 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
   // smaller than the four patches, which then reach into wbuf: wait until every wave has read its last W fragments.
   if (EPI == EPI_NEXT && Lds::SLAB < 4 * 32 * TILED_PITCH) __syncthreads();
   if (!DBG(64)) {
-    const int mr = tr, mc = tc;
+    // (the cell's block coordinates from an OPAQUE copy of the lane id: hipcc otherwise shares `pos.r0 + tr` / `pos.c0 + tc` with the
+    //  prologue's bounds tests, keeps both alive across the whole slab loop and, where an instance sits at its register limit --
+    //  k = 16 at three workgroups per CU --, spills them)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int cell_e = wave * 32 + (lane_e & 31);
+    const int mr = cell_e / TILE_W, mc = cell_e % TILE_W;
     // (HID_IN_ALPHA: the halo id table was overwritten by the dense alpha matrices; the compact per-cell table is still there)
-    const int id = Lds::HID_IN_ALPHA ? cid[cell] : hid[self_idx];
+    const int id = Lds::HID_IN_ALPHA ? cid[cell_e] : hid[(mr + RAD) * HW_ + mc + RAD];
     if (EPI == EPI_NEXT) {
       // next layer's attention dots (its width per head is C as well): tile t belongs to head t / (C/32).
       // att_src / att_dst were staged into LDS: no global-load latency chain here.
@@ -1328,11 +1337,12 @@ __global__ __launch_bounds__(256, (FusedLds<HC, C, K, NT, EPI, SP>::PER_CU)) voi
       const int ncls = a.classes;
       float lg[4] = {0.f, 0.f, 0.f, 0.f};
       float sc = 0.0f, sr = 0.0f;
+      const int hl_e = lane_e >> 5;                      // (from the opaque lane id, like cell_e: `4 * hl` is shared with the prologue's attention-dot address)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int c0 = 8 * g + 4 * hl;                 // unit index within the head
+          const int c0 = 8 * g + 4 * hl_e;               // unit index within the head
           const float4 b4 = *reinterpret_cast<const float4 *>(attl + t * 32 + c0);
           float v[4] = {acc[t][4 * g] + b4.x, acc[t][4 * g + 1] + b4.y, acc[t][4 * g + 2] + b4.z,
                         acc[t][4 * g + 3] + b4.w};
@@ -2087,8 +2097,13 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
   const uint32_t bq0 = dn0 + r * Win::PITCH + hl * 16;
   uint32_t tr0, tr1;
   {
+    // (an opaque copy of hl for this one-off address: hipcc otherwise shares `hl << 3` with phase 2's patch offsets, keeps it alive
+    //  across phase A and phase 1 and -- at k = 16 -- spills it; the reload then sat in pass 0's epilogue behind an s_waitcnt vmcnt(0),
+    //  i.e. behind the W DMA of pass 1 the epilogue is meant to run under)
+    int hl1 = hl;
+    asm volatile("" : "+v"(hl1));
     const int grp = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, cb = grp & 1;
-    const int row0 = wbase + 8 * hl + q;
+    const int row0 = wbase + 8 * hl1 + q;
     const int c = 2 * cb + (p4 >> 1);
     tr0 = slab0 + row0 * 64 + ((c ^ ((row0 >> 2) & 3)) << 4) + 8 * (p4 & 1);
     tr1 = slab0 + (row0 + 4) * 64 + ((c ^ (((row0 + 4) >> 2) & 3)) << 4) + 8 * (p4 & 1);
@@ -2195,17 +2210,15 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
   // first pass's barrier also orders every wave's last scale / shift read before the first patch write)
   const uint32_t wfrag = lds_addr(wpass) + lane * 16;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 ps[NPASS], pd[NPASS];
-#pragma unroll
-  for (int hd = 0; hd < NPASS; ++hd) { ps[hd] = (f32x2){0.f, 0.f}; pd[hd] = (f32x2){0.f, 0.f}; }
+  // (a pass's two-lane partial dots are folded to one float per head as soon as the pass is over -- the same `x + y` the end of the
+  //  kernel used to do -- and the row stores keep the node id, not the 64-bit row pointer: 12 registers less across the passes,
+  //  which is what the k = 16 instance lacked at three workgroups per CU)
+  float sl_[NPASS], dl_[NPASS];
   const int id = cid[cell];
   constexpr int NSTORE = 4;
-  char *prow[NSTORE];
+  int rid_[NSTORE];
 #pragma unroll
-  for (int k = 0; k < NSTORE; ++k) {
-    const int rid = cid[wave * 32 + (lane >> 3) + 8 * k];
-    prow[k] = (rid >= 0 ? reinterpret_cast<char *>(a.out) + (int64_t)rid * (NC * 2) : reinterpret_cast<char *>(a.dump)) + (lane & 7) * 16;
-  }
+  for (int k = 0; k < NSTORE; ++k) rid_[k] = cid[wave * 32 + (lane >> 3) + 8 * k];
   char *patch = patches + wave * (32 * 128);
   const uint32_t asl = lds_addr(attl + 4 * hl);
   auto col_pass = [&](auto cpc) {
@@ -2214,6 +2227,7 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
     if constexpr (cp == 0) wait_vm_lgkm<0>(); else wait_vm_lgkm<NSTORE>();
     __builtin_amdgcn_s_barrier();                        // W(cp) visible
     f32x16 acc0, acc1;
+    f32x2 ps_ = {0.f, 0.f}, pd_ = {0.f, 0.f};
     {
       const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       acc0 = z; acc1 = z;
@@ -2256,23 +2270,25 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
       for (int g = 0; g < 4; ++g) {
         const float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
         const f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
-        ps[cp] += vlo * (f32x2){s4[g].x, s4[g].y}; ps[cp] += vhi * (f32x2){s4[g].z, s4[g].w};
-        pd[cp] += vlo * (f32x2){d4[g].x, d4[g].y}; pd[cp] += vhi * (f32x2){d4[g].z, d4[g].w};
+        ps_ += vlo * (f32x2){s4[g].x, s4[g].y}; ps_ += vhi * (f32x2){s4[g].z, s4[g].w};
+        pd_ += vlo * (f32x2){d4[g].x, d4[g].y}; pd_ += vhi * (f32x2){d4[g].z, d4[g].w};
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 o;
         o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
         char *pb = patch + r * 128 + ((hl ^ ((r >> 3) & 1)) << 3);
         *reinterpret_cast<bf16x4 *>(pb + (((tt * 4 + g) ^ (r & 7)) << 4)) = o;
       }
-      asm volatile("" : "+v"(ps[cp]), "+v"(pd[cp]));
+      asm volatile("" : "+v"(ps_), "+v"(pd_));
       __builtin_amdgcn_sched_barrier(0);
     }
+    sl_[cp] = ps_.x + ps_.y; dl_[cp] = pd_.x + pd_.y;
 #pragma unroll
     for (int k = 0; k < NSTORE; ++k) {
       const int row = (lane >> 3) + 8 * k;
       uint4 q = *reinterpret_cast<const uint4 *>(patch + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
       if (k & 1) q = make_uint4(q.z, q.w, q.x, q.y);
-      *reinterpret_cast<uint4 *>(prow[k] + cp * 128) = q;
+      char *prow = (rid_[k] >= 0 ? reinterpret_cast<char *>(a.out) + (int64_t)rid_[k] * (NC * 2) : reinterpret_cast<char *>(a.dump)) + (lane & 7) * 16;
+      *reinterpret_cast<uint4 *>(prow + cp * 128) = q;
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -2285,7 +2301,7 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
     float srow[NPASS], drow_[NPASS];
 #pragma unroll
     for (int hd = 0; hd < NPASS; ++hd) {
-      const float sl = ps[hd].x + ps[hd].y, dl = pd[hd].x + pd[hd].y;
+      const float sl = sl_[hd], dl = dl_[hd];
       srow[hd] = sl + __shfl_xor(sl, 32);
       drow_[hd] = dl + __shfl_xor(dl, 32);
     }
@@ -2417,8 +2433,8 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   // bf16 storage, 256 -> 256: the two-phase form (three workgroups per CU; bit-identical to the one-phase instance)
   if (split == 3 && HC == 256 && NC == 256 && C == 64 && ctx->opts.bf16_two_phase)
     return g->K == 8 ? launch_two_phase<8, 4>(ctx, a) : g->K == 4 ? launch_two_phase<4, 4>(ctx, a) : launch_two_phase<16, 4>(ctx, a);
-  if (split == 3 && HC == 256 && NC == 64 && C == 64 && ctx->opts.bf16_two_phase >= 2)      // (experiment: the 256 -> 64 instance too)
-    return g->K == 8 ? launch_two_phase<8, 1>(ctx, a) : g->K == 4 ? launch_two_phase<4, 1>(ctx, a) : launch_two_phase<16, 1>(ctx, a);
+  // (the 256 -> 64 instance in the same form -- one column pass -- was built in round 4: bit-identical and neutral, see NOTES_r04;
+  //  its dispatch is gone, the kernel template still takes NPASS = 1)
 #define BGNN_FUSED_CASE(hc, nt) if (HC == hc && NC == nt * 32) return launch_by_stencil<hc, nt, EPI_NEXT>(ctx, g, split, a);
   BGNN_FUSED_CASE(256, 8) BGNN_FUSED_CASE(256, 2)
 #undef BGNN_FUSED_CASE

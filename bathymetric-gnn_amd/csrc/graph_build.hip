@@ -844,7 +844,10 @@ __global__ __launch_bounds__(256, (COMPACT ? 4 : 1)) void features_tiled_kernel(
 #pragma unroll
       for (int k = 0; k < CR * CW / 256; ++k) {
         const int li = tid + 256 * k, lr = li / CW, lc = li % CW;
-        const int si = (lr + R) * SW + lc + R;
+        int si = (lr + R) * SW + lc + R;
+        // (opaque: si only depends on the thread, so LICM hoists the address of EVERY s_xxx[si + constant] below out of the chunk loops,
+        //  one VGPR each -- dozens -- and the k = 16 instance spilled; inside the loop they fold into the DS offset fields)
+        asm volatile("" : "+v"(si));
         if (lr < rows && lc < cols && s_nid[si] >= 0) {
           const float dt = s_depth[si];
 #pragma unroll
@@ -875,7 +878,8 @@ __global__ __launch_bounds__(256, (COMPACT ? 4 : 1)) void features_tiled_kernel(
 #pragma unroll
       for (int k = 0; k < CR * CW / 256; ++k) {
         const int li = tid + 256 * k, lr = li / CW, lc = li % CW;
-        const int si = (lr + R) * SW + lc + R;
+        int si = (lr + R) * SW + lc + R;
+        asm volatile("" : "+v"(si));                             // (as in pass 1)
         if (!(lr < rows && lc < cols)) continue;
         const int id = s_nid[si];
         if (id < 0) continue;

@@ -1214,7 +1214,7 @@ def test_bf16_two_phase_instance_is_bit_identical_to_the_one_phase_instance(conn
     ragged = [synthetic.synthetic_tile(h, w, 700 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (9, 31), (50, 50), (3, 3), (26, 8)])]
     _set_matrix_path("bf16")
     outs = {}
-    for two in (1, 0, 2):                                # (2: the 256 -> 64 instance in the two-phase form as well)
+    for two in (1, 0):
         ctx.set_option("bf16_two_phase", two)
         try:
             u = eng.infer_device(hw, res, d_t, m_t, None).clone()
@@ -1223,7 +1223,7 @@ def test_bf16_two_phase_instance_is_bit_identical_to_the_one_phase_instance(conn
             ctx.set_option("bf16_two_phase", 1)
         outs[two] = (u, rg)
     assert torch.isfinite(outs[1][0]).all() and float(outs[1][0][1].max()) > 0.0
-    for other in (0, 2):
+    for other in (0,):
         assert torch.equal(outs[1][0], outs[other][0])
         for a, b in zip(outs[1][1], outs[other][1]):
             for k in ("classification", "confidence", "correction"):
