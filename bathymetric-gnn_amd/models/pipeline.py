@@ -565,6 +565,257 @@ class BathymetricPipeline:
         ta, tb = plan[rank]["tile_rows"]
         return (int(rs[ta]), int(re[tb - 1])) if tb > ta else (0, 0), plan
 
+    # ---- host grid in, host grids out, streamed (one GPU) -----------------------------------------------------------
+    STREAM_MIN_CELLS = 1 << 24        # surveys from 16 M cells on take the streamed form (below: one upload, one download)
+    STREAM_BAND_TILE_ROWS = 2         # tile rows classified between two band stitches
+    STREAM_UPLOAD_ROWS_BYTES = 128 << 20
+
+    def process_grid_streamed(self, grid: BathymetricGrid, band_tile_rows: Optional[int] = None) -> Dict[str, np.ndarray]:
+        """``process_grid_device`` for a survey that lives in HOST memory, with both PCIe crossings and the host-side copies under the
+        kernels (reference :163-211 is host arrays in, host arrays out).  Same tiles, same kernels, same stitch as
+        ``process_survey_device`` -- the results are bit-identical to it -- in three overlapped roles:
+
+        * an UPLOAD thread copies the survey into pinned slabs and H2D's them chunk by chunk on its own stream; the valid mask is
+          made on the device from the depth (``BathymetricGrid.valid_mask``: finite and not the nodata value; a foreign grid
+          object's own mask is uploaded instead), and as soon as a tile row's rows are resident its tiles' valid counts are taken
+          (``bgnn_tile_valid_counts``) -- the ``min_valid_ratio`` filter never makes the classifying stream wait for the host;
+        * THIS thread cuts and classifies the kept tiles, tile row by tile row, into a ring of per-tile result slots that holds
+          just the tile rows a stitch can still reach; after every ``band_tile_rows`` tile rows the survey rows NO later tile
+          touches are final: they are stitched (``bgnn_stitch_tiles`` on a row band -- the stitch is a per-cell gather, so a band is
+          the same arithmetic as the whole survey) together with the valid mask as float32, and queued for download;
+        * a DOWNLOAD thread waits for a band's D2H (own stream, pinned slabs) and copies it into the five result arrays -- fresh
+          pageable memory, whose first touch costs as much as the copy itself: that runs beside the kernels too."""
+        import threading
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        eng, ctx, dev = self._engine, self._engine.ctx, self._engine.ctx.device
+        tm = self.tile_manager
+        H, W = (int(v) for v in grid.shape)
+        depth_h = np.ascontiguousarray(grid.depth, dtype=np.float32)
+        plain_mask = type(grid) is BathymetricGrid
+        valid_h = None if plain_mask else np.ascontiguousarray(grid.valid_mask).view(np.uint8)
+        nodata = grid.nodata_value if plain_mask else None
+        use_unc = self.model.in_channels == 8 and grid.uncertainty is not None
+        unc_h = np.ascontiguousarray(grid.uncertainty, dtype=np.float32) if use_unc else None
+        ntr, ntc, specs = tm.compute_tile_grid((H, W))
+        sa = np.array([[s.row_start, s.col_start, s.row_end, s.col_end] for s in specs], np.int64)
+        th, tw = int(sa[0, 2] - sa[0, 0]), int(sa[0, 3] - sa[0, 1])
+        cells = th * tw
+        assert np.all((sa[:, 2] - sa[:, 0]) * (sa[:, 3] - sa[:, 1]) == cells)
+        rs = sa[::ntc, 0].copy(); re = sa[::ntc, 2].copy(); cs = sa[:ntc, 1].copy(); ce = sa[:ntc, 3].copy()
+        nb = max(1, int(band_tile_rows or self.STREAM_BAND_TILE_ROWS))
+        # tile rows a later band's stitch still reads: those that end past the first row of the band's first tile row
+        reach = max(int(np.count_nonzero(re[:t] > rs[t])) for t in range(ntr))
+        K = min(ntr, nb + reach)                                  # ring slots (tile rows)
+        bands = [(a, min(a + nb, ntr)) for a in range(0, ntr, nb)]
+        band_rows = []                                            # survey rows that become final with each band
+        R0 = 0
+        for a, b in bands:
+            R1 = int(rs[b]) if b < ntr else H
+            R1 = max(R1, R0)
+            band_rows.append((R0, R1)); R0 = R1
+        max_rows = max(r1 - r0 for r0, r1 in band_rows)
+        # ---- device / pinned buffers ----
+        mk = lambda dt, *shape: torch.empty(shape, dtype=dt, device=dev)
+        pins = self.__dict__.setdefault("_stream_pins", {})      # pinned slabs are kept between calls (page-locking ~1 GB costs ~0.3 s)
+        sig = (H, W, th, tw, nb, use_unc, plain_mask)
+        if self.__dict__.get("_stream_pins_sig") != sig:          # ... for surveys of the same geometry; another one starts afresh
+            pins.clear()
+            self.__dict__["_stream_pins_sig"] = sig
+
+        def pin(dt, *shape):
+            lst = pins.setdefault((dt, shape), [])
+            i = taken[(dt, shape)] = taken.get((dt, shape), -1) + 1
+            while len(lst) <= i:
+                lst.append(torch.empty(shape, dtype=dt, pin_memory=True))
+            return lst[i]
+        taken: Dict = {}
+        depth_t, valid_t = mk(torch.float32, H, W), mk(torch.uint8, H, W)
+        unc_t = mk(torch.float32, H, W) if use_unc else None
+        r_all = mk(torch.float32, 3, K * ntc * cells)             # ring: [channel][slot][tile][cells]
+        o_dev = [mk(torch.float32, 5, max_rows, W) for _ in range(2)]
+        o_pin = [pin(torch.float32, 5, max_rows, W) for _ in range(2)]
+        up_rows = max(1, min(H, self.STREAM_UPLOAD_ROWS_BYTES // (4 * W)))
+        n_up = 2 + (2 if use_unc else 0) + (2 if valid_h is not None else 0)
+        up_pin = [pin(torch.float32, up_rows, W) for _ in range(2)]
+        up_pin_u = [pin(torch.float32, up_rows, W) for _ in range(2)] if use_unc else None
+        up_pin_m = [pin(torch.uint8, up_rows, W) for _ in range(2)] if valid_h is not None else None
+        torch.cuda.synchronize(dev)                               # (buffers made on this stream, used on three others)
+        # (the upload thread has a library context of its own -- calls on one context are not re-entrant --; its stream is the upload stream)
+        up_ctx = self.__dict__.get("_upload_ctx")
+        if up_ctx is None or up_ctx.handle is None:
+            up_ctx = self.__dict__["_upload_ctx"] = rt.new_context(dev)
+        up_stream, down_stream = up_ctx.stream, torch.cuda.Stream(dev)
+        out = {k: np.empty((H, W), np.float32) for k in ("classification", "confidence", "correction", "cleaned_depth", "valid_mask")}
+        order = ("classification", "confidence", "correction", "cleaned_depth", "valid_mask")
+        # ---- tile-row state published by the upload thread ----
+        cv = threading.Condition()
+        keep_rows: Dict[int, np.ndarray] = {}
+        row_ready = [torch.cuda.Event() for _ in range(ntr)]     # tile row t's survey rows (and mask) are resident
+        errors: List[BaseException] = []
+        org_all = np.ascontiguousarray(sa[:, :2], dtype=np.int32)
+        org_t = torch.from_numpy(org_all).to(dev)
+
+        def uploader():
+            try:
+                done_rows, next_t, slot_ev = 0, 0, [None, None]
+                with torch.cuda.stream(up_stream):
+                    k = 0
+                    while done_rows < H:
+                        r0, r1 = done_rows, min(H, done_rows + up_rows)
+                        j = k % 2
+                        if slot_ev[j] is not None:
+                            slot_ev[j].synchronize()               # the slab's previous H2D has left it
+                        n = r1 - r0
+                        np.copyto(up_pin[j].numpy()[:n], depth_h[r0:r1])
+                        depth_t[r0:r1].copy_(up_pin[j][:n], non_blocking=True)
+                        if use_unc:
+                            np.copyto(up_pin_u[j].numpy()[:n], unc_h[r0:r1])
+                            unc_t[r0:r1].copy_(up_pin_u[j][:n], non_blocking=True)
+                        if valid_h is not None:
+                            np.copyto(up_pin_m[j].numpy()[:n], valid_h[r0:r1])
+                            valid_t[r0:r1].copy_(up_pin_m[j][:n], non_blocking=True)
+                        else:                                      # BathymetricGrid.valid_mask on the device
+                            d = depth_t[r0:r1]
+                            m = torch.isfinite(d)
+                            if nodata is not None and not np.isnan(nodata):
+                                m &= d != nodata
+                            valid_t[r0:r1].copy_(m)
+                        slot_ev[j] = torch.cuda.Event(); slot_ev[j].record(up_stream)
+                        done_rows, k = r1, k + 1
+                        # tile rows whose rows are now all resident: valid counts -> min_valid_ratio filter (iterate_tiles, tiling.py:203-209)
+                        t0 = next_t
+                        while next_t < ntr and re[next_t] <= done_rows:
+                            next_t += 1
+                        if next_t > t0:
+                            n_t = (next_t - t0) * ntc
+                            cnt_t = torch.empty(n_t, dtype=torch.int64, device=dev)
+                            rt.check(up_ctx.lib.bgnn_tile_valid_counts(up_ctx.handle, H, W, rt.ptr(valid_t), n_t,
+                                                                       rt.ptr(org_t[t0 * ntc:next_t * ntc]), th, tw, rt.ptr(cnt_t)))
+                            for t in range(t0, next_t):
+                                row_ready[t].record(up_stream)
+                            keep = ~((cnt_t.cpu().numpy() / cells) < tm.min_valid_ratio)      # (syncs the upload stream only)
+                            with cv:
+                                for t in range(t0, next_t):
+                                    keep_rows[t] = keep[(t - t0) * ntc:(t - t0 + 1) * ntc]
+                                cv.notify_all()
+            except BaseException as e:                               # noqa: BLE001 -- handed to the caller's thread
+                with cv:
+                    errors.append(e); cv.notify_all()
+
+        import queue
+        down_q: "queue.Queue" = queue.Queue()
+        slot_free = [threading.Event(), threading.Event()]
+        for e in slot_free:
+            e.set()
+
+        def downloader():
+            try:
+                while True:
+                    item = down_q.get()
+                    if item is None:
+                        return
+                    j, r0, r1, ev = item
+                    ev.synchronize()
+                    src = o_pin[j].numpy()
+                    for c, name in enumerate(order):
+                        np.copyto(out[name][r0:r1], src[c, :r1 - r0])
+                    slot_free[j].set()
+            except BaseException as e:                               # noqa: BLE001
+                with cv:
+                    errors.append(e); cv.notify_all()
+                for e2 in slot_free:
+                    e2.set()
+
+        t_up = threading.Thread(target=uploader, name="bgnn-survey-up", daemon=True)
+        t_dn = threading.Thread(target=downloader, name="bgnn-survey-down", daemon=True)
+        t_up.start(); t_dn.start()
+        resol = np.array([[float(grid.resolution[0]), float(grid.resolution[1])]], np.float64)
+        pitch = max(th, tw)
+        colw = np.zeros((ntc, pitch), np.float32)
+        for j in range(ntc):
+            colw[j, :ce[j] - cs[j]] = tm._create_1d_blend(int(ce[j] - cs[j]))
+        dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        cs_t, ce_t, cw_t = dv(cs.astype(np.int32)), dv(ce.astype(np.int32)), dv(colw)
+        tile_off = np.full((ntr, ntc), -1, np.int64)
+        d_b = mk(torch.float32, min(self.tile_batch, ntc) * cells); m_b = mk(torch.uint8, min(self.tile_batch, ntc) * cells)
+        u_b = mk(torch.float32, min(self.tile_batch, ntc) * cells) if use_unc else None
+        n_proc = 0
+        band_done = [None, None]                                  # D2H events of the band that last used each device / pinned slot
+        try:
+            for bi, ((ta, tb), (R0, R1)) in enumerate(zip(bands, band_rows)):
+                with cv:
+                    while not errors and any(t not in keep_rows for t in range(ta, tb)):
+                        cv.wait(0.05)
+                    if errors:
+                        raise errors[0]
+                for t in range(ta, tb):
+                    kept = np.nonzero(keep_rows[t])[0]
+                    slot = t % K
+                    tile_off[t, :] = -1
+                    tile_off[t, kept] = (slot * ntc + np.arange(len(kept), dtype=np.int64)) * cells
+                    if not len(kept):
+                        continue
+                    n_proc += len(kept)
+                    ctx.stream.wait_event(row_ready[t])
+                    idx_t = torch.from_numpy(t * ntc + kept).to(dev)
+                    for b0 in range(0, len(kept), self.tile_batch):
+                        nbt = min(self.tile_batch, len(kept) - b0)
+                        o_b = org_t[idx_t[b0:b0 + nbt]].contiguous()
+                        ctx.begin()
+                        rt.check(ctx.lib.bgnn_cut_tiles(ctx.handle, H, W, rt.ptr(depth_t), rt.ptr(valid_t), rt.ptr(unc_t), nbt, rt.ptr(o_b),
+                                                        th, tw, rt.ptr(d_b), rt.ptr(m_b), rt.ptr(u_b)))
+                        ctx.end()
+                        lo = (slot * ntc + b0) * cells; hi = lo + nbt * cells; n = nbt * cells
+                        eng.infer_device(np.tile(np.array([[th, tw]], np.int32), (nbt, 1)), np.tile(resol, (nbt, 1)), d_b[:n], m_b[:n],
+                                         u_b[:n] if u_b is not None else None, out=(r_all[0, lo:hi], r_all[1, lo:hi], r_all[2, lo:hi]))
+                if R1 <= R0:
+                    continue
+                # ---- stitch the rows that are final now, with the tile rows that reach into them ----
+                inv = np.nonzero((rs < R1) & (re > R0))[0]
+                assert inv.max() < tb and inv.min() > tb - 1 - K, "a stitch only reads tile rows still in the ring"
+                roww = np.zeros((len(inv), pitch), np.float32)
+                for i, t in enumerate(inv):
+                    roww[i, :re[t] - rs[t]] = tm._create_1d_blend(int(re[t] - rs[t]))
+                j = bi % 2
+                if band_done[j] is not None:
+                    torch.cuda.current_stream(dev).wait_event(band_done[j])      # the device slab's last download has left it
+                rs_t, re_t = dv((rs[inv] - R0).astype(np.int32)), dv((re[inv] - R0).astype(np.int32))
+                rw_t, off_t = dv(roww), dv(tile_off[inv].reshape(-1))
+                o = o_dev[j]
+                n_r = R1 - R0
+                ctx.begin()
+                rt.check(ctx.lib.bgnn_stitch_tiles(
+                    ctx.handle, n_r, W, len(inv), ntc, rt.ptr(rs_t), rt.ptr(re_t), rt.ptr(cs_t), rt.ptr(ce_t), rt.ptr(rw_t), rt.ptr(cw_t),
+                    pitch, rt.ptr(off_t), rt.ptr(r_all[0]), rt.ptr(r_all[1]), rt.ptr(r_all[2]), rt.ptr(depth_t[R0:R1]), rt.ptr(valid_t[R0:R1]),
+                    C.c_float(self.config.inference.auto_correct_threshold),
+                    rt.ptr(o[0]), rt.ptr(o[1]), rt.ptr(o[2]), rt.ptr(o[3])))
+                ctx.end()
+                # (the four stitched grids are [n_r][W] blocks at the head of their [max_rows][W] planes; the mask as float32 beside them)
+                o[4, :n_r].copy_(valid_t[R0:R1])
+                stitched = torch.cuda.Event(); stitched.record(torch.cuda.current_stream(dev))
+                slot_free[j].wait()                                # the pinned slab's last band has been copied out
+                with cv:
+                    if errors:
+                        raise errors[0]
+                slot_free[j].clear()
+                with torch.cuda.stream(down_stream):
+                    down_stream.wait_event(stitched)
+                    for c in range(5):                             # (contiguous blocks: a strided copy would go through a host-side temporary)
+                        o_pin[j][c, :n_r].copy_(o[c, :n_r], non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(down_stream)
+                band_done[j] = ev
+                down_q.put((j, R0, R1, ev))
+        finally:
+            down_q.put(None)
+            t_up.join(); t_dn.join()
+            torch.cuda.synchronize(dev)
+        if errors:
+            raise errors[0]
+        self.last_tile_counts = (n_proc, ntr * ntc - n_proc)
+        logger.info(f"Processed {n_proc} tiles ({ntr * ntc - n_proc} skipped below min_valid_ratio)")
+        return out
+
     def process_grid_device(self, grid: BathymetricGrid) -> Optional[Dict[str, np.ndarray]]:
         """Survey path with everything between the two PCIe crossings on the device: the survey is uploaded once,
         processed by ``process_survey_device`` and the four result grids come back in one copy.  Same results as the host
@@ -581,6 +832,8 @@ class BathymetricPipeline:
         up = lambda a, lo, hi, dt: torch.from_numpy(np.ascontiguousarray(a[lo:hi], dtype=dt)).to(dev)
         rank, world = shard_info()
         H, W = (int(v) for v in grid.shape)
+        if world == 1 and H * W >= self.STREAM_MIN_CELLS:
+            return self.process_grid_streamed(grid)
         if world == 1:
             depth_t = up(grid.depth, 0, H, np.float32)
             valid_t = torch.from_numpy(np.ascontiguousarray(valid_np).view(np.uint8)).to(dev)

@@ -230,7 +230,7 @@ def test_wide_layer_with_an_operand_split_path_runs_exact(gpu_device):
     exact = model.predict(g)["class_logits"].clone()
     for path in ("bf16x3", "fp16x3"):
         _set_matrix_path(path)
-        assert (model.predict(g)["class_logits"] - exact).abs().max().item() < 2e-5
+        assert (model.predict(g)["class_logits"] - exact).abs().max().item() < TOL        # (calibrated heads amplify the split paths' ~6e-6)
 
 
 def test_batched_equals_per_graph_and_vr_processor(gpu_device):

@@ -63,6 +63,51 @@ def test_survey_crop_property(gpu_device):
         assert np.array_equal(np.nan_to_num(res[name]).view(np.uint32), np.nan_to_num(f[k]).view(np.uint32))
 
 
+@pytest.mark.parametrize("in_channels,band,foreign", [(7, 1, False), (7, 2, False), (8, 3, False), (7, 2, True)])
+def test_streamed_host_survey_equals_the_resident_one(in_channels, band, foreign, gpu_device):
+    """process_grid_streamed (host survey in, host grids out: upload thread + band-wise stitch + download thread, a ring of tile-row
+    result slots) against process_survey_device on the whole survey resident in HBM: the five result grids bit for bit -- for several
+    band heights (so that bands, ring slots and the survey's ragged last tile row / column fall differently), with an uncertainty
+    band, with skipped tiles (nodata corner), with NaN / inf depths, and for a foreign grid object whose valid mask is its own."""
+    from bathymetric_gnn_amd import synthetic
+    from bathymetric_gnn_amd.config import Config
+    from bathymetric_gnn_amd.data import BathymetricGrid
+    from bathymetric_gnn_amd.models import BathymetricGNN, BathymetricPipeline
+    cfg = Config(); cfg.tile.tile_size, cfg.tile.overlap = 64, 16          # stride 48
+    pipe = BathymetricPipeline(cfg, tile_batch=5)
+    pipe.STREAM_UPLOAD_ROWS_BYTES = 37 * 4 * 611                           # upload chunks of 37 rows: tile rows become ready mid-way
+    sd = synthetic.synthetic_state_dict(in_channels=in_channels, seed=1234)
+    m = BathymetricGNN(in_channels=in_channels, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    pipe.set_model(m.to(gpu_device).eval())
+    d, mk, u = synthetic.synthetic_tile(700, 611, 33, "V1", True)
+    d[:150, :130] = 1.0e6; d[300, 200] = np.nan; d[301, 200] = np.inf
+    unc = u if in_channels == 8 else None
+    grid = BathymetricGrid(depth=d, uncertainty=unc, nodata_value=1.0e6, resolution=(0.5, 0.5))
+    valid_np = grid.valid_mask
+    if foreign:                       # not a BathymetricGrid: its valid_mask is taken as given (here: a hole the depth does not show)
+        valid_np = valid_np.copy(); valid_np[400:420, 100:140] = False
+
+        class Foreign:
+            depth, uncertainty, resolution, shape, valid_mask, nodata_value = d, unc, (0.5, 0.5), d.shape, valid_np, 1.0e6
+        grid = Foreign()
+    depth_t = torch.from_numpy(d).to(gpu_device); valid_t = torch.from_numpy(valid_np).to(gpu_device)
+    unc_t = torch.from_numpy(unc).to(gpu_device) if unc is not None else None
+    full = pipe.process_survey_device(depth_t, valid_t, unc_t, (0.5, 0.5)).cpu().numpy()
+    counts = pipe.last_tile_counts
+    assert counts[1] > 0
+    res = pipe.process_grid_streamed(grid, band_tile_rows=band)
+    assert pipe.last_tile_counts == counts
+    for k, name in enumerate(("classification", "confidence", "correction", "cleaned_depth")):
+        assert res[name].shape == d.shape and res[name].dtype == np.float32
+        assert np.array_equal(res[name].view(np.uint32), full[k].view(np.uint32)), name
+    assert np.array_equal(res["valid_mask"], valid_np.astype(np.float32))
+    assert np.isnan(res["classification"]).any() and (res["classification"] == 2).any()      # (uncovered invalid cells stay NaN)
+    # the default entry takes the streamed form from STREAM_MIN_CELLS on
+    pipe.STREAM_MIN_CELLS = 1
+    res2 = pipe.process_grid(grid) if not foreign else pipe.process_grid_device(grid)
+    assert all(np.array_equal(res2[k].view(np.uint32), res[k].view(np.uint32)) for k in res)
+
+
 @pytest.mark.parametrize("S", [60000, 20000])
 def test_config5_full_size_survey_resident_in_hbm(gpu_device, S):
     """BASELINE config 5 at FULL size on one GPU (models/pipeline.py:170-190 is the loop it stands for): a 60000 x 60000
