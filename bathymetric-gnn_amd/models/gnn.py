@@ -278,24 +278,48 @@ class BathymetricGNN(nn.Module):
 
     def _weights_version(self):
         """(storage, version counter) of every parameter and buffer: changes whenever a weight is written or moved.  The LIST of
-        tensors is cached -- walking the module tree costs ~0.2 ms, as much as the host side of a whole 50 000-node batch -- and is
-        rebuilt when the module is converted / moved (``_apply``), loaded (``load_state_dict``) or has a sub-module assigned."""
-        ts = self.__dict__.get("_wv_tensors")
-        if ts is None:
-            ts = self.__dict__["_wv_tensors"] = list(self.parameters()) + list(self.buffers())
-        return tuple((p.data_ptr(), p._version) for p in ts)
+        tensors is cached -- walking the module tree costs ~0.2 ms, as much as the host side of a whole 50 000-node batch -- beside
+        the slots it was read from: every ``_parameters`` / ``_buffers`` / ``_modules`` dict of the tree with its length and the
+        objects it held.  A call re-checks those slots by identity (~10 us), so replacing a nested parameter or sub-module
+        (``model.gnn.convs[0].lin.weight = nn.Parameter(...)``, ``head.mlp[3] = nn.Linear(...)``, ``register_buffer`` on a child)
+        rebuilds the list like ``_apply`` / ``load_state_dict`` / an assignment on the root do.  ``invalidate_native()`` forces it."""
+        st = self.__dict__.get("_wv_struct")
+        if st is not None:
+            for d, k, o in st[0]:
+                if d.get(k) is not o:
+                    st = None
+                    break
+            else:
+                for d, n in st[1]:
+                    if len(d) != n:
+                        st = None
+                        break
+        if st is None:
+            slots, sizes, ts = [], [], []
+            for m in self.modules():
+                for d in (m._parameters, m._buffers, m._modules):
+                    sizes.append((d, len(d)))
+                    slots += [(d, k, o) for k, o in d.items()]
+                ts += [t for d in (m._parameters, m._buffers) for t in d.values() if t is not None]
+            st = self.__dict__["_wv_struct"] = (slots, sizes, ts)
+        return tuple((p.data_ptr(), p._version) for p in st[2])
+
+    def invalidate_native(self):
+        """Forget the cached tensor list and the packed copies: the next call re-reads every weight."""
+        self.__dict__.pop("_wv_struct", None)
+        self._drop_native()
 
     def _apply(self, fn, *a, **k):
-        self.__dict__.pop("_wv_tensors", None)
+        self.__dict__.pop("_wv_struct", None)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self.__dict__.pop("_wv_tensors", None)
+        self.__dict__.pop("_wv_struct", None)
         return super().load_state_dict(*a, **k)
 
     def __setattr__(self, name, value):
         if isinstance(value, (nn.Module, nn.Parameter)):
-            self.__dict__.pop("_wv_tensors", None)
+            self.__dict__.pop("_wv_struct", None)
         super().__setattr__(name, value)
 
     def _drop_native(self, only_ctx_id=None):

@@ -76,12 +76,17 @@ def test_streamed_host_survey_equals_the_resident_one(in_channels, band, foreign
     cfg = Config(); cfg.tile.tile_size, cfg.tile.overlap = 64, 16          # stride 48
     pipe = BathymetricPipeline(cfg, tile_batch=5)
     pipe.STREAM_UPLOAD_ROWS_BYTES = 37 * 4 * 611                           # upload chunks of 37 rows: tile rows become ready mid-way
-    sd = synthetic.synthetic_state_dict(in_channels=in_channels, seed=1234)
-    m = BathymetricGNN(in_channels=in_channels, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-    pipe.set_model(m.to(gpu_device).eval())
     d, mk, u = synthetic.synthetic_tile(700, 611, 33, "V1", True)
     d[:150, :130] = 1.0e6; d[300, 200] = np.nan; d[301, 200] = np.inf
     unc = u if in_channels == 8 else None
+    # heads calibrated on one tile-sized crop of the survey (classes mix, so the label arbitration and the corrections are exercised)
+    from _calibration import calibrate_heads
+    from oracle import graph_cpu
+    cr = (slice(400, 464), slice(300, 364))
+    og = graph_cpu.build_graph(d[cr], (d[cr] != 1.0e6) & np.isfinite(d[cr]), None if unc is None else unc[cr], (0.5, 0.5))
+    sd = calibrate_heads(synthetic.synthetic_state_dict(in_channels=in_channels, seed=1234), og.x, og.edge_index, og.edge_attr)
+    m = BathymetricGNN(in_channels=in_channels, edge_dim=3, dropout=0.0); m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    pipe.set_model(m.to(gpu_device).eval())
     grid = BathymetricGrid(depth=d, uncertainty=unc, nodata_value=1.0e6, resolution=(0.5, 0.5))
     valid_np = grid.valid_mask
     if foreign:                       # not a BathymetricGrid: its valid_mask is taken as given (here: a hole the depth does not show)

@@ -73,6 +73,20 @@ def test_pack_weights_order_and_invalidate():
     with torch.no_grad():
         m.gnn.convs[0].bias.add_(1.0)
     assert m._weights_version() != v0                           # native handle would be rebuilt
+    # replacing NESTED parameters / modules / buffers is seen too (the cached tensor list is re-checked slot by slot)
+    v1 = m._weights_version()
+    assert m._weights_version() == v1
+    m.gnn.convs[0].lin.weight = torch.nn.Parameter(torch.zeros_like(m.gnn.convs[0].lin.weight))
+    v2 = m._weights_version()
+    assert v2 != v1
+    m.classification_head.mlp[3] = torch.nn.Linear(m.classification_head.mlp[3].in_features, 3)
+    v3 = m._weights_version()
+    assert v3 != v2 and np.array_equal(m.pack_weights()[:n0], blob[:n0])
+    m.gnn.norms[0].module.register_buffer("running_mean", torch.ones_like(m.gnn.norms[0].module.running_mean))
+    v4 = m._weights_version()
+    assert v4 != v3
+    m.invalidate_native()
+    assert m._weights_version() == v4                           # same tensors, re-read
 
 
 def test_checkpoint_loading_paths(tmp_path, monkeypatch):
