@@ -195,6 +195,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
     o.fused_front = getenv("BGNN_NO_FUSED_FRONT") ? 0 : 1;
     o.fused_persistent = getenv("BGNN_PERSISTENT") ? 1 : 0;
     o.bf16_two_phase = getenv("BGNN_NO_TWO_PHASE") ? 0 : env_int("BGNN_TWO_PHASE", 1);
+    o.bf16_layer0_af = getenv("BGNN_NO_LAYER0_AF") ? 0 : 1;
     o.stats_narrow = env_int("BGNN_STATS_NARROW", -1);
     o.fused_lds_pad_kb = env_int("BGNN_FUSED_LDS_PAD", 0);
     o.diag_mask = env_int("BGNN_FUSED_DBG", 0);
@@ -211,7 +212,7 @@ int bgnn_ctx_create(int device, void *stream, bgnn_ctx **out) {
 static int *option_slot(bgnn_ctx *ctx, const char *name) {
   BgnnOpts &o = ctx->opts;
   struct { const char *n; int *p; } tab[] = {
-      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent}, {"bf16_two_phase", &o.bf16_two_phase}, {"stats_narrow", &o.stats_narrow},
+      {"matrix_path", &o.matrix_path}, {"fused", &o.fused}, {"fold_extractor", &o.fold_extractor}, {"ragged_atlas", &o.ragged_atlas}, {"features_tiled", &o.features_tiled}, {"fused_front", &o.fused_front}, {"fused_persistent", &o.fused_persistent}, {"bf16_two_phase", &o.bf16_two_phase}, {"bf16_layer0_af", &o.bf16_layer0_af}, {"stats_narrow", &o.stats_narrow},
       {"fused_lds_pad_kb", &o.fused_lds_pad_kb},
       {"diag_mask", &o.diag_mask}, {"diag_stamps", &o.diag_stamps}, {"gemm_waves", &o.gemm_waves},
       {"gemm_diag", &o.gemm_diag}, {"gemm_no_wres", &o.gemm_no_wres}, {"gemm_pair_major", &o.gemm_pair_major}};
@@ -784,6 +785,22 @@ static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const fl
     }
   }
 
+  // layer 0 "aggregate first" (bf16 path, default shape): the folded lin_0 weight as four per-head [64 k][64 columns] bf16 images
+  // ([head][k-step][tile] KiB, accumulator-operand k order), and layer 0's folded shift with the folded lin_0 bias carried through the
+  // BatchNorm scale (the attention coefficients of a node sum to 1: sum_j alpha_ij (W h_j + b) = W sum_j alpha_ij h_j + b)
+  size_t o_l0af_W = 0, o_l0af_sh = 0;
+  if (gat && hid == 64 && L > 1 && d->heads == 4) {
+    o_l0af_W = reserve((size_t)4 * 2048); o_l0af_sh = reserve(HC0);
+    for (int hd = 0; hd < 4; ++hd) {
+      std::vector<float> wh((size_t)hid * 64);
+      for (int k = 0; k < hid; ++k)
+        for (int c = 0; c < 64; ++c) wh[(size_t)k * 64 + c] = pk[o_l0f_Wt + (size_t)k * HC0 + hd * 64 + c];
+      pack_bf16_image_accop(wh.data(), hid, 64, pk.data() + o_l0af_W + (size_t)hd * 2048);
+    }
+    for (int o = 0; o < HC0; ++o)
+      pk[o_l0af_sh + o] = (float)((double)pk[lo[0].sh + o] + (double)pk[lo[0].sc + o] * (double)pk[o_l0f_b + o]);
+  }
+
   // plain backbones (hidden 64): the layer weight in the fused layer kernel's column-permuted image (launch_fused_plain_layer)
   std::vector<size_t> o_plainfp(L, 0);
   if (!gat && hid == 64) {
@@ -827,6 +844,8 @@ static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const fl
   m->l0f_Wt_blk = o_l0f_blk ? m->blob + o_l0f_blk : nullptr;
   m->hd_W0bf = gat ? m->blob + o_hW0bf : nullptr;
   m->hd_W0fp = gat ? m->blob + o_hW0fp : nullptr;
+  m->l0af_W = o_l0af_W ? m->blob + o_l0af_W : nullptr;
+  m->l0af_shift = o_l0af_sh ? m->blob + o_l0af_sh : nullptr;
   m->layers.resize(L);
   for (int l = 0; l < L && !gat; ++l) {
     BgnnLayer &Ly = m->layers[l];
@@ -1324,6 +1343,8 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       return BGNN_ERR_UNSUPPORTED;
     }
   }
+  bool layer0_done = false;                           // bf16 path: layer 0's aggregate already ran (aggregate-first launch): the loop starts at layer 1
+  const size_t nl_gat = gat ? m->layers.size() : 0;
   if (!gat) {
     // GCN / GraphSAGE / GIN backbones (gnn.py:120-143; torch_geometric default arguments): plain gathers + GEMMs.
     // Not the hot path: no fusion beyond BatchNorm / bias / ReLU folded into the neighbouring kernel.
@@ -1395,12 +1416,27 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       // (active extractor dropout sits between the two: the first layer then keeps its own launch)
       const bool front = hid == 64 && gemm_front_available(ctx, rows, L0.heads * hid, smode) && !(dp && dp->p_extractor > 0.0f);
       BGNN_REQUIRE(front || sm != 3, "matrix_path = bf16 needs fused_front = 1");
+      // bf16 path, default shape: layer 0 aggregates the extractor's h1 and applies lin_0 afterwards, inside the fused launch
+      // (gat_layer_bf16_2p_kernel, AF) -- no lin_0 product in HBM, no front GEMM
+      if (sm == 3 && front && ctx->opts.bf16_layer0_af && ctx->opts.bf16_two_phase && m->l0af_W && nl_gat >= 2 && use_fused && !o->hidden) {
+        const BgnnLayer &L1 = m->layers[1];
+        const float *V3a = nullptr;
+        if (g->kind == 0 && g->compact_edges && !g->edge_default) { const float *v3; BGNN_TRY(model_canonical_V(m, g, &v3)); V3a = v3; }
+        if (L1.heads == 4 && L1.Wbf && g->kind == 0) {
+          BGNN_TRY(launch_extractor_af(ctx, g->d_x8, m->fe_W0t, m->fe_b0, m->l0f_Wbf + (size_t)hid * L0.heads * hid / 2, Y, asdX, dm, rows, L0.heads));
+          int rc = launch_fused_layer0_af(ctx, g, L0, L1, hid, V3a, Y, asdX, m->l0af_W, m->l0af_shift, X, asdY);
+          if (rc == BGNN_OK) { std::swap(asdX, asdY); layer0_done = true; }
+          else if (rc != BGNN_ERR_UNSUPPORTED) return rc;
+        }
+      }
+      if (!layer0_done) {
       if (!front) BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, Y, hid, dm, rows, 8, hid, 1));
       if (!front && dp) BGNN_TRY(drop(Y, hid, dp->p_extractor, 1));
       BGNN_TRY(launch_gemm_f32(ctx, front ? g->d_x8 : Y, front ? 8 : hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid,
                                L0.heads * hid, 0, L0.att_src, L0.att_dst, asdX, L0.heads, hid, wsplit, smode,
                                front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr, front && smode == 0 ? m->l0f_Wpm : nullptr,
                                m->l0f_Wt_blk));
+      }
     } else {
       BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");
       BGNN_TRY(launch_gemm_f32(ctx, g->d_x8, 8, m->fe_W0t, m->fe_b0, X, hid, dm, rows, 8, hid, 1));
@@ -1415,7 +1451,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
   // a graph built with another edge feature list than the default: the fused kernels take the edge vectors over the canonical three
   const float *v3_all = nullptr;
   if (gat && use_fused && g->kind == 0 && g->compact_edges && !g->edge_default) BGNN_TRY(model_canonical_V(m, g, &v3_all));
-  for (size_t l = 0; l < nl; ++l) {
+  for (size_t l = layer0_done ? 1 : 0; l < nl; ++l) {
     const float *V3 = v3_all ? v3_all + l * (size_t)d.heads * 3 : nullptr;
     const BgnnLayer &Leval = m->layers[l];
     BgnnLayer Ltrain = Leval;                          // training mode: out = aggregate + bias, BatchNorm afterwards

@@ -82,6 +82,9 @@ struct BgnnOpts {
   int bf16_two_phase = 1;    // matrix_path = bf16: the 256 -> 256 fused layer in its two-phase form (aggregate all slabs to bf16 registers, then
                              // the GEMM in four column passes: three workgroups per CU; bit-identical to the one-phase instance, 0 selects that;
                              // 2: the 256 -> 64 instance in the same form too -- experiment, neutral)
+  int bf16_layer0_af = 1;    // matrix_path = bf16, default model shape: layer 0 aggregates the extractor's 64-channel h1 and applies the folded lin_0
+                             // weight per head afterwards, inside the fused launch (no front GEMM, no 512-byte lin_0 rows in HBM); 0: front GEMM + the
+                             // ordinary two-phase launch.  Same mathematics, another rounding sequence (not bit-identical to 0)
   int stats_narrow = -1;     // box statistics with 16 instead of 64 running sums per workgroup (four times the workgroups, a quarter of the
                              // work between two barriers): -1 picks it when the wide launch would leave most CUs idle; bit-identical
   int fused_front = 1;       // 1: extractor layer 1 runs inside the lin_0 GEMM where that GEMM's W-resident form is used (0: own launch)
@@ -172,6 +175,7 @@ struct bgnn_model {
   float *l0f_Wpm = nullptr;                         // l0f_Wt with the columns of tile pairs interleaved (gemm_f32.hip, PM form)
   float *l0f_Wt_blk = nullptr;                      // l0f_Wt in 256-column blocks (layer 0 wider than 256 columns)
   float *hd_W0fp = nullptr;                         // hd_W0t column-permuted for the fused exact-f32 kernel
+  float *l0af_W = nullptr, *l0af_shift = nullptr;   // layer 0 aggregate-first (bf16 path): per-head bf16 images of l0f_Wt; layer 0's shift + scale * l0f_b
   std::vector<BgnnLayer> layers;
   float *ones = nullptr;      // [256] of 1.0f: the identity scale of an unfolded epilogue
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
@@ -289,6 +293,9 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
                     const float *front_W0t = nullptr, const float *front_b0 = nullptr, const float *Wt_pm = nullptr,
                     const float *Wt_blk = nullptr);
 bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode);
+// bf16 path, layer 0 aggregate-first: extractor layer 1 -> h1 [M][64] bf16 + layer 0's attention dots through the bf16 front GEMM's alpha tile
+int launch_extractor_af(bgnn_ctx *ctx, const float *x8, const float *W0t, const float *b0, const float *alpha_tile, void *h1, float *asd,
+                        const int64_t *d_m, int64_t max_rows, int H);
 // training-mode dropout (bgnn.h, bgnn_dropout): one counter-based draw per element, see there
 struct DropSpec {
   uint32_t thr = 0;          // keep <=> hash >= thr   (floor(p * 2^32); 0: nothing is dropped)
@@ -323,6 +330,9 @@ int launch_gat_aggregate_tiled(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLay
 // (V3: the layer's edge vector over the canonical three attributes, [heads][3] -- nullptr: L.V is that already, default list)
 int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
                             const void *xw, const float *asd, void *xw_next, float *asd_next);
+// ... layer 0 of the bf16 path from the extractor's h1 (aggregate, then the folded lin_0 weight per head, then lin_1): gat_layer_fused.hip
+int launch_fused_layer0_af(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
+                           const void *h1, const float *asd, const float *W0af, const float *shift_af, void *xw_next, float *asd_next);
 bool fused_heads_available(const bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_model *m);
 // one layer of a plain backbone as aggregate -> GEMM -> post-op (mode 1 GCN, 2 GraphSAGE, 3 GIN's first Linear); see gat_layer_fused.hip
 int launch_fused_plain_layer(bgnn_ctx *ctx, const bgnn_graph *g, int mode, int C, const float *x, const float *dinv, const float *Wfp,

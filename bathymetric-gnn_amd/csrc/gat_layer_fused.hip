@@ -85,6 +85,7 @@ struct FusedArgs {
   void *out;              // [rows][NC]  f32, or bf16 with SP = 3
   float *asd_out;         // [rows][2*H2]
   int H2, C2;
+  const float *W0af;      // layer 0 "aggregate first" (gat_layer_bf16_2p_kernel, AF): the folded lin_0 weight as per-head 64 x 64 bf16 images
   // EPI_HEADS
   const float *hd_tab;    // [HEADW] b0 [96] | second-layer rows (cls [classes], conf, corr) at 96 + 32 j | their biases at 288
   const float *local_std; // [rows]
@@ -1900,9 +1901,19 @@ struct TwoPhaseLds {
   static_assert(3 * BYTES <= 160 * 1024, "three workgroups per CU");
 };
 
-template <int K, int NPASS = 4>       // NPASS: column passes = heads of the next layer (4: 256 -> 256; 1: 256 -> 64, the last GAT layer's lin)
+// AF ("aggregate first", layer 0 only): a.xw is the extractor's h1 [rows][64] bf16 (gemm_f32.hip, extractor_af_kernel) instead of the
+// 256-channel lin_0 product.  The sum over the in-edges is linear, so head hd's 64 output channels are W0_hd (sum_j alpha^hd_ij h1_j) + b:
+// phase 1 aggregates the TWO 32-channel slabs of h1 once per head (the same 8 x 8 aggregation MFMAs, two slab DMAs instead of eight, a
+// quarter of the bytes), an inserted step applies each head's 64 x 64 block of the folded lin_0 weight (a.W0af: 32 KB through the pass
+// buffer, 8 MFMAs per head), folded bias + BatchNorm + ReLU (a.shift carries W's bias: the coefficients of a node sum to 1), and hands
+// phase 2 the same [32 nodes x 256] bf16 operands.  The front GEMM's launch, its 512-byte rows and six slab round trips per block go.
+template <int K, int NPASS = 4, bool AF = false>       // NPASS: column passes = heads of the next layer (4: 256 -> 256; 1: 256 -> 64, the last GAT layer's lin)
 __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) {
+  static_assert(!AF || NPASS == 4, "aggregate-first: layer 0 of the default shape (256 -> 256)");
+  static_assert(!AF || TwoPhaseLds<K, NPASS>::SLAB_B + TwoPhaseLds<K, NPASS>::PAD_B + TwoPhaseLds<K, NPASS>::ALPHA_B >= TwoPhaseLds<K, NPASS>::W_B,
+                "aggregate-first: the scale / shift table sits clear of the pass buffer the heads' weight blocks land in");
   constexpr int NTH = 256, HC = 256, C = 64, H = 4, NC = 64 * NPASS, NT = 2 * NPASS, NSLAB = 8, SPH = 2, NHL = 2;
+  constexpr int SRC_ROWB = AF ? 128 : HC * 2;             // bytes of a source row (AF: the 64-channel h1)
   using Geo = FusedGeom<K>;
   using Lds = TwoPhaseLds<K, NPASS>;
   using Win = AggWindow<K>;
@@ -2017,7 +2028,7 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
     for (int p = 0; p < NPIECE; ++p) {
       const int row = prow_r[p] * HW_ + prow_c[p];
       const int c = cc ^ swz(row);
-      dbase[p] = drow[p] >= 0 ? xbase + ((uint64_t)(uint32_t)drow[p] * (uint32_t)(HC * 2) + (uint32_t)(c * 16)) : zp;
+      dbase[p] = drow[p] >= 0 ? xbase + ((uint64_t)(uint32_t)drow[p] * (uint32_t)SRC_ROWB + (uint32_t)(c * 16)) : zp;
     }
   }
   auto issue_slab = [&](int s) {
@@ -2108,8 +2119,8 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
     tr0 = slab0 + row0 * 64 + ((c ^ ((row0 >> 2) & 3)) << 4) + 8 * (p4 & 1);
     tr1 = slab0 + (row0 + 4) * 64 + ((c ^ (((row0 + 4) >> 2) & 3)) << 4) + 8 * (p4 & 1);
   }
-  auto densify = [&](int hd) {
-    if (hd == 0) {
+  auto densify = [&](int hd, bool clear = true) {
+    if (hd == 0 && clear) {
       const u32x4 z4 = {0u, 0u, 0u, 0u};
       constexpr int DB = 32 * Win::PITCH;
 #pragma unroll
@@ -2201,10 +2212,111 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
     xh[s][0] = to_bf16x8(g[0], g[1]);
     xh[s][1] = to_bf16x8(g[2], g[3]);
   };
-  slab_step(std::integral_constant<int, 0>{}); slab_step(std::integral_constant<int, 1>{});
-  slab_step(std::integral_constant<int, 2>{}); slab_step(std::integral_constant<int, 3>{});
-  slab_step(std::integral_constant<int, 4>{}); slab_step(std::integral_constant<int, 5>{});
-  slab_step(std::integral_constant<int, 6>{}); slab_step(std::integral_constant<int, 7>{});
+  if constexpr (!AF) {
+    slab_step(std::integral_constant<int, 0>{}); slab_step(std::integral_constant<int, 1>{});
+    slab_step(std::integral_constant<int, 2>{}); slab_step(std::integral_constant<int, 3>{});
+    slab_step(std::integral_constant<int, 4>{}); slab_step(std::integral_constant<int, 5>{});
+    slab_step(std::integral_constant<int, 6>{}); slab_step(std::integral_constant<int, 7>{});
+  } else {
+    // ---- aggregate first: the two slabs of h1, each under all four heads' coefficients; then the heads' 64 x 64 weight blocks
+    bf16x8 xa[H][2][2];                                  // [head][slab][k half]: sum_j alpha^hd_ij h1_j as bf16 MFMA operands (64 VGPRs)
+    auto af_slab = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      wait_vm_lgkm<0>();                                 // slab s is all this wave has in flight
+      __builtin_amdgcn_s_barrier();                      // slab s visible to every wave (s = 0: phase A is over on every wave)
+      if constexpr (s == 0) { scsh[tid] = scv; scsh[HC + tid] = shv; }     // (nothing is in flight: visible stores are fine; read in the weight step)
+      auto head = [&](auto hc) {
+        constexpr int hd = decltype(hc)::value;
+        // the wave's dense matrix is private to it and LDS operations of a wave are served in order: the MFMAs' reads of the head
+        // before are complete (agg_blocks waits for them), these writes are served before the reads below
+        densify(hd, s == 0);
+        f32x16 d;
+        if constexpr (Win::NKB == 8) {
+          agg_blocks<0, 4, true, false>(d, tr0, tr1, bq0, hl);
+          agg_blocks<4, 4, false, Win::TAIL_BEYOND_PITCH>(d, tr0, tr1, bq0, hl);
+        } else {
+          agg_blocks<0, 3, true, false>(d, tr0, tr1, bq0, hl);
+          agg_blocks<3, 2, false, false>(d, tr0, tr1, bq0, hl);
+        }
+        f32x4 g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (f32x4){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
+        xa[hd][s][0] = to_bf16x8(g[0], g[1]);
+        xa[hd][s][1] = to_bf16x8(g[2], g[3]);
+      };
+      head(std::integral_constant<int, 0>{}); head(std::integral_constant<int, 1>{});
+      head(std::integral_constant<int, 2>{}); head(std::integral_constant<int, 3>{});
+      __builtin_amdgcn_s_barrier();                      // every wave has read slab s
+      if constexpr (s == 0) {
+        issue_slab(1);
+      } else {
+        // the image and the alpha matrices are dead: the heads' weight blocks (32 pieces of 1 KiB, [head][k-step][tile], into the pass
+        // buffer) and the next layer's att vectors can be requested
+        if (lane * 4 < NC)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(((wave & 1) == 0 ? a.att_src : a.att_dst) + lane * 4),
+                                           (__attribute__((address_space(3))) void *)(attl + (wave & 1) * NC), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = j * 4 + wave;
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(reinterpret_cast<const char *>(a.W0af) + q * 1024 + lane * 16),
+                                           (__attribute__((address_space(3))) void *)(wpass + q * 1024), 16, 0, 0);
+        }
+      }
+    };
+    af_slab(std::integral_constant<int, 0>{}); af_slab(std::integral_constant<int, 1>{});
+    wait_vm_lgkm<0>();
+    __builtin_amdgcn_s_barrier();                        // the weight blocks (and the att vectors) are visible
+    const uint32_t w0frag = lds_addr(wpass) + lane * 16;
+    auto head_gemm = [&](auto hc) {
+      constexpr int hd = decltype(hc)::value;
+      // one 32-column tile at a time (4 fragments, 16 accumulator registers): both tiles at once did not fit beside xa / xh
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 w[4];                                      // k-step kk, tile t of head hd: (hd * 8 + 2 kk + t) KiB
+        if (t == 0) { w[0] = lds_read4<(hd * 8 + 0) * 1024>(w0frag); w[1] = lds_read4<(hd * 8 + 2) * 1024>(w0frag);
+                      w[2] = lds_read4<(hd * 8 + 4) * 1024>(w0frag); w[3] = lds_read4<(hd * 8 + 6) * 1024>(w0frag); }
+        else { w[0] = lds_read4<(hd * 8 + 1) * 1024>(w0frag); w[1] = lds_read4<(hd * 8 + 3) * 1024>(w0frag);
+               w[2] = lds_read4<(hd * 8 + 5) * 1024>(w0frag); w[3] = lds_read4<(hd * 8 + 7) * 1024>(w0frag); }
+        lds_reads_done();
+        if (hd == H - 1 && t == 1) {
+          // every wave has read the last fragments: the pass buffer can take the first column pass of phase 2, which then flies
+          // under this tile's MFMAs and epilogue
+          __builtin_amdgcn_s_barrier();
+          issue_w(0);
+        }
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)                   // k-step kk = channels 16 kk .. of h1 = slab kk / 2, half kk % 2
+          acc = mfma_lp(__builtin_bit_cast(bf16x8, w[kk]), xa[hd][kk / 2][kk % 2], acc);
+        // folded bias + BatchNorm + ReLU of layer 0's output channels 64 hd + 32 t ..: "slab" 2 hd + t of the 256-channel h
+        const int sl = 2 * hd + t;
+        f32x4 g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (f32x4){acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+        const uint32_t cp = scsh0 + sl * 128;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          f32x4 sc0, sc1, sh0, sh1;
+          if (jp == 0) { sc0 = lds_read4<0>(cp); sc1 = lds_read4<32>(cp); sh0 = lds_read4<HC * 4>(cp); sh1 = lds_read4<HC * 4 + 32>(cp); }
+          else { sc0 = lds_read4<64>(cp); sc1 = lds_read4<96>(cp); sh0 = lds_read4<HC * 4 + 64>(cp); sh1 = lds_read4<HC * 4 + 96>(cp); }
+          lds_reads_done();
+          g[2 * jp] = g[2 * jp] * sc0 + sh0;
+          g[2 * jp + 1] = g[2 * jp + 1] * sc1 + sh1;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm("v_max_f32 %0, 0, %0" : "+v"(g[j].x)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].y));
+            asm("v_max_f32 %0, 0, %0" : "+v"(g[j].z)); asm("v_max_f32 %0, 0, %0" : "+v"(g[j].w));
+          }
+        }
+        xh[2 * hd + t][0] = to_bf16x8(g[0], g[1]);
+        xh[2 * hd + t][1] = to_bf16x8(g[2], g[3]);
+      }
+    };
+    head_gemm(std::integral_constant<int, 0>{}); head_gemm(std::integral_constant<int, 1>{});
+    head_gemm(std::integral_constant<int, 2>{}); head_gemm(std::integral_constant<int, 3>{});
+  }
 
   // ---- phase 2: the GEMM, one head (64 columns) of the next layer per pass (W(0) and the att vectors are already in flight; the
   // first pass's barrier also orders every wave's last scale / shift read before the first patch write)
@@ -2317,11 +2429,11 @@ __global__ __launch_bounds__(256, 3) void gat_layer_bf16_2p_kernel(FusedArgs a) 
   }
 }
 
-template <int K, int NPASS>
+template <int K, int NPASS, bool AF = false>
 static int launch_two_phase(bgnn_ctx *ctx, const FusedArgs &a) {
   constexpr size_t lds_bytes = (size_t)TwoPhaseLds<K, NPASS>::BYTES;
   static std::atomic<uint64_t> configured{0};
-  auto kern = gat_layer_bf16_2p_kernel<K, NPASS>;
+  auto kern = gat_layer_bf16_2p_kernel<K, NPASS, AF>;
   if (!(configured.load(std::memory_order_relaxed) >> (ctx->device & 63) & 1)) {
     BGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     configured.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
@@ -2445,6 +2557,22 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   BGNN_FUSED_CASE(128, 4) BGNN_FUSED_CASE(128, 2) BGNN_FUSED_CASE(64, 2)
 #undef BGNN_FUSED_CASE
   return BGNN_ERR_UNSUPPORTED;
+}
+
+// Layer 0 of the bf16 path, aggregate first: h1 [rows][64] bf16 + layer 0's attention dots (launch_extractor_af) -> lin_1's product and dots.
+// W0af: per-head images of the folded lin_0 weight; shift_af: L.shift + L.scale * (folded lin_0 bias).  UNSUPPORTED: take the front GEMM.
+int launch_fused_layer0_af(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer &L, const BgnnLayer &Ln, int C, const float *V3,
+                           const void *h1, const float *asd, const float *W0af, const float *shift_af, void *xw_next, float *asd_next) {
+  if (!fused_supported(g, C) || (!g->edge_default && !V3) || !W0af || !shift_af) return BGNN_ERR_UNSUPPORTED;
+  if (C != 64 || L.heads != 4 || Ln.heads != 4 || Ln.d_in != 256 || !Ln.Wbf) return BGNN_ERR_UNSUPPORTED;
+  FusedArgs a{};
+  fill_common(a, g, L, V3, h1, asd, L.concat ? 1 : 0);
+  a.shift = shift_af;
+  a.Wt = Ln.Wbf; a.W0af = W0af;
+  a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
+  a.H2 = Ln.heads; a.C2 = C;
+  ProfScope ps(ctx, BGNN_K_FUSED);
+  return g->K == 8 ? launch_two_phase<8, 4, true>(ctx, a) : g->K == 4 ? launch_two_phase<4, 4, true>(ctx, a) : launch_two_phase<16, 4, true>(ctx, a);
 }
 
 // One layer of a plain backbone (GCN / GraphSAGE / GIN) as aggregate -> GEMM -> post-op in ONE launch (kernel template AGG = mode):

@@ -19,6 +19,7 @@
 //     then holds 16 output CHANNELS of ONE row (4 groups of 4 consecutive channels), so bias /
 //     ReLU / the attention dot products are in-lane work and stores are float4.
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include "bgnn_internal.h"
 
@@ -707,6 +708,128 @@ static int launch_wres64(bgnn_ctx *ctx, const GemmArgs &a) {
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   const int nw = ctx->opts.gemm_waves;
   hipLaunchKernelGGL(kern, dim3(ctx->num_cus * per_cu), dim3(64 * nw), lds_bytes, ctx->stream, a);
+  BGNN_HIP_CHECK(hipGetLastError());
+  return BGNN_OK;
+}
+
+// ---- layer 0 "aggregate first" (matrix_path = bf16, gat_layer_fused.hip gat_layer_bf16_2p_kernel<K, 4, AF>) --------------------------
+// GATConv's sum over the in-edges is linear, so  sum_j alpha_ij (W h1_j + b)  =  W (sum_j alpha_ij h1_j) + b sum_j alpha_ij : layer 0 can
+// aggregate the extractor's 64-channel h1 (128 bytes per node as bf16) instead of the 256-channel lin_0 product (512 bytes) and apply
+// each head's 64 x 64 block of the folded lin_0 weight afterwards, inside the fused launch.  What is left of the front GEMM is this
+// kernel: extractor layer 1 (the same eight float32 MFMAs), h1 rounded to bf16 -- the operand the front GEMM multiplies -- stored, and the
+// attention dots of layer 0 through the front GEMM's own alpha tile (pack_alpha_tile): [alpha_src | alpha_dst] come out bit for bit
+// as the bf16 front GEMM writes them.  32 + 128 + 32 bytes per node instead of 32 + 512 + 32, no 64 -> 256 product.
+struct ExtractorAfArgs {
+  const float *X;         // [M][8] node features
+  const float *W0t;       // [8][64] extractor layer 1 (transposed)
+  const float *b0;        // [64]
+  const float *alpha_tile;   // 4 k-steps x 1 KiB of bf16 A fragments, then 8 floats: the bias' share of the dots
+  void *h1;               // [M][64] bf16
+  float *asd;             // [M][2 H]
+  const int64_t *d_m;
+  int H;
+};
+
+__global__ __launch_bounds__(256, 3) void extractor_af_kernel(ExtractorAfArgs a) {
+  __shared__ __attribute__((aligned(128))) char patches_[4 * 32 * 128];     // per wave: [32 rows][128 B] of bf16, chunks XOR-swizzled
+  __shared__ float b0l[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 64) b0l[threadIdx.x] = a.b0[threadIdx.x];
+  float w0[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[t][i] = a.W0t[(4 * h + i) * 64 + t * 32 + r];
+  bf16x8 wa[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) wa[st] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(a.alpha_tile) + st * 1024 + lane * 16);
+  float cbv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cbv[i] = a.alpha_tile[1024 + 4 * h + i];
+  __syncthreads();
+  const int64_t M = *a.d_m;
+  char *patch = patches_ + wave * (32 * 128);
+  const int64_t stride = (int64_t)gridDim.x * 4 * 32;
+  int64_t row0 = (int64_t)blockIdx.x * 4 * 32 + wave * 32;
+  f32x4 xq = {0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](int64_t rb) {
+    const int64_t row = rb + r;
+    xq = *reinterpret_cast<const f32x4 *>(a.X + (row < M ? row : M - 1) * 8 + 4 * h);
+  };
+  if (row0 < M) load_x(row0);
+  for (; row0 < M; row0 += stride) {
+    // extractor layer 1: the instruction sequence of the front GEMM (gemm_wres64_kernel, FRONT)
+    f32x16 a1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a1[t][i] = 0.0f;
+    const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[t][i], xv[i], a1[t], 0, 0, 0);
+    if (row0 + stride < M) load_x(row0 + stride);
+    float4 ax[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                     // channels 8s + 4h + i = tile s / 4, registers 4 (s % 4) + i
+      const float4 b = *reinterpret_cast<const float4 *>(b0l + 8 * s + 4 * h);
+      float4 v = make_float4(a1[s / 4][4 * (s % 4)] + b.x, a1[s / 4][4 * (s % 4) + 1] + b.y, a1[s / 4][4 * (s % 4) + 2] + b.z,
+                             a1[s / 4][4 * (s % 4) + 3] + b.w);
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      ax[s] = v;
+    }
+    f32x16 acca;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acca[i] = 0.0f;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    // patch: 16-byte chunk s (channels 8s .. 8s + 7) of row r at chunk s ^ (r & 7), its two 8-byte halves swapped on rows with bit 3 set
+    // (ds_write_b64 is served per 16 consecutive lanes: 8 chunk slots x 2 halves = 16 distinct bank pairs)
+    char *pb = patch + r * 128 + ((h ^ ((r >> 3) & 1)) << 3);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const float v[8] = {ax[2 * st].x, ax[2 * st].y, ax[2 * st].z, ax[2 * st].w, ax[2 * st + 1].x, ax[2 * st + 1].y, ax[2 * st + 1].z, ax[2 * st + 1].w};
+      bf16x8 xh;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xh[i] = (__bf16)v[i];
+      acca = mfma_lp(wa[st], xh, acca);
+      const bf16x4 lo = {xh[0], xh[1], xh[2], xh[3]}, hi = {xh[4], xh[5], xh[6], xh[7]};
+      *reinterpret_cast<bf16x4 *>(pb + (((2 * st) ^ (r & 7)) << 4)) = lo;
+      *reinterpret_cast<bf16x4 *>(pb + (((2 * st + 1) ^ (r & 7)) << 4)) = hi;
+    }
+    {
+      // lane (r, h): registers 0-3 = the hi parts of head 0-3's src (h = 0) / dst (h = 1) dot, registers 4-7 the lo parts
+      const int64_t row = row0 + r;
+      const int H = a.H;
+      if (row < M) {
+        const float d0 = acca[0] + acca[4] + cbv[0], d1 = acca[1] + acca[5] + cbv[1], d2 = acca[2] + acca[6] + cbv[2],
+                    d3 = acca[3] + acca[7] + cbv[3];
+        float *p = a.asd + row * 2 * H + h * H;
+        if (H == 4) *reinterpret_cast<float4 *>(p) = make_float4(d0, d1, d2, d3);
+        else { p[0] = d0; if (H > 1) p[1] = d1; if (H > 2) p[2] = d2; }
+      }
+    }
+    // (wave-private patch: the wave's own LDS writes are complete before its reads are served -- one queue, in order)
+    char *dst = reinterpret_cast<char *>(a.h1) + row0 * 128 + lane * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (lane >> 3) + 8 * k;             // (row >> 3) & 1 == k & 1: the half swap is known at compile time
+      uint4 q = *reinterpret_cast<const uint4 *>(patch + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+      if (k & 1) q = make_uint4(q.z, q.w, q.x, q.y);
+      if (row0 + row < M) *reinterpret_cast<uint4 *>(dst + k * 1024) = q;
+    }
+  }
+}
+
+int launch_extractor_af(bgnn_ctx *ctx, const float *x8, const float *W0t, const float *b0, const float *alpha_tile, void *h1, float *asd,
+                        const int64_t *d_m, int64_t max_rows, int H) {
+  if (max_rows <= 0) return BGNN_OK;
+  ProfScope ps(ctx, BGNN_K_GEMM);
+  ExtractorAfArgs a{x8, W0t, b0, alpha_tile, h1, asd, d_m, H};
+  const int64_t groups = (max_rows + 127) / 128;
+  const int grid = (int)std::min<int64_t>(groups, (int64_t)ctx->num_cus * 8);
+  hipLaunchKernelGGL(extractor_af_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
   return BGNN_OK;
 }

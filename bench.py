@@ -43,11 +43,14 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 DEG = {"4-connected": 4, "8-connected": 8, "16-dilated": 16}
 
 
-def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3, act_bytes=4):
+def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=8, edge_dim=3, act_bytes=4, layer0_af=False):
     """SURVEY.md 8(d) per-node figures (compulsory traffic: each tensor read once + written once).  ``act_bytes``: bytes per
     stored layer activation (4 = fp32, the reference's dtype; 2 = bf16 storage of BASELINE config 3).  ``fused_bytes``
     prices the fused launches (xW in / next xW out at ``act_bytes``; attention dots and edge attributes stay f32);
-    ``front_bytes`` the front GEMM launch (32-byte feature row in, xW_0 + attention dots out)."""
+    ``front_bytes`` the front GEMM launch (32-byte feature row in, xW_0 + attention dots out).  ``layer0_af`` (bf16 path, default
+    shape): layer 0 aggregates the extractor's ``hidden``-channel output and applies lin_0 inside the fused launch, so the front launch
+    writes and the first fused launch reads ``hidden`` channels per node instead of ``heads * hidden`` -- priced at what that form has to
+    move (SURVEY's figure for the reference's operation order would flatter it: 3 772 instead of 3 388 B/node at k = 16)."""
     agg_bytes = 0
     gemm_flops = 2 * (in_ch * hidden)                              # feature extractor layer 1 (layer 2 is folded into lin_0: executed flops)
     gemm_bytes = 4 * (8 + hidden) + 4 * (hidden + hidden)
@@ -71,7 +74,7 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
     # hidden x hidden product of the reference is not run
     H0 = heads if num_layers > 1 else 1
     front_flops = 2 * (in_ch * hidden + hidden * (hidden * H0))
-    front_bytes = 32 + act_bytes * hidden * H0 + 4 * 2 * H0
+    front_bytes = 32 + act_bytes * hidden * (1 if layer0_af else H0) + 4 * 2 * H0
     for l in range(num_layers):
         last = l == num_layers - 1
         H = 1 if last else heads
@@ -80,7 +83,8 @@ def algorithmic_model(num_layers=4, hidden=64, heads=4, in_ch=7, classes=3, deg=
             Hn = 1 if l + 1 == num_layers - 1 else heads
             nc = Hn * hidden
             fused_flops += 2 * hc * nc
-            fused_bytes += act_bytes * hc + 4 * 2 * H + 4 * deg * edge_dim + act_bytes * nc + 4 * 2 * Hn
+            src = hidden if (layer0_af and l == 0) else hc
+            fused_bytes += act_bytes * src + 4 * 2 * H + 4 * deg * edge_dim + act_bytes * nc + 4 * 2 * Hn
         else:
             fused_flops += 2 * hidden * nh * (hidden // 2)
             fused_bytes += act_bytes * hc + 4 * 2 * H + 4 * deg * edge_dim + 4 * 3
@@ -319,6 +323,12 @@ class Bench:
             m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
             self._models[key] = (m.to(self.dev).eval(), sd)
         return self._models[key]
+
+    def ctx_option(self, name):
+        try:
+            return int(self.ctx.get_option(name))
+        except Exception:
+            return 0
 
     def barrier(self):
         if self.dist is not None:
@@ -595,8 +605,10 @@ class Bench:
     def report(self, wl, m):
         """value / ms_per_step / rooflines / kernels of one measured workload (rank 0's kernel events)."""
         steps, prof = m["steps"], m["prof"]
+        af = bool(wl["bf16"] and self.layers >= 2 and (self.hidden, self.heads) == (64, 4) and self.ctx_option("bf16_layer0_af")
+                  and self.ctx_option("bf16_two_phase"))
         am = algorithmic_model(num_layers=self.layers, deg=wl["deg"], act_bytes=2 if wl["bf16"] else 4,
-                               in_ch=8 if wl["kind"] == "vr" else 7, hidden=self.hidden, heads=self.heads)
+                               in_ch=8 if wl["kind"] == "vr" else 7, hidden=self.hidden, heads=self.heads, layer0_af=af)
         n_local = wl["nodes_per_step"] * steps
         kernels = {k: {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps} for k, v in prof.items() if v["launches"]}
 
@@ -638,7 +650,8 @@ class Bench:
             if bf16 or split:
                 # bf16 / 16-bit split MFMAs: the front GEMM's matrix work is negligible against that pipe -- it is a streaming
                 # kernel (32-byte feature row in, xW_0 + attention dots out) and is priced by its bytes
-                roofs["front_gemm"] = roof("gemm_wres64_kernel", "gemm", "hbm", am["front_bytes"],
+                roofs["front_gemm"] = roof("extractor_af_kernel" if af else "gemm_wres64_kernel", "gemm", "hbm", am["front_bytes"],
+                                           "extractor layer 1 + layer 0's attention dots (aggregate-first: feature row in, h1 as bf16 + dots out)" if af else
                                            "front GEMM on 16-bit MFMA: HBM-bound, priced by compulsory bytes (feature row in, xW_0 + attention dots out)")
             else:
                 roofs["front_gemm"] = roof("gemm_wres64_kernel", "gemm", "mfma", am["front_flops"],

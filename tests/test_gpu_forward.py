@@ -1024,8 +1024,8 @@ def _bf16_bound(ref64):
     return BF16_LOGIT_BOUND * max(1.0, float(ref64["class_logits"].abs().max()) / 0.25)
 
 
-@pytest.mark.parametrize("conn", ["16-dilated", "8-connected"])
-def test_config3_bf16_storage_distance_to_float64(conn, gpu_device):
+@pytest.mark.parametrize("conn,af", [("16-dilated", 1), ("8-connected", 1), ("16-dilated", 0), ("8-connected", 0)])
+def test_config3_bf16_storage_distance_to_float64(conn, af, gpu_device):
     """configs[2]: 256 x 256 tile, k = 16, layer activations stored as bf16 (matrix_path = bf16).  Reports and bounds the
     distance of the class logits to the oracle's float64 forward, next to the exact-f32 path's, and what that distance does to the
     DECISION: the heads are calibrated to a logit spread of 1.0 (round 3 used 0.1: with |logit| <= 0.24 only 8 % of the nodes had a
@@ -1044,8 +1044,16 @@ def test_config3_bf16_storage_distance_to_float64(conn, gpu_device):
     _set_matrix_path("exact_f32")
     exact = model.predict(g)
     _set_matrix_path("bf16")
-    out = model.predict(g)
-    out2 = model.predict(g)
+    # af = 1 (default): layer 0 aggregates the extractor's h1 and applies lin_0 per head afterwards; 0: front GEMM + ordinary launch
+    from bathymetric_gnn_amd import runtime as rt
+    ctx = rt.get_context(gpu_device)
+    assert ctx.get_option("bf16_layer0_af") == 1
+    ctx.set_option("bf16_layer0_af", af)
+    try:
+        out = model.predict(g)
+        out2 = model.predict(g)
+    finally:
+        ctx.set_option("bf16_layer0_af", 1)
     assert torch.equal(out["class_logits"], out2["class_logits"])                    # deterministic
     e_exact, e_bf16 = _fp64_distance(exact, ref64), _fp64_distance(out, ref64)
     conf_err = float((out["confidence"].double().cpu() - ref64["confidence"]).abs().max())
@@ -1057,7 +1065,7 @@ def test_config3_bf16_storage_distance_to_float64(conn, gpu_device):
     flips_exact = float((exact["predicted_class"].cpu() != ref64["predicted_class"]).double().mean())
     classes = torch.bincount(ref64["predicted_class"], minlength=3).double() / ref64["predicted_class"].numel()
     bound = _bf16_bound(ref64)
-    row = {"connectivity": conn, "nodes": int(og.x.shape[0]), "logit_abs_max": float(ref64["class_logits"].abs().max()),
+    row = {"connectivity": conn, "layer0_aggregate_first": af, "nodes": int(og.x.shape[0]), "logit_abs_max": float(ref64["class_logits"].abs().max()),
            "logit_bound_scaled": bound, "exact_f32": {"max": e_exact[0], "rms": e_exact[1], "class_flip_rate_all_nodes": flips_exact},
            "bf16_storage": {"max": e_bf16[0], "rms": e_bf16[1]},
            "bf16_confidence_max_err": conf_err, "class_agreement_on_clear_nodes": agree, "clear_fraction": float(clear.double().mean()),
@@ -1065,7 +1073,7 @@ def test_config3_bf16_storage_distance_to_float64(conn, gpu_device):
     print("config3", json.dumps(row))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):
-        json.dump(row, open(os.path.join(out_dir, f"config3_accuracy_{conn}.json"), "w"), indent=1)
+        json.dump(row, open(os.path.join(out_dir, f"config3_accuracy_{conn}{'' if af else '_front_gemm'}.json"), "w"), indent=1)
     assert e_exact[0] < TOL
     assert e_bf16[0] < bound and e_bf16[1] < bound / 4, row
     assert float(classes.min()) > 0.05, row                                           # every class is really there
@@ -1214,15 +1222,21 @@ def test_bf16_two_phase_instance_is_bit_identical_to_the_one_phase_instance(conn
     ragged = [synthetic.synthetic_tile(h, w, 700 + i, "V1") for i, (h, w) in enumerate([(40, 56), (17, 23), (9, 31), (50, 50), (3, 3), (26, 8)])]
     _set_matrix_path("bf16")
     outs = {}
-    for two in (1, 0):
-        ctx.set_option("bf16_two_phase", two)
+    # (layer 0's aggregate-first launch is another rounding sequence: off for the bit comparison, then held against it within bf16 noise)
+    for two, af in ((1, 0), (0, 0), (1, 1)):
+        ctx.set_option("bf16_two_phase", two); ctx.set_option("bf16_layer0_af", af)
         try:
             u = eng.infer_device(hw, res, d_t, m_t, None).clone()
             rg = eng.infer([t[0] for t in ragged], [t[1] for t in ragged], None, [(0.5, 1.0)] * len(ragged))
         finally:
-            ctx.set_option("bf16_two_phase", 1)
-        outs[two] = (u, rg)
+            ctx.set_option("bf16_two_phase", 1); ctx.set_option("bf16_layer0_af", 1)
+        outs[2 if af else two] = (u, rg)
     assert torch.isfinite(outs[1][0]).all() and float(outs[1][0][1].max()) > 0.0
+    assert torch.isfinite(outs[2][0]).all() and not torch.equal(outs[2][0], outs[1][0])
+    assert float((outs[2][0][1] - outs[1][0][1]).abs().max()) < 2e-2                  # confidence grids: aggregate-first vs front GEMM
+    assert torch.equal(outs[2][0] == 0, outs[1][0] == 0)                              # the same cells are written
+    for a, b in zip(outs[2][1], outs[1][1]):
+        assert np.abs(a["confidence"] - b["confidence"]).max() < 2e-2
     for other in (0,):
         assert torch.equal(outs[1][0], outs[other][0])
         for a, b in zip(outs[1][1], outs[other][1]):

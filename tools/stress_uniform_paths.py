@@ -35,10 +35,13 @@ for rnd in range(args.rounds):
     ctx.set_option("fused_persistent", 0); ctx.set_option("fused_front", 1); ctx.set_option("gemm_pair_major", 1)
     ok = all(torch.equal(o, outs[0]) for o in outs[1:])
     ctx.set_option("matrix_path", "bf16")
+    af = eng.infer_device(hw, res, d, m, u).clone(); af2 = eng.infer_device(hw, res, d, m, u).clone()   # layer 0 aggregate-first (default)
+    ctx.set_option("bf16_layer0_af", 0)               # front GEMM + ordinary launch: another rounding sequence, compared within bf16 noise
     bf = eng.infer_device(hw, res, d, m, u).clone(); bf2 = eng.infer_device(hw, res, d, m, u).clone()
     ctx.set_option("bf16_two_phase", 0)               # the one-phase 256 -> 256 instance: bit-identical to the two-phase form
     bf1 = eng.infer_device(hw, res, d, m, u).clone()
-    ctx.set_option("bf16_two_phase", 1)
+    ctx.set_option("bf16_two_phase", 1); ctx.set_option("bf16_layer0_af", 1)
+    ok = ok and torch.equal(af, af2) and float((af[1] - bf[1]).abs().max()) < 2e-2
     ctx.set_option("matrix_path", "exact_f32")
     err = float((bf[1] - outs[0][1]).abs().max())
     ok = ok and torch.equal(bf, bf2) and torch.equal(bf, bf1) and err < 5e-2 and bool(torch.isfinite(bf).all())

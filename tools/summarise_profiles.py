@@ -115,7 +115,7 @@ def main():
             cls_acc[cls][0] += (2.0 * fb + wb) * n
             cls_acc[cls][1] += n
         for cls, (tot, n) in cls_acc.items():
-            if cls in ("gat_layer_fused_kernel", "gat_aggregate_tiled_kernel", "gemm_f32_kernel", "gemm_wres64_kernel", "features_kernel"):
+            if cls in ("gat_layer_fused_kernel", "gat_aggregate_tiled_kernel", "gemm_f32_kernel", "gemm_wres64_kernel", "features_kernel", "extractor_af_kernel"):
                 key = cls if mode not in ("split", "c3") else cls + ":" + mode
                 if mode == "unfused" and cls != "gat_aggregate_tiled_kernel":
                     continue
