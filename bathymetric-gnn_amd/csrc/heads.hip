@@ -148,6 +148,8 @@ int launch_heads_final(bgnn_ctx *ctx, const bgnn_model *m, const float *hid, int
     hipLaunchKernelGGL((heads_final_fast_kernel<3, 32>), grid, block, 0, ctx->stream, a);
   else if (a.classes == 3 && a.hh == 16 && ldh % 4 == 0)
     hipLaunchKernelGGL((heads_final_fast_kernel<3, 16>), grid, block, 0, ctx->stream, a);
+  else if (a.classes == 3 && a.hh == 64 && ldh % 4 == 0)          // hidden 128 (and the widths padded to it): the runtime-width kernel took 25 ms per 8.4 M nodes
+    hipLaunchKernelGGL((heads_final_fast_kernel<3, 64>), grid, block, 0, ctx->stream, a);
   else
     hipLaunchKernelGGL(heads_final_kernel, grid, block, 0, ctx->stream, a);
   BGNN_HIP_CHECK(hipGetLastError());
