@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_util
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# the kernels these counters are collected on (the summary carries the stamp; DESIGN.md quotes only stamped figures)
+python3 -c "import sys; sys.path.insert(0, '$R'); from bathymetric_gnn_amd import runtime; print(runtime.build_id())" > $O/build_id.txt
 for mode in exact c3; do
   flag=""; [ $mode = c3 ] && flag="--workload c3"
   for ctr in MfmaUtil VALUBusy; do

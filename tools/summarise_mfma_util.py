@@ -17,7 +17,10 @@ out = {"_note": "rocprofv3 --kernel-trace --pmc MfmaUtil / --pmc VALUBusy (separ
 for mode in ("exact", "c3"):
     for ctr in ("MfmaUtil", "VALUBusy"):
         acc = collections.defaultdict(list)
-        for f in glob.glob(os.path.join(a.src, f"{mode}_{ctr}", "**", "*counter_collection.csv"), recursive=True):
+        files = glob.glob(os.path.join(a.src, f"{mode}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+        # (gpurun MERGES a run's output into gpurun_out/: an earlier run's file may sit beside the new one -- newest only)
+        files = sorted(files, key=os.path.getmtime)[-1:]
+        for f in files:
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != ctr:
                     continue

@@ -5,12 +5,20 @@ import collections, csv, glob, json, os, re, sys
 mode = sys.argv[1] if len(sys.argv) > 1 else "c3"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "gpurun_out", f"prof_sq_{mode}", "**", "*counter_collection.csv"), recursive=True):
+files = glob.glob(os.path.join(root, "gpurun_out", f"prof_sq_{mode}", "**", "*counter_collection.csv"), recursive=True)
+newest_of = {}
+for f in files:                              # (one file per counter group; an earlier run's file merged beside it is dropped)
+    g = os.path.relpath(f, os.path.join(root, "gpurun_out", f"prof_sq_{mode}")).split(os.sep)[0]
+    if g not in newest_of or os.path.getmtime(f) > os.path.getmtime(newest_of[g]):
+        newest_of[g] = f
+for f in newest_of.values():
     for r in csv.DictReader(open(f)):
         k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("bgnn::", ""); k = re.sub(r"\(.*\)$", "", k)
-        if "fused" in k or "gemm" in k:
+        if "fused" in k or "gemm" in k or "2p_kernel" in k or "extractor" in k:
             acc[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
-out = {"_note": f"rocprofv3 --kernel-trace --pmc (a few counters per pass, tools/collect_sq_counters.sh {mode}); full-batch launches of "
+bid = os.path.join(root, "gpurun_out", f"prof_sq_{mode}", "build_id.txt")
+out = {"build_id": open(bid).read().strip() if os.path.exists(bid) else None,
+       "_note": f"rocprofv3 --kernel-trace --pmc (a few counters per pass, tools/collect_sq_counters.sh {mode}); full-batch launches of "
                 "bench.py --no-extras; 'share' = counter / SQ_WAVE_CYCLES for the SQ cycle counters"}
 for k, cs in acc.items():
     row = {}
