@@ -84,7 +84,7 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
  *                     the GEMM in column passes; bit-identical to 0, the one-phase instance)          [BGNN_NO_TWO_PHASE]
  *   "bf16_layer0_af"  1 (default): matrix_path 3, default model shape: layer 0 aggregates the extractor's 64-channel output and applies the
  *                     folded lin_0 weight per head afterwards, inside the fused launch (GATConv's sum is linear; no lin_0 GEMM launch, no
- *                     256-channel lin_0 rows in HBM); 0: lin_0 GEMM first (another rounding sequence)        [BGNN_NO_LAYER0_AF]
+ *                     256-channel lin_0 rows in HBM; needs bf16_two_phase = 1); 0: lin_0 GEMM first (another rounding sequence)   [BGNN_NO_LAYER0_AF]
  *   "stats_narrow"    -1 (default): 16-wide box-statistics workgroups when the 64-wide launch would leave CUs idle; 0 / 1 force
  * plus experiment / diagnostic knobs ("fused_lds_pad_kb", "gemm_waves", "gemm_no_wres"; "diag_mask",
  * "diag_stamps", "gemm_diag" exist only in the diagnostic build of the library).  Unknown names -> BGNN_ERR_INVALID. */

@@ -1591,6 +1591,23 @@ def test_any_edge_feature_list_and_self_loops_run_on_the_fused_kernels(ef, conn,
         ctx.set_option("fused", 1)
     assert n_fused0 == 0 and n_agg0 == 4
     assert (out["class_logits"] - ref["class_logits"]).abs().max().item() < TOL
+    # matrix_path = bf16 on the same graph: layer 0's aggregate-first launch takes the canonical edge vector too -- against the
+    # front-GEMM form within bf16 noise, both near the exact path
+    res = {}
+    _set_matrix_path("bf16")
+    try:
+        for af in (1, 0):
+            ctx.set_option("bf16_layer0_af", af)
+            res[af], n_f, n_a = _fused_launches(lambda: model.predict(g))
+            assert n_f == 4 and n_a == 0
+    finally:
+        ctx.set_option("bf16_layer0_af", 1)
+        _set_matrix_path("exact_f32")
+    for af in (1, 0):
+        assert torch.isfinite(res[af]["class_logits"]).all()
+        assert (res[af]["confidence"] - out["confidence"]).abs().max().item() < 3e-2, af
+    assert not torch.equal(res[1]["class_logits"], res[0]["class_logits"])
+    assert (res[1]["confidence"] - res[0]["confidence"]).abs().max().item() < 2e-2
 
 
 def test_table_cache_full_of_pinned_entries_gives_private_tables(gpu_device):
