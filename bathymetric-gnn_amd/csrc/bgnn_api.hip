@@ -366,11 +366,27 @@ static inline float f16_to_f32(uint16_t h) {
   float f; memcpy(&f, &u, 4); return f;
 }
 
-// returns false when a float16 image would overflow (|w| >= 65504): the caller then leaves that image out
-static bool pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool f16) {
-  if (f16)
-    for (size_t i = 0; i < (size_t)D * NC; ++i)
-      if (!(std::fabs(Wt[i]) < 65504.0f)) return false;
+// float16 images hold W * 2^S, S chosen so that the largest |w| lands in [2^12, 2^13): the lo part of an element is then ~2^-11 of it
+// and NORMAL in float16 for everything within 2^14 of the largest weight -- unscaled, the lo parts of glorot-sized weights (|w| <=
+// 0.14, lo <= 6.7e-5) sat at float16's smallest normal and were carried with an absolute step of 2^-24, i.e. ~21 bits of W: that,
+// not the dropped lo x lo term, was what put fp16x3 2.4x farther from the float64 forward than the exact path (profiles/NOTES_r05.md).
+// The kernels multiply their accumulators by 2^-S (*inv_scale; exact) before the epilogue.  Returns false when a weight is beyond float16's range.
+static bool pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool f16, float *inv_scale = nullptr) {
+  float sc = 1.0f;
+  if (f16) {
+    float amax = 0.0f;
+    for (size_t i = 0; i < (size_t)D * NC; ++i) {
+      if (!(std::fabs(Wt[i]) < 65504.0f)) return false;   // (a weight that large also drives the ACTIVATIONS out of float16's range: bf16 split instead)
+      amax = std::max(amax, std::fabs(Wt[i]));
+    }
+    if (amax > 0.0f) {
+      int e;
+      std::frexp(amax, &e);                              // amax = m 2^e, m in [0.5, 1)
+      const int S = std::max(-100, std::min(100, 13 - e));
+      sc = std::ldexp(1.0f, S);
+    }
+  }
+  if (inv_scale) *inv_scale = 1.0f / sc;
   uint16_t *dst = reinterpret_cast<uint16_t *>(dst_as_float);
   const int NT = NC / 32;
   for (int hc = 0; hc < D / 16; ++hc)
@@ -379,7 +395,7 @@ static bool pack_split(const float *Wt, int D, int NC, float *dst_as_float, bool
         for (int kg = 0; kg < 2; ++kg)
           for (int m = 0; m < 32; ++m)
             for (int i = 0; i < 8; ++i) {
-              const float w = Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m];
+              const float w = Wt[(size_t)(hc * 16 + kg * 8 + i) * NC + t * 32 + m] * sc;
               const uint16_t hi = f16 ? f16_rne(w) : bf16_rne(w);
               const uint16_t v = part == 0 ? hi : f16 ? f16_rne(w - f16_to_f32(hi)) : bf16_rne(w - bf16_to_f32(hi));
               dst[((((size_t)hc * NT + t) * 2 + part) * 2 + kg) * 256 + m * 8 + i] = v;
@@ -750,6 +766,8 @@ static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const fl
   std::vector<size_t> o_wsp(L, 0), o_wsp16(L, 0), o_wbf(L, 0), o_wfp(L, 0);
   size_t o_hW0sp = 0, o_l0fsp = 0, o_hW0sp16 = 0, o_l0fsp16 = 0, o_hW0bf = 0, o_l0fbf = 0, o_hW0fp = 0, o_l0fpm = 0;
   bool f16_ok = true;                  // every weight fits float16: else BGNN_SPLIT_F16 falls back to the bf16 split
+  std::vector<float> inv16(L, 1.0f);   // 2^-S of each float16 image (pack_split)
+  float inv16_hd = 1.0f, inv16_l0f = 1.0f;
   if (gat) {
     for (int l = 1; l < L; ++l) {
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
@@ -764,18 +782,18 @@ static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const fl
       const int H = l == L - 1 ? 1 : d->heads, D = hid * d->heads, HC = H * hid;
       std::vector<float> src(pk.begin() + lo[l].Wt, pk.begin() + lo[l].Wt + (size_t)D * HC);
       pack_split(src.data(), D, HC, pk.data() + o_wsp[l], false);
-      if (!pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true)) f16_ok = false;
+      if (!pack_split(src.data(), D, HC, pk.data() + o_wsp16[l], true, &inv16[l])) f16_ok = false;
       pack_bf16_image_accop(src.data(), D, HC, pk.data() + o_wbf[l]);
       pack_tilegroup_image(src.data(), D, HC, pk.data() + o_wfp[l]);
     }
     std::vector<float> src(pk.begin() + o_hW0t, pk.begin() + o_hW0t + (size_t)hid * HT);
     pack_split(src.data(), hid, HT, pk.data() + o_hW0sp, false);
-    if (!pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true)) f16_ok = false;
+    if (!pack_split(src.data(), hid, HT, pk.data() + o_hW0sp16, true, &inv16_hd)) f16_ok = false;
     pack_bf16_image_accop(src.data(), hid, HT, pk.data() + o_hW0bf);
     pack_tilegroup_image(src.data(), hid, HT, pk.data() + o_hW0fp);
     std::vector<float> src0(pk.begin() + o_l0f_Wt, pk.begin() + o_l0f_Wt + (size_t)hid * HC0);
     pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp, false);
-    if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true)) f16_ok = false;
+    if (!pack_split(src0.data(), hid, HC0, pk.data() + o_l0fsp16, true, &inv16_l0f)) f16_ok = false;
     pack_bf16_image_accop(src0.data(), hid, HC0, pk.data() + o_l0fbf);
     if (o_l0fpm) pack_tilegroup_image(src0.data(), hid, HC0, pk.data() + o_l0fpm, 2);
     if (HC0 / hid <= 4) {
@@ -839,6 +857,7 @@ static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const fl
   m->l0f_Wt = m->blob + o_l0f_Wt; m->l0f_b = m->blob + o_l0f_b;
   m->l0f_Wsp = gat ? m->blob + o_l0fsp : nullptr;
   m->l0f_Wsp16 = gat && f16_ok ? m->blob + o_l0fsp16 : nullptr;
+  m->l0f_Wsp16_inv = inv16_l0f; m->hd_W0sp16_inv = inv16_hd;
   m->l0f_Wbf = gat ? m->blob + o_l0fbf : nullptr;
   m->l0f_Wpm = gat && o_l0fpm ? m->blob + o_l0fpm : nullptr;
   m->l0f_Wt_blk = o_l0f_blk ? m->blob + o_l0f_blk : nullptr;
@@ -870,6 +889,7 @@ static int model_create_native(bgnn_ctx *ctx, const bgnn_model_desc *d, const fl
     Ly.V = m->blob + lo[l].V; Ly.scale = m->blob + lo[l].sc; Ly.shift = m->blob + lo[l].sh;
     Ly.Wsp = l > 0 ? m->blob + o_wsp[l] : nullptr;
     Ly.Wsp16 = l > 0 && f16_ok ? m->blob + o_wsp16[l] : nullptr;
+    Ly.Wsp16_inv = inv16[l];
     Ly.Wbf = l > 0 ? m->blob + o_wbf[l] : nullptr;
     Ly.Wfp = l > 0 ? m->blob + o_wfp[l] : nullptr;
     Ly.tr_bias = m->blob + lo[l].tr_bias; Ly.bn_w = m->blob + lo[l].tr_bw; Ly.bn_b = m->blob + lo[l].tr_bb;
@@ -1435,7 +1455,7 @@ static int forward_impl(bgnn_ctx *ctx, bgnn_model *m, bgnn_graph *g, float thr_a
       BGNN_TRY(launch_gemm_f32(ctx, front ? g->d_x8 : Y, front ? 8 : hid, m->l0f_Wt, m->l0f_b, X, L0.heads * hid, dm, rows, hid,
                                L0.heads * hid, 0, L0.att_src, L0.att_dst, asdX, L0.heads, hid, wsplit, smode,
                                front ? m->fe_W0t : nullptr, front ? m->fe_b0 : nullptr, front && smode == 0 ? m->l0f_Wpm : nullptr,
-                               m->l0f_Wt_blk));
+                               m->l0f_Wt_blk, smode == 2 ? m->l0f_Wsp16_inv : 1.0f));
       }
     } else {
       BGNN_REQUIRE(!bf16, "matrix_path = bf16 needs fold_extractor = 1");

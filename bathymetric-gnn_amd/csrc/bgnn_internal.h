@@ -147,7 +147,8 @@ struct BgnnLayer {
   float *scale;     // [width]  BN weight / sqrt(var + eps)
   float *shift;     // [width]  (conv bias - mean) * scale + BN bias
   float *Wsp;       // Wt as a bf16 hi / lo split image for the bf16x3 matrix path (same byte geometry as Wt; see pack_split)
-  float *Wsp16;     // the same with float16 parts (fp16x3)
+  float *Wsp16;     // the same with float16 parts (fp16x3), of W * 2^S ...
+  float Wsp16_inv = 1.0f;   // ... 2^-S: the kernels' accumulators are multiplied by it (bgnn_api.hip pack_split)
   float *Wfp;       // Wt with the columns of every row permuted for the fused exact-f32 kernel (gat_layer_fused.hip: WTileGroup)
   float *Wbf;       // Wt as a bf16 (hi only) image for the bf16 storage path: [D/16][NC/32][1 KiB] in MFMA A-fragment lane order
   // non-attention backbones (desc.gnn_type != BGNN_GNN_GAT): Wt = GCN lin^T [hid][hid] | SAGE [lin_l^T ; lin_r^T] [2 hid][hid]
@@ -181,6 +182,7 @@ struct bgnn_model {
   int head_hidden_total;      // (2 or 3) * hid/2, padded to a multiple of 32
   float *hd_W0t, *hd_b0;      // [hid][head_hidden_total], [head_hidden_total]
   float *hd_W0sp = nullptr, *hd_W0sp16 = nullptr;   // hd_W0t as bf16 / float16 hi / lo split images
+  float hd_W0sp16_inv = 1.0f, l0f_Wsp16_inv = 1.0f; // 2^-S of the float16 images (pack_split)
   float *hd_W1, *hd_b1;       // second layers packed: cls [classes][hid/2], conf [hid/2], corr [hid/2]; biases
   float *hd_tab = nullptr;    // fused heads epilogue's LDS image, [296]: b0 [96] | second-layer rows [<= 6][32] | their biases [8]
   // The fused layer kernels rebuild a slot's attributes in the CANONICAL order (distance, depth_difference, slope).  For a graph built
@@ -291,7 +293,7 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
                     const float *att_src = nullptr, const float *att_dst = nullptr, float *asd = nullptr,
                     int H = 0, int C = 0, const float *Wt_split = nullptr, int split_mode = 0,
                     const float *front_W0t = nullptr, const float *front_b0 = nullptr, const float *Wt_pm = nullptr,
-                    const float *Wt_blk = nullptr);
+                    const float *Wt_blk = nullptr, float split_inv_scale = 1.0f);
 bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int split_mode);
 // bf16 path, layer 0 aggregate-first: extractor layer 1 -> h1 [M][64] bf16 + layer 0's attention dots through the bf16 front GEMM's alpha tile
 int launch_extractor_af(bgnn_ctx *ctx, const float *x8, const float *W0t, const float *b0, const float *alpha_tile, void *h1, float *asd,

@@ -30,7 +30,8 @@ struct TiledArgs {
 };
 
 template <int HC, int C, int K, int TH, int TW>
-__global__ __launch_bounds__(256, 3) void gat_aggregate_tiled_kernel(TiledArgs a) {
+// (8 heads: the halo's alpha_src table takes the block's LDS past a third of the CU's -- two workgroups per CU there)
+__global__ __launch_bounds__(256, (HC / C >= 8 ? 2 : 3)) void gat_aggregate_tiled_kernel(TiledArgs a) {
   static_assert(TH == TILE_H && TW == TILE_W, "one thread per cell of a 16x16 block");
   constexpr int H = HC / C;
   constexpr int HW_ = HALO_W, HR = HALO_ROWS;

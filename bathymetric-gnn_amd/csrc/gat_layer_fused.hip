@@ -85,6 +85,7 @@ struct FusedArgs {
   void *out;              // [rows][NC]  f32, or bf16 with SP = 3
   float *asd_out;         // [rows][2*H2]
   int H2, C2;
+  float w_inv;            // SP = 2: the float16 weight image holds W * 2^S (bgnn_api.hip pack_split); accumulators *= 2^-S before the epilogue
   const float *W0af;      // layer 0 "aggregate first" (gat_layer_bf16_2p_kernel, AF): the folded lin_0 weight as per-head 64 x 64 bf16 images
   // EPI_HEADS
   const float *hd_tab;    // [HEADW] b0 [96] | second-layer rows (cls [classes], conf, corr) at 96 + 32 j | their biases at 288
@@ -1211,6 +1212,13 @@ __global__ __launch_bounds__(256, (AGG != 0 && K == 16 ? 2 : FusedLds<HC, C, K, 
     }
   }
 
+  if constexpr (SP == 2) {                              // the float16 image holds W * 2^S (bgnn_api.hip pack_split): exact power-of-two rescale
+    const float wi = a.w_inv;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] *= wi;
+  }
   const float *attl = attr;                             // att_src | att_dst (DMA'd there during slab 0)
   // exact / split paths: the store patches below stay inside the slab region, which every wave left at the last slab's
   // second barrier -- a wave goes straight from its last MFMA into its own epilogue.  bf16 storage: the slab region is
@@ -2528,6 +2536,7 @@ int launch_fused_layer_next(bgnn_ctx *ctx, const bgnn_graph *g, const BgnnLayer 
   int split = ctx->opts.matrix_path;                                   // 0 exact, 1 bf16x3, 2 fp16x3 (opt-in), 3 bf16 storage
   if (split == 2 && !Ln.Wsp16) split = 1;                              // a weight beyond float16's range: bf16 split instead
   a.Wt = split == 3 ? Ln.Wbf : split == 2 ? Ln.Wsp16 : split == 1 ? Ln.Wsp : Ln.Wfp;
+  a.w_inv = Ln.Wsp16_inv;
   a.att_src = Ln.att_src; a.att_dst = Ln.att_dst; a.out = xw_next; a.asd_out = asd_next;
   a.H2 = Ln.heads; a.C2 = C;
   ProfScope ps(ctx, BGNN_K_FUSED);
@@ -2620,6 +2629,7 @@ int launch_fused_layer_heads(bgnn_ctx *ctx, const bgnn_graph *g, const bgnn_mode
   if (split == 2 && !m->hd_W0sp16) split = 1;
   if ((split == 1 || split == 2) && g->K == 16) split = 0;
   a.Wt = split == 3 ? m->hd_W0bf : split == 2 ? m->hd_W0sp16 : split == 1 ? m->hd_W0sp : m->hd_W0fp;
+  a.w_inv = m->hd_W0sp16_inv;
   a.hd_tab = m->hd_tab;
   a.local_std = g->d_local_std;
   a.classes = m->desc.num_classes; a.hh = C / 2; a.has_corr = m->desc.predict_correction;

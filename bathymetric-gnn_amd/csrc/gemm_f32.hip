@@ -48,6 +48,7 @@ struct GemmArgs {
   // one 256-column block of a wider layer (generic kernel only): the attention dots of this block's heads go to columns
   // asd_hd0 .. of the [M][2 asd_H] table (0 / 0: the whole layer in one launch, asd_H = H)
   int asd_H, asd_hd0;
+  float w_inv;            // SP = 2: the float16 weight image holds W * 2^S; the accumulators are multiplied by 2^-S
 };
 
 template <int NT>
@@ -548,6 +549,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wres64_kernel(GemmArgs a) {
             acc[t] = mfma_lp(wh, xh, acc[t]);
           }
         }
+        if constexpr (SP == 2) {                       // the image holds W * 2^S (bgnn_api.hip pack_split): exact power-of-two rescale
+          const float wi = a.w_inv;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] *= wi;
+        }
       }
     } else if (!(BGNN_DIAG && (a.dbg & 2)))
 #pragma unroll
@@ -851,7 +859,7 @@ bool gemm_front_available(const bgnn_ctx *ctx, int64_t max_rows, int NC, int spl
 int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, const float *bias, float *Y, int ldy,
                     const int64_t *d_m, int64_t max_rows, int K, int NC, int relu, const float *att_src,
                     const float *att_dst, float *asd, int H, int C, const float *Wt_split, int split_mode,
-                    const float *front_W0t, const float *front_b0, const float *Wt_pm, const float *Wt_blk) {
+                    const float *front_W0t, const float *front_b0, const float *Wt_pm, const float *Wt_blk, float split_inv_scale) {
   if (NC > 256) {
     // a layer wider than 256 columns (heads x hidden up to 512): one launch of the generic kernel per 256-column block of the
     // blocked weight image; a block's heads write their attention dots into their columns of the shared [M][2 H] table.  The opt-in
@@ -863,7 +871,7 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
       ProfScope ps(ctx, BGNN_K_GEMM);
       GemmArgs a{X, Wt_blk + (size_t)b * K * 256, bias ? bias + b * 256 : nullptr, Y + b * 256, d_m, att_src ? att_src + b * 256 : nullptr,
                  att_dst ? att_dst + b * 256 : nullptr, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, att_src ? 256 / C : 0, C, 0, nullptr, nullptr,
-                 att_src ? H : 0, att_src ? b * (256 / C) : 0};
+                 att_src ? H : 0, att_src ? b * (256 / C) : 0, 1.0f};
       if (max_rows <= 0) return BGNN_OK;
       dim3 grid((unsigned)((max_rows + 127) / 128)), block(256);
       if (att_src) hipLaunchKernelGGL((gemm_f32_kernel<8, true>), grid, block, 0, ctx->stream, a);
@@ -878,7 +886,8 @@ int launch_gemm_f32(bgnn_ctx *ctx, const float *X, int ldx, const float *Wt, con
   if (max_rows <= 0) return BGNN_OK;
   ProfScope ps(ctx, BGNN_K_GEMM);
   const int gemm_dbg = BGNN_DIAG ? ctx->opts.gemm_diag : 0;
-  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg, front_W0t, front_b0, 0, 0};
+  GemmArgs a{X, Wt, bias, Y, d_m, att_src, att_dst, asd, ctx->zero_page + 2048, ldx, ldy, K, relu, H, C, gemm_dbg, front_W0t, front_b0, 0, 0,
+             split_mode == 2 ? split_inv_scale : 1.0f};
   if (front_W0t) BGNN_REQUIRE(K == 64 && att_src && gemm_front_available(ctx, max_rows, NC, split_mode) && (split_mode != 3 || Wt_split),
                               "gemm: the fused front needs the W-resident K = 64 attention form");
   const bool no_wres = ctx->opts.gemm_no_wres != 0;

@@ -931,6 +931,14 @@ def main():
                     # (brief, in the line: what the opt-in operand-split paths give and how far their logits are from the headline path's)
                     line.setdefault("opt_in_split", {"note": "not the headline; max |dlogit| vs the exact-f32 path"})[env] = {
                         "value": detail[key]["value"], "max_dlogit": detail[key]["max_abs_logit_diff_vs_exact_f32"]}
+                # distance to the float64 forward: measured by the -m gpu suite against the oracle (test_matrix_paths_distance_to_float64),
+                # not by this run -- the committed record of that test is quoted (max over its two tiles)
+                rec = os.path.join(ROOT, "profiles", "split_accuracy.json")
+                if os.path.exists(rec) and "opt_in_split" in line:
+                    acc = json.load(open(rec))
+                    worst = lambda k: max(float(v[k]["max"]) for v in acc.values() if isinstance(v, dict) and k in v)
+                    line["opt_in_split"]["max_dist_to_float64"] = {"exact_f32": worst("exact_f32_mfma"), "fp16x3": worst("fp16x3"), "bf16x3": worst("bf16x3"),
+                                                                  "source": "profiles/split_accuracy.json (GPU test suite vs the float64 oracle)"}
             guarded("split_paths", _splits)
             # ---- the other single-GPU BASELINE configs, same protocol (rank 0, N = 1), each with its own roofline ----------
             k_x, w_x = max(4, min(args.steps, 10)), 2

@@ -742,7 +742,11 @@ def test_matrix_paths_distance_to_float64(gpu_device):
         report[name] = row
         print(name, json.dumps(row))
         assert row["exact_f32_mfma"]["max"] < TOL and row["fp16x3"]["max"] < TOL and row["bf16x3"]["max"] < TOL
-        assert row["fp16x3"]["max"] < 4 * max(row["exact_f32_mfma"]["max"], row["cpu_float32"]["max"])   # float32-grade
+        # fp16x3 with the weight images scaled into float16's normal range (round 5): no farther from the float64 forward than the
+        # exact-f32 path itself (it was 2.4 x farther while the weights' lo parts sat in the subnormal range) -- 10 % slack for the
+        # run-to-run differences of which elements round which way
+        assert row["fp16x3"]["max"] < 1.1 * row["exact_f32_mfma"]["max"] + 2e-8, row
+        assert row["fp16x3"]["rms"] < 1.1 * row["exact_f32_mfma"]["rms"] + 1e-9, row
         assert row["bf16x3"]["max"] < 5e-5
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):
