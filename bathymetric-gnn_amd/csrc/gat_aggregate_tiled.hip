@@ -31,6 +31,8 @@ struct TiledArgs {
 
 template <int HC, int C, int K, int TH, int TW>
 // (8 heads: the halo's alpha_src table takes the block's LDS past a third of the CU's -- two workgroups per CU there)
+// (the 16-slab instances -- 512 columns -- are not fully unrolled by hipcc: the slab's head index stays a run-time value there and the
+//  coefficient array lives in scratch, 160 / 304 B per lane; rare shapes, still 3x the thread-per-node kernel they replace)
 __global__ __launch_bounds__(256, (HC / C >= 8 ? 2 : 3)) void gat_aggregate_tiled_kernel(TiledArgs a) {
   static_assert(TH == TILE_H && TW == TILE_W, "one thread per cell of a 16x16 block");
   constexpr int H = HC / C;
