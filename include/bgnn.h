@@ -62,7 +62,9 @@ void *bgnn_ctx_stream(bgnn_ctx *ctx);
 
 /* Run-time switches of a context (all int-valued).  Defaults are taken from the environment ONCE, when the context is
  * created (the variable in brackets); afterwards only this call changes them:
- *   "matrix_path"     0 exact f32 (default), 1 bf16x3, 2 fp16x3: opt-in operand-split MFMA paths [BGNN_SPLIT_BF16 / BGNN_SPLIT_F16];
+ *   "matrix_path"     0 exact f32 (default), 1 bf16x3, 2 fp16x3: opt-in operand-split MFMA paths [BGNN_SPLIT_BF16 / BGNN_SPLIT_F16]
+ *                     (hi + lo parts of both operands, three 16-bit MFMAs, float32 accumulate; fp16x3 keeps its weight images scaled
+ *                     into float16's normal range and lands as close to a float64 forward as the exact path, while |activations| < 65504);
  *                     3 bf16: layer activations stored as bf16 in HBM and multiplied on the bf16 MFMA, float32 softmax /
  *                     aggregation / accumulation (BASELINE config 3 "bf16 node features"; no 1e-4 contract) [BGNN_BF16]
  *   "fused"           1 (default): K4 fused with the next K3 / K5 + K6; 0: separate kernels           [BGNN_NO_FUSED]
